@@ -1,0 +1,295 @@
+"""Oracle (test infrastructure): problem solvers, restating /root/reference/solvers/*.m.
+
+Each function performs the reference solver's one-time setup (Gram matrix,
+Cholesky, pseudo-inverse, difference operator), builds the same ``options``
+constraint fields and calls the oracle's ``getproxops`` + ``admm``.  MATLAB's
+parallel pool size (``gcp().NumWorkers``) is passed explicitly as ``workers``.
+Parity pin status: see ``oracle/__init__.py``.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+from .admm_ref import admm
+from .proxops_ref import getproxops
+
+
+def slicemaker(slices, workers, length):
+    """errorcheck.m:216-267.  Returns a list of slice sizes."""
+    sl = np.atleast_1d(np.floor(np.real(np.asarray(slices, dtype=np.float64)))).astype(np.int64)
+    if sl.size == 1 and sl[0] > 0:
+        # 238-243 (bug q13: when `length` divides evenly, the last full slice is
+        # overwritten by mod(len, size) = 0 -- restated literally).
+        size = int(sl[0])
+        nfull = length // size
+        out = [size] * nfull
+        last = -(-length // size)  # ceil
+        while len(out) < last:
+            out.append(0)
+        out[last - 1] = length % size
+        return out
+    if sl.size == 1 and sl[0] == 0:
+        if length % workers != 0:  # 249-255
+            rem = length % workers
+            size = length // workers
+            return [size + 1] * rem + [size] * (workers - rem)
+        return [length // workers] * workers  # 258
+    if int(sl.sum()) != length:
+        raise ValueError("The number of parallel slices does not match length of x!")
+    return [int(k) for k in sl]
+
+
+def huber_cvx(x):
+    """CVX ``huber`` (huberfit.m:180): x^2 if |x|<=1 else 2|x|-1."""
+    ax = np.abs(x)
+    return np.where(ax <= 1.0, x * x, 2.0 * ax - 1.0)
+
+
+def lasso(D, s, lam, options=None, workers=1):
+    """solvers/lasso.m:77-245."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    rho = float(options.get("rho", 1.0))
+    parallel = options.get("parallel", "none") in ("both", "zming", "xminf")  # 144-156
+    if parallel:
+        options["parallel"] = "none"
+        options["stopcond"] = "both"
+    m, n = D.shape
+    if not parallel:  # 159-192
+        Dts = D.T @ s
+        if m >= n:
+            L = sla.cholesky(D.T @ D + rho * np.eye(n), lower=True)
+        else:
+            L = sla.cholesky((D @ D.T) / rho + np.eye(m), lower=True)
+        args = dict(D=D, Dts=Dts, L=L, U=L.T, m=m, n=n)
+        args["lambda"] = lam
+        args["parallel"] = 0
+        args["rho"] = rho
+        minx, minz, extra = getproxops("LASSO", args)
+    else:  # 193-224
+        slices = options.get("slices", 0)
+        slices = np.atleast_1d(slices)[0]  # lasso.m:197 takes only slices(1)
+        slices = slicemaker(slices, workers, m)
+        args = dict(slices=slices, D=D, s=s, rho=rho, parallel=1)
+        args["lambda"] = lam
+        minx, minz, extra = getproxops("LASSO", args)
+        options["altu"] = extra["altu"]
+        options["specialnorms"] = extra["specialnorms"]
+    options["obj"] = lambda x, z: 0.5 * float(np.sum((D @ x - s) ** 2)) + lam * float(np.sum(np.abs(z)))  # 227
+    options.update(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, parallel="none")  # 232-239
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    if parallel:
+        results["_consensus"] = extra  # oracle-side: true consensus z lives in extra["_state"]["z"]
+    return results
+
+
+def lad(D, s, options=None):
+    """solvers/lad.m:51-154."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    m, n = D.shape
+    args = dict(D=D, s=s)
+    if options.get("relax", 1) != 1:  # 124-126
+        args["userelax"] = 1
+    args["R"] = sla.cholesky(D.T @ D, lower=True)  # 134 (un-shifted, q20)
+    minx, minz, _ = getproxops("lad", args)
+    options.update(A=D, B=-1, c=s, m=m, nA=n, nB=m)  # 140-145
+    options["obj"] = lambda x, z: float(np.sum(np.abs(z)))  # 148
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def huberfit(D, s, options=None):
+    """solvers/huberfit.m:83-186."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    m, n = D.shape
+    args = dict(D=D, s=s)
+    if options.get("relax", 1) != 1:
+        args["userelax"] = 1
+    args["R"] = sla.cholesky(D.T @ D, lower=True)  # 166
+    minx, minz, _ = getproxops("huberfit", args)
+    options.update(A=D, B=-1, c=s, m=m, nA=n, nB=m)
+    options["obj"] = lambda x, z: 0.5 * float(np.sum(huber_cvx(z)))  # 180
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def tv_operator(n):
+    """totalvariation.m:127  D = spdiags([ones -ones], 0:1, n, n)."""
+    return sp.diags([np.ones(n), -np.ones(n - 1)], [0, 1], shape=(n, n), format="csr")
+
+
+def totalvariation(s, lam, options=None):
+    """solvers/totalvariation.m:62-167."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    s = np.asarray(s, dtype=np.float64).reshape(-1)
+    n = s.size
+    D = tv_operator(n)
+    Dt = D.T.tocsr()
+    DtD = (Dt @ D).tocsc()
+    objective = lambda x, z: 0.5 * float(np.sum((x - s) ** 2)) + lam * float(np.sum(np.abs(x[1:] - x[:-1])))  # 134-135
+    args = dict(D=D, Dt=Dt, DtD=DtD, s=s)
+    args["lambda"] = lam
+    xmin, zmin, _ = getproxops("TotalVariation", args)
+    options.update(A=D, At=Dt, B=-1, nB=n, c=0, m=n)  # 151-157
+    options["obj"] = objective
+    results = admm(xmin, zmin, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def unwrappedadmm(zming, D, options=None, workers=1, keep_init=True):
+    """solvers/unwrappedadmm.m:1-143.
+
+    ``keep_init`` (documented deviation q14): explicit ``x0/z0/u0`` win over the
+    reference's unconditional ``rand`` so that runs are reproducible.
+    """
+    options = dict(options or {})
+    m, n = D.shape
+    par = options.get("parallel", "none") in ("xminf", "zming", "both")
+    if par:  # 45-74
+        options["parallel"] = "zming" if options["parallel"] == "both" else "none"
+        slices = slicemaker(options.get("slices", 0), workers, m)
+        options["slices"] = slices
+        starts = np.concatenate([[0], np.cumsum(slices)])
+        st = {}
+
+        def preprocess():  # 96-123
+            W = np.zeros((n, n))
+            for i in range(len(slices)):
+                Di = D[starts[i]:starts[i + 1], :]
+                W = W + Di.T @ Di
+            st["W"] = W
+
+        def proxf(_x, z, u, _rho):  # 125-141
+            d = 0
+            for i in range(len(slices)):
+                lo, hi = starts[i], starts[i + 1]
+                d = d + D[lo:hi, :].T @ (z[lo:hi] - u[lo:hi])
+            return np.linalg.solve(st["W"], d)
+
+        xminf = proxf
+        options["preprocess"] = preprocess
+    else:  # 76-78
+        Dplus = np.linalg.pinv(D)
+        xminf = lambda _x, z, u, _rho: Dplus @ (z - u)
+    options.update(A=D, At=D.T, B=-1, nB=m, c=0, m=m)
+    rng = np.random.default_rng(0)
+    for key, size in (("x0", n), ("z0", m), ("u0", m)):  # 87-89
+        if not (keep_init and key in options):
+            options[key] = rng.random(size)
+    options["maxiters"] = 1000  # 90
+    options["stopcond"] = "both"
+    options["nodualerror"] = 1
+    if options.get("parallel") == "zming":
+        # admm.m:397-407, 447-467: zming(x,z,u,rho,k) per slice, concatenated.
+        sl = options["slices"]
+        zi = zming
+        zming = lambda x, z, u, rho: np.concatenate([zi(x, z, u, rho, k) for k in range(len(sl))])
+        options["parallel"] = "none"
+    return admm(xminf, zming, options)
+
+
+def linearsvm(D, ell, C, options=None, workers=1):
+    """solvers/linearsvm.m:92-246."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    loss = options.get("lossfunction", "hinge")  # 154-158
+    par = options.get("parallel", "none") in ("both", "zming", "xminf")
+    args = dict(D=D, Dt=D.T, ell=ell, C=C, lossfunction=loss)
+    if par:
+        options["parallel"] = "both"  # 174
+        args["slices"] = slicemaker(options.get("slices", 0), workers, D.shape[0])
+        options["slices"] = args["slices"]
+    else:
+        args["Dplus"] = np.linalg.pinv(D)  # 185
+    _, minz, _ = getproxops("LinearSVM", args)
+    if loss == "hinge":  # 231-237
+        options["obj"] = lambda x, z: 0.5 * float(x @ x) + C * float(np.sum(np.maximum(1 - ell * (D @ x), 0)))
+    else:
+        options["obj"] = lambda x, z: 0.5 * float(x @ x) + C * float(np.sum(np.maximum(np.sign(1 - ell * (D @ x)), 0)))
+    results = unwrappedadmm(minz, D, options, workers=workers)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def basispursuit(D, s, options=None):
+    """solvers/basispursuit.m:52-145."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    n = D.shape[1]
+    DDt = D @ D.T
+    P = np.eye(n) - D.T @ np.linalg.solve(DDt, D)  # 116-119
+    q = D.T @ np.linalg.solve(DDt, s)  # 120
+    minx, minz, _ = getproxops("BasisPursuit", dict(P=P, q=q))
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = lambda x, z: float(np.sum(np.abs(x)))  # 140
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def model(P, Q, r, s, options=None):
+    """solvers/model.m:47-143."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    n = P.shape[1]
+    args = dict(PtP=P.T @ P, Ptr=P.T @ r, QtQ=Q.T @ Q, Qts=Q.T @ s, n=n)
+    minx, minz, _ = getproxops("Model", args)
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = lambda x, z: 0.5 * float(np.sum((P @ x - r) ** 2)) + 0.5 * float(np.sum((Q @ z - s) ** 2))
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def quadraticprogram_bounded(P, q, r, lb, ub, options=None):
+    """solvers/quadraticprogram.m:99-246, 'bounded' constraint branch (210-219)."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    n = P.shape[0]
+    rho = float(options.get("rho", 1.0))
+    args = dict(P=P, q=q, lb=lb, ub=ub, rho=rho, n=n, constraint="bounded")
+    minx, minz, _ = getproxops("quadraticprogram", args)
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = lambda x, z: 0.5 * float(x @ (P @ x)) + float(q @ x) + r  # 242
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def quadraticprogram_standard(P, q, r, D, s, options=None):
+    """solvers/quadraticprogram.m, 'standard' constraint branch (193-209)."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    n = P.shape[0]
+    rho = float(options.get("rho", 1.0))
+    args = dict(P=P, q=q, D=D, s=s, rho=rho, n=n, constraint="standard")
+    minx, minz, _ = getproxops("quadraticprogram", args)
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = lambda x, z: 0.5 * float(x @ (P @ x)) + float(q @ x) + r
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def linearprogram(b, D, s, options=None):
+    """solvers/linearprogram.m:81-185."""
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    n = D.shape[1]
+    minx, minz, _ = getproxops("LinearProgram", dict(D=D, b=b, s=s, n=n))
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = lambda x, z: float(b @ x)  # 180
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
