@@ -1,0 +1,295 @@
+"""The reference's plug-in surface on top of the HIP engine.
+
+    [minx, minz, extra] = getproxops(problem, args)      (getProxOps.m:13)
+    results             = admm(xminf, zming, options)    (admm.m:24)
+
+``getproxops`` returns *descriptor* prox operators: objects that name an engine-native
+x-/z-update and share one device-resident problem (data + cached factor).  When ``admm``
+receives a matching pair it runs the whole loop (admm.m:496-743) on the device through
+the C ABI.  ``options`` and ``results`` are dicts with the reference's field names.
+There is no CPU fallback: user-supplied Python callables are rejected loudly.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+
+__all__ = ["admm", "getproxops", "ProxOp"]
+
+_PROBLEMS = ("model", "basispursuit", "totalvariation", "linearsvm", "lasso", "linearprogram",
+             "quadraticprogram", "covarianceselection", "lad", "huberfit")
+
+
+class _Problem:
+    """Shared state behind a (minx, minz) pair: what getproxops' closure captured."""
+
+    def __init__(self, kind, engine, expect, extra=None):
+        self.kind = kind
+        self.engine = engine
+        self.expect = expect  # constraint the solver must pass to admm: dict(A=..., c=..., nA, nB)
+        self.extra = extra or {}
+
+
+class ProxOp:
+    """Descriptor of an engine-native proximal operator (role 'x' or 'z')."""
+
+    def __init__(self, problem, role):
+        self.problem = problem
+        self.role = role
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(
+            "engine-native proximal operators run inside admm(); calling one on host arrays "
+            "would need a CPU path, which this package does not have")
+
+    def __repr__(self):
+        return f"<ProxOp {self.problem.kind}:{self.role}>"
+
+
+def _get(args, name):
+    if name not in args:
+        raise KeyError(f"args.{name} is required for this problem (getProxOps.m)")
+    return args[name]
+
+
+def getproxops(problem, args):
+    """Prox-operator factory (getProxOps.m:13-917).  ``args`` uses the reference's field names.
+
+    Engine-side extensions: the cached factor (``args.L``/``args.U``/``args.R``) and
+    ``args.Dts`` may be omitted -- they are then built on the device (MFMA Gram + blocked
+    Cholesky) instead of being passed in from host MATLAB code; ``args.xsolve`` selects how
+    the factor is applied ('trsv' | 'inverse'); ``args.device`` the GPU ordinal.
+    """
+    if not isinstance(problem, str):
+        raise TypeError("Given problem argument is not a string specifying for which problem "
+                        "proximal operators are needed!")
+    if not isinstance(args, dict):
+        raise TypeError("Given struct args is not a struct containing arguments needed for "
+                        "proximal operators for the given problem!")
+    kind = problem.lower()
+    if kind not in _PROBLEMS:
+        raise ValueError("Invalid input for problem - given string is not a solver!")
+    xs = {"auto": L.XSOLVE_AUTO, "trsv": L.XSOLVE_TRSV, "inverse": L.XSOLVE_INVERSE,
+          "cg": L.XSOLVE_CG}[str(args.get("xsolve", "auto")).lower()]
+    dev = int(args.get("device", 0))
+    extra = {}
+
+    if kind == "lasso":
+        if args.get("parallel", 0):
+            raise NotImplementedError("consensus lasso (args.parallel=1) is not engine-native yet")
+        D = _get(args, "D")
+        lam = _get(args, "lambda")
+        rho = float(args.get("rho", 1.0))
+        m, n = D.shape
+        s = args.get("s")
+        if s is None:
+            raise KeyError("args.s is required (the engine forms Dts = D'*s itself)")
+        Lf = args.get("L")
+        if Lf is not None and hasattr(Lf, "toarray"):
+            Lf = Lf.toarray()  # lasso.m:175 stores the factor sparse
+        eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev)
+        prob = _Problem("lasso", eng, dict(A=1, c=0.0, nA=n, nB=n))
+    elif kind in ("lad", "huberfit"):
+        D, s = _get(args, "D"), _get(args, "s")
+        m, n = D.shape
+        code = L.PROB_LAD if kind == "lad" else L.PROB_HUBERFIT
+        eng = Engine(code, D=D, s=s, Lfactor=args.get("R"), userelax=int(bool(args.get("userelax", 0))),
+                     xsolve=xs, device=dev)
+        prob = _Problem(kind, eng, dict(A="D", c="s", nA=n, nB=m))
+    elif kind == "linearsvm":
+        D, ell, Cval = _get(args, "D"), _get(args, "ell"), _get(args, "C")
+        loss = args.get("lossfunction", "hinge")
+        m, n = D.shape
+        eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
+                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev)
+        prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
+    elif kind == "quadraticprogram":
+        if _get(args, "constraint") != "bounded":
+            raise NotImplementedError("standard-form QP (KKT solve per iteration) is not engine-native")
+        if "altproxg" in args:
+            raise NotImplementedError("args.altproxg (user prox) needs a CPU path; not supported")
+        P, q = _get(args, "P"), _get(args, "q")
+        n = P.shape[0]
+        eng = Engine(L.PROB_QP_BOUNDED, P=P, q=q, lb=_get(args, "lb"), ub=_get(args, "ub"),
+                     rho=float(_get(args, "rho")), r=float(args.get("r", 0.0)), xsolve=xs, device=dev)
+        prob = _Problem("quadraticprogram", eng, dict(A=1, c=0.0, nA=n, nB=n))
+    elif kind == "basispursuit":
+        P, q = _get(args, "P"), _get(args, "q")
+        n = P.shape[0]
+        eng = Engine(L.PROB_BASISPURSUIT, P=P, q=q, device=dev)
+        prob = _Problem("basispursuit", eng, dict(A=1, c=0.0, nA=n, nB=n))
+    else:
+        raise NotImplementedError(f"problem '{kind}' is outside the engine's hot-path scope (SURVEY.md section 8)")
+    return ProxOp(prob, "x"), ProxOp(prob, "z"), extra
+
+
+# ---------------------------------------------------------------------------------------
+def _setopt(options, name, default):
+    """admm.m:780-971.  q2: ``Hnormtol`` is read from ``Hreltol`` in the reference; accept both."""
+    if name == "Hnormtol":
+        if "Hreltol" in options:
+            return options["Hreltol"]
+        return options.get("Hnormtol", default)
+    return options.get(name, default)
+
+
+def _check_constraint(options, prob):
+    """The solver passes A, B, c, m, nA, nB (e.g. lasso.m:232-238, lad.m:140-145); they must
+    describe the same constraint the engine-native pair implements (B = -I always)."""
+    if "A" not in options:
+        raise ValueError("Must specify a matrix A in constraint Ax + Bz = c!")
+    if "B" not in options:
+        raise ValueError("Must specify a matrix B in constraint Ax + Bz = c!")
+    B = options["B"]
+    if not (np.isscalar(B) and float(B) == -1.0):
+        raise ValueError("engine-native problems use B = -1 (z enters the constraint as -z)")
+    exp = prob.expect
+    A = options["A"]
+    if exp["A"] == 1:
+        if not (np.isscalar(A) and float(A) == 1.0):
+            raise ValueError(f"{prob.kind}: constraint matrix A must be the scalar 1")
+    else:
+        if np.isscalar(A) or tuple(A.shape) != (exp["nB"], exp["nA"]):
+            raise ValueError(f"{prob.kind}: constraint matrix A must be the data matrix D")
+    c = options.get("c", None)
+    if c is None:
+        if int(options.get("m", 0)) <= 0:
+            raise ValueError("Must specify a vector c in constraint Ax + Bz = c!")
+    elif np.isscalar(c):
+        if int(options.get("m", 0)) == 0:
+            raise ValueError("Given vector c is scalar and no length m has been provided")
+        if exp["c"] == "s" and float(c) != 0.0:
+            raise ValueError("scalar non-zero c is not supported")
+    for key in ("nA", "nB"):
+        if key in options and int(options[key]) not in (0, exp[key]):
+            raise ValueError(f"options.{key} does not match the problem size")
+
+
+def admm(xminf, zming, options):
+    """Run ADMM on the device (admm.m:24).  See the module docstring."""
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    if not (isinstance(xminf, ProxOp) and isinstance(zming, ProxOp)):
+        raise NotImplementedError(
+            "admm() on MI355X needs engine-native proximal operators from getproxops(); arbitrary "
+            "host callables would require a CPU loop, which this package deliberately lacks")
+    if xminf.problem is not zming.problem or xminf.role != "x" or zming.role != "z":
+        raise ValueError("xminf/zming must be the (minx, minz) pair returned by one getproxops call")
+    prob = xminf.problem
+    eng = prob.engine
+    _check_constraint(options, prob)
+    for unsupported in ("altu", "specialnorms", "preprocess"):
+        if unsupported in options and options[unsupported] is not None:
+            raise NotImplementedError(f"options.{unsupported} (host callback) is not supported by the device loop")
+    if _setopt(options, "adaptive", 0):
+        raise NotImplementedError("options.adaptive (experimental in the reference, admm.m:724-741) is not supported")
+    par = _setopt(options, "parallel", "none")
+    if par in ("xminf", "zming", "both"):
+        raise NotImplementedError("options.parallel in-prox slicing is replaced by row-sharded engines")
+
+    quiet = _setopt(options, "quiet", 1)
+    rho = float(_setopt(options, "rho", 1.0))
+    N = _setopt(options, "maxiters", 1000)
+    N = int(math.ceil(float(np.real(N)))) if N > 0 else 1000  # admm.m:334-339
+    fast = _setopt(options, "fast", 0)
+    fasttype = _setopt(options, "fasttype", "weak")
+    alg = L.FAST_OFF
+    if fast:
+        alg = L.FAST_WEAK if fasttype == "weak" else L.FAST_STRONG
+    objevals = bool(_setopt(options, "objevals", 0))
+    convtest = bool(_setopt(options, "convtest", 0))
+    stopcond = _setopt(options, "stopcond", "standard")
+    if stopcond not in ("standard", "hnorm", "both"):
+        stopcond = "none"  # the reference's strcmp chain silently matches nothing
+    record_history = bool(options.get("record_history", 1))
+    nA, nB = prob.expect["nA"], prob.expect["nB"]
+
+    x0 = options.get("x0")
+    z0 = options.get("z0")
+    u0 = options.get("u0")
+    for name, v0, ln in (("x0", x0, nA), ("z0", z0, nB), ("u0", u0, nB)):
+        if v0 is not None and np.asarray(v0).size != ln:
+            raise ValueError(f"options.{name} has the wrong length")
+
+    summ = eng.run(rho=rho, maxiters=N, domaxiters=_setopt(options, "domaxiters", 0),
+                   relax=_setopt(options, "relax", 1), fast=alg, objevals=objevals, convtest=convtest,
+                   convtol=_setopt(options, "convtol", 1e-10),
+                   stopcond=stopcond,
+                   nodualerror=_setopt(options, "nodualerror", 0), abstol=_setopt(options, "abstol", 1e-5),
+                   reltol=_setopt(options, "reltol", 1e-3), Hnormtol=_setopt(options, "Hnormtol", 1e-6),
+                   restart=_setopt(options, "restart", 0.999), dvaltol=_setopt(options, "dvaltol", 1e-8),
+                   record_history=record_history, check_every=int(options.get("check_every", 0)),
+                   x0=x0, z0=z0, u0=u0)
+    steps = int(summ.steps)
+    results = {}
+    results["x0"] = np.zeros(nA) if x0 is None else np.array(x0, dtype=np.float64).reshape(-1)
+    results["z0"] = np.zeros(nB) if z0 is None else np.array(z0, dtype=np.float64).reshape(-1)
+    results["u0"] = np.zeros(nB) if u0 is None else np.array(u0, dtype=np.float64).reshape(-1)
+    use_h = convtest or stopcond in ("hnorm", "both")
+    if alg == L.FAST_WEAK:
+        results["dvaltol"] = _setopt(options, "dvaltol", 1e-8)
+    if use_h:
+        results["Hnormtol"] = _setopt(options, "Hnormtol", 1e-6)
+
+    if record_history:
+        results["xvals"] = eng.fetch(L.F_XVALS, nA * steps, (nA, steps))
+        results["zvals"] = eng.fetch(L.F_ZVALS, nB * steps, (nB, steps))
+        results["uvals"] = eng.fetch(L.F_UVALS, nB * steps, (nB, steps))
+        if alg != L.FAST_OFF:
+            results["vvals"] = eng.fetch(L.F_VVALS, nB * steps, (nB, steps))
+            results["uhatvals"] = eng.fetch(L.F_UHATVALS, nB * steps, (nB, steps))
+    if alg != L.FAST_WEAK:  # q8: accelerated mode records no norms/tolerances (admm.m:619-640)
+        for key, fld in (("pnorm", L.F_PNORM), ("dnorm", L.F_DNORM), ("perr", L.F_PERR), ("derr", L.F_DERR)):
+            results[key] = eng.fetch(fld, steps)
+    if alg != L.FAST_OFF:
+        results["avals"] = eng.fetch(L.F_AVALS, steps)
+        if alg == L.FAST_WEAK:
+            results["dvals"] = eng.fetch(L.F_DVALS, steps)
+            results["restarted"] = eng.fetch(L.F_RESTARTED, steps)
+    if objevals:
+        results["objevals"] = eng.fetch(L.F_OBJEVALS, steps)
+    if use_h:
+        results["Hnormsq"] = eng.fetch(L.F_HNORMSQ, steps)
+        if record_history:  # admm.m:678-681  w = [x; z; rho*u]
+            results["wvals"] = np.asfortranarray(
+                np.concatenate([results["xvals"], results["zvals"], rho * results["uvals"]], axis=0))
+
+    if not quiet and alg != L.FAST_WEAK:  # admm.m:318-330, 661-673
+        hdr = ["Iteration", "Primal Residual Norm", "Primal Error", "Dual Residual Norm", "Dual Error"]
+        if objevals:
+            hdr.append("Objective Value")
+        print("\t".join(f"{h:>20s}" if k else f"{h:>7s}" for k, h in enumerate(hdr)))
+        for i in range(steps):
+            row = (f"{i + 1:3d}\t{results['pnorm'][i]:10.4f}\t{results['perr'][i]:10.4f}\t"
+                   f"{results['dnorm'][i]:10.4f}\t{results['derr'][i]:10.4f}")
+            if objevals:
+                row += f"\t{results['objevals'][i]:10.2f}"
+            print(row)
+
+    if summ.convtest_failed_at > 0:
+        # q4 (admm.m:692-701): the reference prints a diagnostic and returns before steps/xopt/... exist
+        i = int(summ.convtest_failed_at)
+        H2, H1 = results["Hnormsq"][i - 1], results["Hnormsq"][i - 2]
+        print(f"Iteration {i}: H norms not converging to given relative tolerance: "
+              f"{(H2 - H1) / (H1 + np.finfo(float).eps):g} is not less or equal to tol. "
+              f"{_setopt(options, 'convtol', 1e-10):g}")
+        print("ADMM seems to not be converging! Please check that your proximal operators are correct!")
+        results["convtest_failed_at"] = i
+        return results
+
+    results["steps"] = steps
+    results["xopt"] = eng.fetch(L.F_XOPT, nA)
+    results["zopt"] = eng.fetch(L.F_ZOPT, nB)
+    results["uopt"] = eng.fetch(L.F_UOPT, nB)
+    if objevals:
+        results["objopt"] = float(summ.objopt)
+    results["runtime"] = float(summ.runtime_s)
+    if not quiet:
+        print(f"Elapsed time is {results['runtime']:g} seconds.", end="")
+        print(f"Number of steps to convergence: {steps:d}", end="")
+    results["options"] = options
+    return results

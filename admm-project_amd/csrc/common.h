@@ -1,0 +1,79 @@
+// common.h -- shared host/device helpers for libadmm_hip (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/admm_engine.h"
+
+namespace admm {
+
+constexpr int kWave = 64;        // CDNA wavefront width
+constexpr int kBlock = 256;      // default workgroup: 4 waves, one per SIMD
+constexpr int kMaxPartBlocks = 1024;  // cap on blocks that emit reduction partials
+
+// ---- error plumbing -------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define ADMM_HIP_TRY(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      return ::admm::fail(ADMM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    }                                                                                   \
+  } while (0)
+
+#define ADMM_TRY(expr)       \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != ADMM_OK) return _rc; \
+  } while (0)
+
+inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Device control block: lives in device memory, mirrored to pinned host memory when
+// the host polls.  Every loop kernel starts with `if (ctrl->stop) return;` so that
+// iterations enqueued speculatively after a stop condition fired are no-ops.
+struct Ctrl {
+  int32_t stop;            // a stop condition fired (admm.m:706-722) or convtest aborted
+  int32_t iter;            // completed iterations == 0-based index of the one in flight
+  int32_t steps;           // results.steps (admm.m:746)
+  int32_t convfail;        // iteration (1-based) at which convtest aborted (admm.m:692-701)
+  int32_t cg_total;        // accumulated inner CG iterations
+  int32_t pad0;
+  double acurr, aprev;     // fast ADMM alpha (admm.m:271-272, 567, 578)
+  double d, dprev;         // accelerated ADMM restart value (admm.m:278-279, 572-588)
+  double coef;             // (aprev-1)/acurr for the extrapolation in flight
+  double restart_flag;     // 1 if the iteration in flight restarted
+};
+
+#ifdef __HIPCC__
+// ---- wave / block reductions (wave64 shuffles, then LDS across the 4 waves) -------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// Sum over the block; result valid in thread 0.  `scratch` holds >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();  // protect scratch reuse across consecutive calls
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) r += scratch[w];
+  }
+  return r;
+}
+#endif
+
+}  // namespace admm

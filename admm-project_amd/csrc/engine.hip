@@ -1,0 +1,981 @@
+// engine.hip -- C ABI (include/admm_engine.h) and the host side of the device-resident
+// ADMM loop.  create() = the reference solver's one-time setup + getproxops (lasso.m:160-192,
+// lad.m:129-137, huberfit.m:161-169, linearsvm.m:183-217 + unwrappedadmm.m:76-92,
+// quadraticprogram.m:210-232, basispursuit.m:116-127); run() = admm.m:252-767.
+#include <chrono>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "kernels.h"
+#include "loop_kernels.h"
+
+namespace admm {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+struct DevMem {  // owns every device allocation of an engine
+  std::vector<void*> ptrs;
+  int alloc(double** out, size_t elems) {
+    void* p = nullptr;
+    if (elems == 0) elems = 1;
+    hipError_t e = hipMalloc(&p, elems * sizeof(double));
+    if (e != hipSuccess)
+      return fail(ADMM_E_DEVICE, std::string("hipMalloc(") + std::to_string(elems * sizeof(double)) +
+                                     " B): " + hipGetErrorString(e));
+    ptrs.push_back(p);
+    *out = static_cast<double*>(p);
+    return ADMM_OK;
+  }
+  void release() {
+    for (void* p : ptrs) (void)hipFree(p);
+    ptrs.clear();
+  }
+};
+
+struct KTimer {  // per-kernel-class HIP event timing on the engine's stream (bench roofline leg)
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+}  // namespace admm
+
+using namespace admm;
+
+struct admm_comm;  // comm.hip
+namespace admm {
+int comm_allreduce_device(admm_comm* comm, double* buf, size_t count, hipStream_t stream);
+int comm_nranks(admm_comm* comm);
+}  // namespace admm
+
+struct admm_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevMem mem;
+  admm_comm* comm = nullptr;
+
+  int problem = 0;
+  int64_t m = 0, n = 0;  // D is m x n (local rows)
+  int64_t nA = 0;        // length of x
+  int64_t len = 0;       // nB = length of z, u, c
+  bool a_identity = true;
+  int prox = PROX_SOFT;
+  int rhs_kind = RHS_NONE;
+  int xsolve = ADMM_XSOLVE_TRSV;
+  bool fat = false;      // lasso with m < n (getProxOps.m:1201-1205)
+  double lambda = 0, C = 0, rconst = 0, rho_factor = 1.0;
+  int loss = 0;
+
+  // data
+  double* D = nullptr;
+  int64_t ldD = 0;
+  double *s = nullptr, *ell = nullptr, *q = nullptr, *lb = nullptr, *ub = nullptr;
+  double* c = nullptr;      // constraint vector (alias of s) or null
+  double cnorm = 0.0;
+  double* rhs_add = nullptr;  // Dts (lasso) or q (QP)
+  double* Pmat = nullptr;     // QP P (for the objective) or BP projector
+  int64_t ldP = 0;
+
+  // cached factor
+  double* F = nullptr;  // lower Cholesky factor, nF x nF
+  int64_t nF = 0, ldF = 0;
+  double* dinv = nullptr;
+  double* Minv = nullptr;  // explicit inverse (symmetric, full), ld = ldF
+  TrsvPlan trsv{};
+  double* trsv_work = nullptr;
+
+  // GEMV plans + partial buffers
+  GemvNPlan planDN{};   // D*x
+  GemvTPlan planDT{};   // D'*v
+  GemvNPlan planSq{};   // square nA x nA GEMV (Minv or P)
+  double *partDN = nullptr, *partDT = nullptr, *partSq = nullptr;
+
+  // iterates
+  double *x = nullptr, *z = nullptr, *u = nullptr, *rhs = nullptr, *dz = nullptr, *g = nullptr;
+  int64_t ldg = 0;
+  double *v = nullptr, *uhat = nullptr, *zprev = nullptr, *uprev = nullptr;
+  double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
+  double* part = nullptr;     // [S_COUNT][kMaxPartBlocks]
+  double* objpart = nullptr;  // [kMaxPartBlocks]
+  Ctrl* ctrl = nullptr;
+  Ctrl* ctrl_host = nullptr;  // pinned
+
+  // histories of the last run
+  int32_t hist_cap = 0;
+  bool hist_vectors = false, hist_fast = false;
+  double *xhist = nullptr, *zhist = nullptr, *uhist = nullptr, *vhist = nullptr, *uhathist = nullptr;
+  double *pnorm = nullptr, *dnorm = nullptr, *perr = nullptr, *derr = nullptr, *objv = nullptr, *hnorm = nullptr,
+         *avals = nullptr, *dvals = nullptr, *restarted = nullptr;
+  std::vector<void*> hist_ptrs;
+  admm_options last_opts{};
+  admm_run_summary last{};
+  bool has_run = false;
+  double setup_seconds = 0.0;
+
+  bool profiling = false;
+  KTimer timers[ADMM_K_COUNT];
+};
+
+namespace {
+
+int upload(DevMem& mem, double** dst, const double* src, size_t elems, int memkind, hipStream_t stream) {
+  ADMM_TRY(mem.alloc(dst, elems));
+  ADMM_HIP_TRY(hipMemcpyAsync(*dst, src, elems * sizeof(double),
+                              memkind == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+  return ADMM_OK;
+}
+
+// copy a column-major m x n matrix into a zero-padded device buffer with leading dimension ld
+int upload_matrix(DevMem& mem, double** dst, int64_t* ld_out, const double* src, int64_t rows, int64_t cols,
+                  int64_t ld_src, int memkind, hipStream_t stream) {
+  const int64_t ld = round_up(rows, 16);
+  ADMM_TRY(mem.alloc(dst, static_cast<size_t>(ld) * cols));
+  if (ld != rows) ADMM_HIP_TRY(hipMemsetAsync(*dst, 0, sizeof(double) * ld * cols, stream));
+  ADMM_HIP_TRY(hipMemcpy2DAsync(*dst, ld * sizeof(double), src, ld_src * sizeof(double), rows * sizeof(double), cols,
+                                memkind == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                stream));
+  *ld_out = ld;
+  return ADMM_OK;
+}
+
+void free_hist(admm_engine* e) {
+  for (void* p : e->hist_ptrs) (void)hipFree(p);
+  e->hist_ptrs.clear();
+  e->xhist = e->zhist = e->uhist = e->vhist = e->uhathist = nullptr;
+  e->pnorm = e->dnorm = e->perr = e->derr = e->objv = e->hnorm = e->avals = e->dvals = e->restarted = nullptr;
+  e->hist_cap = 0;
+}
+
+int hist_alloc(admm_engine* e, double** out, size_t elems) {
+  void* p = nullptr;
+  if (elems == 0) elems = 1;
+  hipError_t err = hipMalloc(&p, elems * sizeof(double));
+  if (err != hipSuccess)
+    return fail(ADMM_E_DEVICE, std::string("hipMalloc(history ") + std::to_string(elems * sizeof(double)) +
+                                   " B): " + hipGetErrorString(err));
+  e->hist_ptrs.push_back(p);
+  *out = static_cast<double*>(p);
+  return ADMM_OK;
+}
+
+struct TimerScope {
+  admm_engine* e;
+  int which;
+  bool on;
+  size_t slot = 0;
+  TimerScope(admm_engine* eng, int w) : e(eng), which(w), on(eng->profiling) {
+    if (!on) return;
+    KTimer& t = e->timers[which];
+    if (t.used + 2 > t.ev.size()) {
+      for (int k = 0; k < 2; ++k) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        t.ev.push_back(ev);
+      }
+    }
+    slot = t.used;
+    t.used += 2;
+    (void)hipEventRecord(t.ev[slot], e->stream);
+  }
+  ~TimerScope() {
+    if (!on) return;
+    (void)hipEventRecord(e->timers[which].ev[slot + 1], e->stream);
+  }
+};
+
+void collect_timers(admm_engine* e) {
+  for (int w = 0; w < ADMM_K_COUNT; ++w) {
+    KTimer& t = e->timers[w];
+    t.total_ms = 0.0;
+    t.launches = 0;
+    for (size_t k = 0; k + 1 < t.used; k += 2) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, t.ev[k], t.ev[k + 1]) == hipSuccess) {
+        t.total_ms += ms;
+        t.launches += 1;
+      }
+    }
+    t.used = 0;
+  }
+}
+
+// ---- factor setup ------------------------------------------------------------------
+// W (nF x nF, ld) holds an SPD matrix in its lower triangle -> F (in place), dinv, optionally Minv.
+int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind) {
+  e->nF = nF;
+  e->ldF = ld;
+  e->F = W;
+  const int64_t nblk = ceil_div(nF, 64);
+  ADMM_TRY(e->mem.alloc(&e->dinv, static_cast<size_t>(nblk) * 64 * 64));
+  if (Lgiven) {
+    ADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
+    ADMM_HIP_TRY(hipMemcpy2DAsync(W, ld * sizeof(double), Lgiven, nF * sizeof(double), nF * sizeof(double), nF,
+                                  memkind == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                  e->stream));
+    launch_trtri_diag(W, nF, ld, e->dinv, e->stream);
+  } else {
+    double* infod = nullptr;
+    ADMM_TRY(e->mem.alloc(&infod, 1));
+    int32_t* info_dev = reinterpret_cast<int32_t*>(infod);
+    ADMM_TRY(cholesky_lower(W, nF, ld, info_dev, e->dinv, e->stream));
+    int32_t info = 0;
+    ADMM_HIP_TRY(hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (info != 0)
+      return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " +
+                                      std::to_string(info) + ")");
+  }
+  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+    double* X = nullptr;
+    ADMM_TRY(e->mem.alloc(&X, static_cast<size_t>(ld) * nF));
+    ADMM_TRY(trtri_lower_from_diag(W, nF, ld, e->dinv, X, ld, e->stream));
+    ADMM_TRY(e->mem.alloc(&e->Minv, static_cast<size_t>(ld) * nF));
+    // Minv = X' * X  (lower tiles, then mirrored)
+    launch_gemm(1, 0, nF, nF, nF, 1.0, X, ld, X, ld, 0.0, e->Minv, ld, true, e->stream);
+    launch_symmetrize_lower(e->Minv, nF, ld, e->stream);
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    // X is no longer needed
+    (void)hipFree(X);
+    for (auto& p : e->mem.ptrs)
+      if (p == X) p = nullptr;
+    e->planSq = gemv_n_plan(nF, nF, ld);
+    ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+  } else {
+    double* dv = e->dinv;
+    ADMM_TRY(trsv_build(W, nF, ld, &dv, &e->trsv, e->stream));
+    ADMM_TRY(e->mem.alloc(&e->trsv_work, trsv_workspace_elems(e->trsv)));
+  }
+  return ADMM_OK;
+}
+
+// out = F^-T F^-1 y  (out has nF elements).  For the INVERSE path the result is left as
+// chunk partials in partSq unless `materialize`.
+void solve_factor(admm_engine* e, const double* y, double* out) {
+  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+    launch_gemv_n(e->planSq, e->Minv, y, e->partSq, e->ctrl, e->stream);
+    launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldy, e->nF, out, e->ctrl, e->stream);
+  } else {
+    launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
+  }
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+int admm_abi_version(void) { return ADMM_ABI_VERSION; }
+const char* admm_last_error(void) { return g_last_error.c_str(); }
+
+int admm_device_count(int* count) {
+  if (!count) return fail(ADMM_E_INVALID, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(ADMM_E_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return ADMM_OK;
+}
+
+int admm_device_info(int device, char* name, size_t cap, int64_t* hbm_bytes, int32_t* cus) {
+  hipDeviceProp_t prop;
+  ADMM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name && cap > 0) {
+    std::strncpy(name, prop.gcnArchName, cap - 1);
+    name[cap - 1] = 0;
+  }
+  if (hbm_bytes) *hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+  if (cus) *cus = prop.multiProcessorCount;
+  return ADMM_OK;
+}
+
+void admm_options_default(admm_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = sizeof(admm_options);
+  o->maxiters = 1000;   // admm.m:58
+  o->rho = 1.0;         // admm.m:57
+  o->relax = 1.0;       // admm.m:60
+  o->abstol = 1e-5;     // admm.m:71
+  o->reltol = 1e-3;     // admm.m:72
+  o->Hnormtol = 1e-6;   // admm.m:73
+  o->convtol = 1e-10;   // admm.m:68
+  o->restart = 0.999;   // admm.m:282
+  o->dvaltol = 1e-8;    // admm.m:290
+  o->record_history = 1;
+}
+
+void admm_problem_desc_default(admm_problem_desc* d) {
+  if (!d) return;
+  std::memset(d, 0, sizeof(*d));
+  d->struct_size = sizeof(admm_problem_desc);
+  d->rho = 1.0;
+  d->cg_tol = 1e-12;
+  d->cg_maxit = 200;
+  d->nslices = 1;
+}
+
+int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
+  if (!desc || !out) return fail(ADMM_E_INVALID, "desc/out is NULL");
+  if (desc->struct_size != static_cast<int32_t>(sizeof(admm_problem_desc)))
+    return fail(ADMM_E_INVALID, "admm_problem_desc.struct_size mismatch (ABI version skew)");
+  *out = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  int ndev = 0;
+  ADMM_TRY(admm_device_count(&ndev));
+  if (ndev <= 0) return fail(ADMM_E_DEVICE, "no HIP device visible: the ADMM engine has no CPU fallback");
+  if (desc->device < 0 || desc->device >= ndev) return fail(ADMM_E_INVALID, "bad device ordinal");
+  ADMM_HIP_TRY(hipSetDevice(desc->device));
+
+  admm_engine* e = new admm_engine();
+  auto bail = [&](int rc) {
+    admm_engine_destroy(e);
+    return rc;
+  };
+#define E_TRY(expr)                  \
+  do {                               \
+    int _rc = (expr);                \
+    if (_rc != ADMM_OK) return bail(_rc); \
+  } while (0)
+#define E_HIP(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) return bail(fail(ADMM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+
+  e->device = desc->device;
+  e->comm = desc->comm;
+  E_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->problem = desc->problem;
+  e->m = desc->m;
+  e->n = desc->n;
+  e->lambda = desc->lambda;
+  e->C = desc->C;
+  e->rconst = desc->r;
+  e->loss = desc->loss;
+  e->rho_factor = desc->rho;
+  const int mk = desc->mem;
+  const int64_t m = desc->m, n = desc->n;
+  if (!(desc->rho > 0.0)) return bail(fail(ADMM_E_INVALID, "rho must be a positive real (lasso.m:138)"));
+
+  int xs = desc->xsolve;
+  if (xs == ADMM_XSOLVE_AUTO) xs = ADMM_XSOLVE_TRSV;
+  if (xs == ADMM_XSOLVE_CG) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=CG is not implemented yet"));
+  e->xsolve = xs;
+  if (e->comm) return bail(fail(ADMM_E_UNSUPPORTED, "row-sharded engines are not implemented yet"));
+
+  switch (desc->problem) {
+    case ADMM_PROB_LASSO: {
+      if (!desc->D || !desc->s || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "lasso needs D (m x n) and s"));
+      if (desc->lambda < 0) return bail(fail(ADMM_E_INVALID, "lambda must be a nonnegative real (lasso.m:132)"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_SOFT;
+      e->rhs_kind = RHS_RHO_DTS;
+      e->fat = m < n;
+      E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+      E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
+      e->planDN = gemv_n_plan(m, n, e->ldD);
+      e->planDT = gemv_t_plan(m, n, e->ldD);
+      E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
+      E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(3)));
+      // Dts = D'*s   lasso.m:160
+      E_TRY(e->mem.alloc(&e->rhs_add, round_up(n, 2)));
+      launch_gemv_t(e->planDT, e->D, e->s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
+      launch_sum_partials_t(e->planDT, e->partDT, 1, e->rhs_add, round_up(n, 2), nullptr, e->stream);
+      const int64_t nF = e->fat ? m : n;
+      const int64_t ld = round_up(nF, 16);
+      double* W = nullptr;
+      E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * nF));
+      if (!desc->L) {
+        E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
+        if (!e->fat) {  // lasso.m:168  chol(D'*D + rho*I)
+          launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+          launch_add_diag(W, n, ld, desc->rho, e->stream);
+        } else {  // lasso.m:172  chol(1/rho*(D*D') + I)
+          launch_gemm(0, 1, m, m, n, 1.0 / desc->rho, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+          launch_add_diag(W, m, ld, 1.0, e->stream);
+        }
+      }
+      E_TRY(factorize(e, W, nF, ld, desc->L, mk));
+      if (e->fat) {
+        E_TRY(e->mem.alloc(&e->tmpA, round_up(m, 2)));
+        E_TRY(e->mem.alloc(&e->tmpB, round_up(m, 2)));
+      }
+      break;
+    }
+    case ADMM_PROB_LAD:
+    case ADMM_PROB_HUBERFIT:
+    case ADMM_PROB_LINEARSVM: {
+      const bool svm = desc->problem == ADMM_PROB_LINEARSVM;
+      if (!desc->D || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "problem needs D (m x n)"));
+      if (!svm && !desc->s) return bail(fail(ADMM_E_INVALID, "LAD/Huber need the signal vector s"));
+      if (svm && !desc->ell) return bail(fail(ADMM_E_INVALID, "linear SVM needs the label vector ell"));
+      if (m < n) return bail(fail(ADMM_E_INVALID, "D must have full column rank (m >= n) for chol(D'*D) (lad.m:134)"));
+      e->a_identity = false;
+      e->nA = n;
+      e->len = m;
+      e->rhs_kind = RHS_T1;
+      if (desc->problem == ADMM_PROB_LAD) e->prox = PROX_SOFT;
+      else if (desc->problem == ADMM_PROB_HUBERFIT) e->prox = PROX_HUBER;
+      else e->prox = (desc->loss == ADMM_LOSS_01) ? PROX_01 : PROX_HINGE;
+      E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+      if (!svm) {
+        E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
+        e->c = e->s;  // lad.m:142  options.c = s
+      } else {
+        E_TRY(upload(e->mem, &e->ell, desc->ell, m, mk, e->stream));
+      }
+      e->planDN = gemv_n_plan(m, n, e->ldD);
+      e->planDT = gemv_t_plan(m, n, e->ldD);
+      E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
+      E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(3)));
+      const int64_t ld = round_up(n, 16);
+      double* W = nullptr;
+      E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
+      if (!desc->L) {  // lad.m:134  chol(D'*D,'lower') (un-shifted; also D^+ = (D'D)^-1 D' for the SVM)
+        E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
+        launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+      }
+      E_TRY(factorize(e, W, n, ld, desc->L, mk));
+      break;
+    }
+    case ADMM_PROB_QP_BOUNDED: {
+      if (!desc->P || !desc->q || !desc->lb || !desc->ub || n <= 0)
+        return bail(fail(ADMM_E_INVALID, "bounded QP needs P (n x n), q, lb, ub"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_BOX;
+      e->rhs_kind = RHS_RHO_MINUS_Q;
+      E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->lb, desc->lb, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->ub, desc->ub, n, mk, e->stream));
+      e->rhs_add = e->q;
+      const int64_t ld = e->ldP;
+      double* W = nullptr;
+      E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
+      if (!desc->L) {  // getProxOps.m:640-641  chol(P + rho*I)
+        E_HIP(hipMemcpyAsync(W, e->Pmat, sizeof(double) * ld * n, hipMemcpyDeviceToDevice, e->stream));
+        launch_add_diag(W, n, ld, desc->rho, e->stream);
+      }
+      E_TRY(factorize(e, W, n, ld, desc->L, mk));
+      // the objective 1/2 x'Px + q'x + r needs P*x
+      e->planSq = gemv_n_plan(n, n, ld);
+      if (!e->partSq) E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+      break;
+    }
+    case ADMM_PROB_BASISPURSUIT: {
+      if (!desc->P || !desc->q || n <= 0) return bail(fail(ADMM_E_INVALID, "basis pursuit needs P (n x n) and q"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_SOFT;
+      e->rhs_kind = RHS_DIFF;
+      E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+      e->planSq = gemv_n_plan(n, n, e->ldP);
+      E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+      e->xsolve = ADMM_XSOLVE_INVERSE;  // x = P*(z-u) + q is a GEMV by construction
+      break;
+    }
+    case ADMM_PROB_LASSO_CONSENSUS:
+    case ADMM_PROB_TOTALVARIATION:
+      return bail(fail(ADMM_E_UNSUPPORTED, "problem kind not engine-native yet"));
+    default:
+      return bail(fail(ADMM_E_INVALID, "Invalid input for problem - not a solver (getProxOps.m:916)"));
+  }
+
+  // iterates and scratch
+  const int64_t L2 = round_up(e->len, 2), N2 = round_up(e->nA, 2);
+  E_TRY(e->mem.alloc(&e->x, N2));
+  E_TRY(e->mem.alloc(&e->z, L2));
+  E_TRY(e->mem.alloc(&e->u, L2));
+  E_TRY(e->mem.alloc(&e->rhs, L2 > N2 ? L2 : N2));
+  E_TRY(e->mem.alloc(&e->v, L2));
+  E_TRY(e->mem.alloc(&e->uhat, L2));
+  E_TRY(e->mem.alloc(&e->zprev, L2));
+  E_TRY(e->mem.alloc(&e->uprev, L2));
+  if (!e->a_identity) {
+    E_TRY(e->mem.alloc(&e->dz, L2));
+    e->ldg = N2;
+    E_TRY(e->mem.alloc(&e->g, 3 * N2));
+  }
+  E_TRY(e->mem.alloc(&e->part, static_cast<size_t>(S_COUNT) * kMaxPartBlocks));
+  E_TRY(e->mem.alloc(&e->objpart, kMaxPartBlocks));
+  {
+    double* cd = nullptr;
+    E_TRY(e->mem.alloc(&cd, (sizeof(Ctrl) + 7) / 8));
+    e->ctrl = reinterpret_cast<Ctrl*>(cd);
+    E_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->ctrl_host), sizeof(Ctrl), hipHostMallocDefault));
+  }
+  // ||c||  (admm.m:650)
+  if (e->c) {
+    std::vector<double> hc(static_cast<size_t>(e->len));
+    E_HIP(hipMemcpyAsync(hc.data(), e->c, sizeof(double) * e->len, hipMemcpyDeviceToHost, e->stream));
+    E_HIP(hipStreamSynchronize(e->stream));
+    double ss = 0.0;
+    for (double vv : hc) ss += vv * vv;
+    e->cnorm = std::sqrt(ss);
+  }
+  E_HIP(hipStreamSynchronize(e->stream));
+  e->setup_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *out = e;
+  return ADMM_OK;
+#undef E_TRY
+#undef E_HIP
+}
+
+// one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
+static void x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+  TimerScope ts(e, ADMM_K_XSOLVE);
+  *axsrc = e->x;
+  *naxpart = 1;
+  *axld = 0;
+  switch (e->problem) {
+    case ADMM_PROB_LASSO:
+      if (!e->fat) {
+        if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
+          launch_gemv_n(e->planSq, e->Minv, e->rhs, e->partSq, e->ctrl, e->stream);
+          *axsrc = e->partSq;
+          *naxpart = e->planSq.nchunk;
+          *axld = e->planSq.ldy;
+        } else {
+          launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
+        }
+      } else {
+        // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
+        launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
+        launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, e->ctrl, e->stream);
+        solve_factor(e, e->tmpA, e->tmpB);
+        launch_gemv_t(e->planDT, e->D, e->tmpB, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+        const double rho = e->last_opts.rho;
+        launch_combine(e->partDT, e->planDT.nchunk, e->planDT.ldg, -1.0 / (rho * rho), e->rhs, 1.0 / rho, nullptr,
+                       e->x, e->n, e->ctrl, e->stream);
+      }
+      break;
+    case ADMM_PROB_QP_BOUNDED:
+      if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+        // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
+        GemvNPlan p = gemv_n_plan(e->nF, e->nF, e->ldF);
+        launch_gemv_n(p, e->Minv, e->rhs, e->partSq, e->ctrl, e->stream);
+        *axsrc = e->partSq;
+        *naxpart = p.nchunk;
+        *axld = p.ldy;
+      } else {
+        launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
+      }
+      break;
+    case ADMM_PROB_BASISPURSUIT:
+      launch_gemv_n(e->planSq, e->Pmat, e->rhs, e->partSq, e->ctrl, e->stream);
+      launch_combine(e->partSq, e->planSq.nchunk, e->planSq.ldy, 1.0, nullptr, 0.0, e->q, e->x, e->n, e->ctrl,
+                     e->stream);
+      break;
+    default:  // LAD / Huber / SVM: rhs already holds D'*(c + z - u) (row 0 of g)
+      solve_factor(e, e->g, e->x);
+      break;
+  }
+}
+
+int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* summary) {
+  if (!e || !opts) return fail(ADMM_E_INVALID, "engine/options is NULL");
+  if (opts->struct_size != static_cast<int32_t>(sizeof(admm_options)))
+    return fail(ADMM_E_INVALID, "admm_options.struct_size mismatch (ABI version skew)");
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  admm_options o = *opts;
+  if (!(o.rho > 0.0)) return fail(ADMM_E_INVALID, "options.rho must be positive");
+  if (o.maxiters <= 0) o.maxiters = 1000;  // admm.m:334-339
+  if (o.restart <= 0.0 || o.restart >= 1.0) o.restart = 0.999;  // admm.m:285-287
+  if (o.fast != ADMM_FAST_OFF && o.fast != ADMM_FAST_WEAK && o.fast != ADMM_FAST_STRONG)
+    return fail(ADMM_E_INVALID, "bad options.fast");
+  if (o.rho != e->rho_factor && e->F && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
+      e->problem != ADMM_PROB_LINEARSVM)
+    return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
+  if (o.relax != 1.0 && (e->problem == ADMM_PROB_LINEARSVM))
+    return fail(ADMM_E_INVALID,
+                "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");
+  if (o.relax != 1.0 && (e->problem == ADMM_PROB_LAD || e->problem == ADMM_PROB_HUBERFIT)) {
+    // lad.m:124-126 switches to the userelax closures, which take Axhat directly: same fused formula
+  }
+  e->last_opts = o;
+  const int alg = o.fast;  // 0, 1 (strong), 2 (weak)
+  const bool use_h = o.convtest || o.stopcond == ADMM_STOP_HNORM || o.stopcond == ADMM_STOP_BOTH;
+  const int64_t len = e->len, nA = e->nA;
+  const int32_t N = o.maxiters;
+
+  // ---- histories
+  free_hist(e);
+  e->hist_cap = N;
+  e->hist_vectors = o.record_history != 0;
+  e->hist_fast = alg != 0;
+  if (e->hist_vectors) {
+    ADMM_TRY(hist_alloc(e, &e->xhist, static_cast<size_t>(nA) * N));
+    ADMM_TRY(hist_alloc(e, &e->zhist, static_cast<size_t>(len) * N));
+    ADMM_TRY(hist_alloc(e, &e->uhist, static_cast<size_t>(len) * N));
+    if (alg != 0) {
+      ADMM_TRY(hist_alloc(e, &e->vhist, static_cast<size_t>(len) * N));
+      ADMM_TRY(hist_alloc(e, &e->uhathist, static_cast<size_t>(len) * N));
+    }
+  }
+  double** scal[] = {&e->pnorm, &e->dnorm, &e->perr, &e->derr, &e->objv, &e->hnorm, &e->avals, &e->dvals,
+                     &e->restarted};
+  for (double** p : scal) {
+    ADMM_TRY(hist_alloc(e, p, N));
+    ADMM_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(double) * N, e->stream));
+  }
+
+  // ---- initial iterates (admm.m:252-254) and control block
+  auto init_vec = [&](double* dst, const double* src, int64_t cnt) -> int {
+    if (src) ADMM_HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyHostToDevice, e->stream));
+    else ADMM_HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * cnt, e->stream));
+    return ADMM_OK;
+  };
+  ADMM_TRY(init_vec(e->x, o.x0, nA));
+  ADMM_TRY(init_vec(e->z, o.z0, len));
+  ADMM_TRY(init_vec(e->u, o.u0, len));
+  ADMM_HIP_TRY(hipMemcpyAsync(e->v, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));     // admm.m:269
+  ADMM_HIP_TRY(hipMemcpyAsync(e->uhat, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));  // admm.m:270
+  Ctrl c0{};
+  c0.acurr = 1.0;
+  c0.aprev = 1.0;
+  c0.d = INFINITY;
+  c0.dprev = INFINITY;
+  *e->ctrl_host = c0;
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl, e->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  for (auto& t : e->timers) t.used = 0;
+
+  // ---- objective wiring (solver-supplied handles: lasso.m:227, lad.m:148, huberfit.m:180,
+  //      linearsvm.m:231-236, quadraticprogram.m:242, basispursuit.m:140)
+  ProxArgs pa{};
+  FinArgs fa{};
+  fa.obj_scale_part = 0.0;
+  pa.objz = OBJZ_NONE;
+  pa.objx = OBJX_NONE;
+  bool obj_lasso_gemv = false, obj_qp_gemv = false;
+  if (o.objevals) {
+    switch (e->problem) {
+      case ADMM_PROB_LASSO:
+        obj_lasso_gemv = true;
+        fa.obj_scale_part = 0.5;
+        pa.objz = OBJZ_ABS;
+        fa.obj_scale_z = e->lambda;
+        break;
+      case ADMM_PROB_LAD:
+        pa.objz = OBJZ_ABS;
+        fa.obj_scale_z = 1.0;
+        break;
+      case ADMM_PROB_HUBERFIT:
+        pa.objz = OBJZ_HUBER;
+        fa.obj_scale_z = 0.5;
+        break;
+      case ADMM_PROB_LINEARSVM:
+        pa.objx = (e->loss == ADMM_LOSS_01) ? OBJX_ZEROONE : OBJX_HINGE;
+        fa.obj_scale_x = e->C;
+        fa.obj_half_xnorm = 0.5;
+        break;
+      case ADMM_PROB_QP_BOUNDED:
+        obj_qp_gemv = true;
+        fa.obj_scale_part = 1.0;
+        fa.obj_const = e->rconst;
+        break;
+      case ADMM_PROB_BASISPURSUIT:
+        pa.objx = OBJX_ABS;
+        fa.obj_scale_x = 1.0;
+        break;
+      default:
+        break;
+    }
+  }
+
+  // ---- static parts of the kernel argument blocks
+  pa.len = len;
+  pa.c = e->c;
+  pa.ell = e->ell;
+  pa.lb = e->lb;
+  pa.ub = e->ub;
+  pa.z = e->z;
+  pa.u = e->u;
+  pa.uhat = e->uhat;
+  pa.v = e->v;
+  pa.zprev = e->zprev;
+  pa.uprev = e->uprev;
+  pa.dz = e->dz;
+  pa.rhs = e->rhs;
+  pa.rhs_add = e->rhs_add;
+  pa.zhist = e->zhist;
+  pa.uhist = e->uhist;
+  pa.xhist = e->a_identity ? e->xhist : nullptr;
+  pa.vhist = e->vhist;
+  pa.uhathist = e->uhathist;
+  pa.part = e->part;
+  pa.rho = o.rho;
+  pa.relax = o.relax;
+  pa.prox = e->prox;
+  pa.rhs_kind = e->rhs_kind;
+  pa.alg = alg;
+  pa.a_identity = e->a_identity ? 1 : 0;
+  switch (e->prox) {
+    case PROX_SOFT:
+      pa.t = (e->problem == ADMM_PROB_LASSO) ? e->lambda / o.rho : 1.0 / o.rho;  // getProxOps.m:455 | 810, 142
+      break;
+    case PROX_HINGE:
+      pa.t = e->C / o.rho;  // getProxOps.m:1096
+      break;
+    case PROX_01:
+      pa.t = o.rho / e->C;  // getProxOps.m:1100
+      break;
+    default:
+      pa.t = 0.0;
+      break;
+  }
+
+  fa.len = len;
+  fa.nA = nA;
+  fa.part = e->part;
+  fa.g = e->a_identity ? nullptr : e->g;
+  fa.ldg = e->ldg;
+  fa.x = e->a_identity ? nullptr : e->x;
+  fa.xhist = e->a_identity ? nullptr : e->xhist;
+  fa.cnorm = e->cnorm;
+  fa.rho = o.rho;
+  fa.rhoH = o.rho;
+  fa.abstol = o.abstol;
+  fa.reltol = o.reltol;
+  fa.Hnormtol = o.Hnormtol;
+  fa.convtol = o.convtol;
+  fa.restart = o.restart;
+  fa.dvaltol = o.dvaltol;
+  fa.alg = alg;
+  fa.a_identity = pa.a_identity;
+  fa.nodualerror = o.nodualerror;
+  fa.objevals = o.objevals;
+  fa.use_h = use_h ? 1 : 0;
+  fa.convtest = o.convtest;
+  fa.stopcond = o.stopcond;
+  fa.domaxiters = o.domaxiters;
+  fa.maxiters = N;
+  fa.pnorm = e->pnorm;
+  fa.dnorm = e->dnorm;
+  fa.perr = e->perr;
+  fa.derr = e->derr;
+  fa.objv = e->objv;
+  fa.hnorm = e->hnorm;
+  fa.avals = e->avals;
+  fa.dvals = e->dvals;
+  fa.restarted = e->restarted;
+  fa.ctrl = e->ctrl;
+
+  ExtrapArgs xa{};
+  xa.len = len;
+  xa.z = e->z;
+  xa.u = e->u;
+  xa.zprev = e->zprev;
+  xa.uprev = e->uprev;
+  xa.c = e->c;
+  xa.v = e->v;
+  xa.uhat = e->uhat;
+  xa.rhs = e->rhs;
+  xa.rhs_add = e->rhs_add;
+  xa.vhist = e->vhist;
+  xa.uhathist = e->uhathist;
+  xa.rho = o.rho;
+  xa.rhs_kind = e->rhs_kind;
+
+  const int nrhs_dual = o.nodualerror ? 1 : 3;
+  int check_every = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+
+  // ---- loop (admm.m:315 tic .. 756 toc)
+  const auto tstart = std::chrono::steady_clock::now();
+  // rhs of the first x-update from the initial iterates (zx = v = z0, ux = uhat = u0)
+  launch_initial_rhs(len, e->rhs_kind, o.rho, e->z, e->u, e->c, e->rhs_add, e->rhs, e->stream);
+  if (!e->a_identity) {
+    TimerScope ts(e, ADMM_K_GEMV_T);
+    launch_gemv_t(e->planDT, e->D, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+    launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+  }
+  int32_t enq = 0;
+  bool stopped = false;
+  while (enq < N && !stopped) {
+    const int32_t batch = (N - enq < check_every) ? N - enq : check_every;
+    for (int32_t b = 0; b < batch; ++b) {
+      const double* axsrc;
+      int32_t naxpart;
+      int64_t axld;
+      x_update(e, &axsrc, &naxpart, &axld);
+      if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        axsrc = e->partDN;
+        naxpart = e->planDN.nchunk;
+        axld = e->planDN.ldy;
+      }
+      int nblk = 1;
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        pa.axsrc = axsrc;
+        pa.naxpart = naxpart;
+        pa.axld = axld;
+        pa.x_out = e->a_identity ? e->x : nullptr;
+        launch_prox(pa, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      if (alg == 2) {
+        launch_fast_decide(fa, e->stream);
+        launch_extrapolate(xa, e->ctrl, e->stream);
+      }
+      if (!e->a_identity) {  // D'*[c+zx-ux, z-zprev, u]  (getProxOps.m:1514; admm.m:624, 654) in ONE pass
+        TimerScope ts(e, ADMM_K_GEMV_T);
+        launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs_dual, e->partDT, e->ctrl, e->stream);
+        launch_sum_partials_t(e->planDT, e->partDT, nrhs_dual, e->g, e->ldg, e->ctrl, e->stream);
+      }
+      fa.objpart = nullptr;
+      fa.nobjpart = 0;
+      if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob = 0;
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        launch_residual_sq(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->s, e->m, e->objpart, &nob, e->ctrl,
+                           e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob;
+      } else if (obj_qp_gemv) {  // 1/2 x'Px + q'x + r  (quadraticprogram.m:242)
+        int nob = 0;
+        GemvNPlan p = gemv_n_plan(e->n, e->n, e->ldP);
+        launch_gemv_n(p, e->Pmat, e->x, e->partSq, e->ctrl, e->stream);
+        launch_qp_objective(e->partSq, p.nchunk, p.ldy, e->x, e->q, e->n, e->objpart, &nob, e->ctrl, e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob;
+      }
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+    }
+    enq += batch;
+    if (!o.domaxiters || enq >= N) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      if (e->ctrl_host->stop) stopped = true;
+    }
+  }
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
+  if (e->profiling) collect_timers(e);
+
+  e->last = admm_run_summary{};
+  e->last.steps = e->ctrl_host->steps;
+  e->last.stopped_early = (e->ctrl_host->steps < N) ? 1 : 0;
+  e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.runtime_s = runtime;
+  e->last.objopt = NAN;
+  if (o.objevals && e->last.steps > 0) {  // admm.m:752-754: obj(x,z) at the final iterates == last objevals entry
+    double v = NAN;
+    ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (e->last.steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+    e->last.objopt = v;
+  }
+  e->has_run = true;
+  if (summary) *summary = e->last;
+  return ADMM_OK;
+}
+
+int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t* written) {
+  if (!e || !dst) return fail(ADMM_E_INVALID, "engine/dst is NULL");
+  if (!e->has_run && field != ADMM_F_FACTOR) return fail(ADMM_E_INVALID, "no run to fetch results from");
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  const size_t steps = static_cast<size_t>(e->last.steps);
+  const double* src = nullptr;
+  size_t count = 0;
+  bool need_vec_hist = false, need_fast = false;
+  switch (field) {
+    case ADMM_F_XOPT: src = e->x; count = e->nA; break;
+    case ADMM_F_ZOPT: src = e->z; count = e->len; break;
+    case ADMM_F_UOPT: src = e->u; count = e->len; break;
+    case ADMM_F_XVALS: src = e->xhist; count = e->nA * steps; need_vec_hist = true; break;
+    case ADMM_F_ZVALS: src = e->zhist; count = e->len * steps; need_vec_hist = true; break;
+    case ADMM_F_UVALS: src = e->uhist; count = e->len * steps; need_vec_hist = true; break;
+    case ADMM_F_VVALS: src = e->vhist; count = e->len * steps; need_vec_hist = true; need_fast = true; break;
+    case ADMM_F_UHATVALS: src = e->uhathist; count = e->len * steps; need_vec_hist = true; need_fast = true; break;
+    case ADMM_F_PNORM: src = e->pnorm; count = steps; break;
+    case ADMM_F_DNORM: src = e->dnorm; count = steps; break;
+    case ADMM_F_PERR: src = e->perr; count = steps; break;
+    case ADMM_F_DERR: src = e->derr; count = steps; break;
+    case ADMM_F_OBJEVALS: src = e->objv; count = steps; break;
+    case ADMM_F_HNORMSQ: src = e->hnorm; count = steps; break;
+    case ADMM_F_AVALS: src = e->avals; count = steps; need_fast = true; break;
+    case ADMM_F_DVALS: src = e->dvals; count = steps; need_fast = true; break;
+    case ADMM_F_RESTARTED: src = e->restarted; count = steps; need_fast = true; break;
+    case ADMM_F_FACTOR: {
+      if (!e->F) return fail(ADMM_E_INVALID, "problem has no cached factor");
+      count = static_cast<size_t>(e->nF) * e->nF;
+      if (cap < count) return fail(ADMM_E_CAPACITY, "destination too small");
+      ADMM_HIP_TRY(hipMemcpy2D(dst, e->nF * sizeof(double), e->F, e->ldF * sizeof(double), e->nF * sizeof(double),
+                               e->nF, hipMemcpyDeviceToHost));
+      // strictly-upper part of the buffer is not part of the factor
+      for (int64_t j = 1; j < e->nF; ++j)
+        for (int64_t i = 0; i < j; ++i) dst[i + j * e->nF] = 0.0;
+      if (written) *written = count;
+      return ADMM_OK;
+    }
+    default:
+      return fail(ADMM_E_INVALID, "unknown result field");
+  }
+  if (need_vec_hist && !e->hist_vectors)
+    return fail(ADMM_E_INVALID, "vector histories were not recorded (options.record_history = 0)");
+  if (need_fast && !e->hist_fast) return fail(ADMM_E_INVALID, "field exists only for fast/accelerated ADMM runs");
+  if (!src) return fail(ADMM_E_INVALID, "field not available for this run");
+  if (cap < count) return fail(ADMM_E_CAPACITY, "destination too small");
+  if (count) ADMM_HIP_TRY(hipMemcpy(dst, src, count * sizeof(double), hipMemcpyDeviceToHost));
+  if (written) *written = count;
+  return ADMM_OK;
+}
+
+int admm_engine_setup_seconds(admm_engine* e, double* seconds) {
+  if (!e || !seconds) return fail(ADMM_E_INVALID, "NULL argument");
+  *seconds = e->setup_seconds;
+  return ADMM_OK;
+}
+
+int admm_engine_set_profiling(admm_engine* e, int enabled) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  e->profiling = enabled != 0;
+  return ADMM_OK;
+}
+
+int admm_engine_kernel_time(admm_engine* e, int which, double* total_ms, int64_t* launches) {
+  if (!e || which < 0 || which >= ADMM_K_COUNT) return fail(ADMM_E_INVALID, "bad argument");
+  if (total_ms) *total_ms = e->timers[which].total_ms;
+  if (launches) *launches = e->timers[which].launches;
+  return ADMM_OK;
+}
+
+void admm_engine_destroy(admm_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  free_hist(e);
+  for (auto& t : e->timers)
+    for (hipEvent_t ev : t.ev) (void)hipEventDestroy(ev);
+  e->mem.release();
+  if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+}  // extern "C"

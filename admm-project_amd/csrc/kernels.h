@@ -1,0 +1,72 @@
+// kernels.h -- host-side launchers of the HIP kernels (all enqueue on `stream`, never sync).
+#pragma once
+#include "common.h"
+
+namespace admm {
+
+// ---------------------------------------------------------------- GEMV (gemv.hip)
+// Plan for y = D*x with column-chunk partials: ypart is [nchunk][ldy].
+struct GemvNPlan {
+  int64_t m, n, ld;
+  int64_t ldy;          // >= m, row stride between chunk partials
+  int32_t nchunk;       // number of column chunks (partials to sum)
+  int64_t cols_per_chunk;
+  size_t part_elems() const { return static_cast<size_t>(nchunk) * ldy; }
+};
+GemvNPlan gemv_n_plan(int64_t m, int64_t n, int64_t ld);
+// ypart[c][i] = sum_{j in chunk c} D[i,j]*x[j]; x may be given as the sum alpha*(xa - xb) + xc
+void launch_gemv_n(const GemvNPlan& p, const double* D, const double* x, double* ypart, const Ctrl* ctrl,
+                   hipStream_t stream);
+// y[i] = sum_c ypart[c][i]  (stand-alone reduce, used outside the fused consumers)
+void launch_sum_partials(const double* part, int32_t nchunk, int64_t ld, int64_t len, double* y, const Ctrl* ctrl,
+                         hipStream_t stream);
+
+// Plan for G = D'*[v0 v1 v2] with row-chunk partials: gpart is [nchunk][nrhs][ldg].
+struct GemvTPlan {
+  int64_t m, n, ld;
+  int64_t ldg;           // >= n
+  int32_t nchunk;        // row chunks
+  int32_t rows_per_chunk;
+  size_t part_elems(int nrhs) const { return static_cast<size_t>(nchunk) * nrhs * ldg; }
+};
+GemvTPlan gemv_t_plan(int64_t m, int64_t n, int64_t ld);
+void launch_gemv_t(const GemvTPlan& p, const double* D, const double* v0, const double* v1, const double* v2,
+                   int nrhs, double* gpart, const Ctrl* ctrl, hipStream_t stream);
+// g[r][j] = sum_c gpart[c][r][j]; g has row stride ldg_out
+void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,
+                           const Ctrl* ctrl, hipStream_t stream);
+
+// ---------------------------------------------------------------- dense setup (dense.hip)
+// C = alpha*op(A)*op(B) + beta*C, column-major fp64 on the MFMA f64 path.  transA/transB: 0 = N, 1 = T.
+// lower_only: compute only tiles that touch the lower triangle (SYRK-style symmetric results).
+void launch_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc, bool lower_only,
+                 hipStream_t stream);
+// In-place blocked lower Cholesky; info (device int) gets the failing pivot (1-based) or 0.
+// dinv (optional, [ceil(n/64)][64*64]) receives the inverted 64x64 diagonal blocks of the factor.
+int cholesky_lower(double* A, int64_t n, int64_t lda, int32_t* info_dev, double* dinv, hipStream_t stream);
+// invert the 64x64 diagonal blocks of an existing lower factor
+void launch_trtri_diag(const double* L, int64_t n, int64_t ldl, double* dinv, hipStream_t stream);
+// X = inv(L) (lower, upper part zero) from L and its inverted diagonal blocks
+int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double* dinv, double* X, int64_t ldx,
+                          hipStream_t stream);
+// mirror the lower triangle into the upper one
+void launch_symmetrize_lower(double* A, int64_t n, int64_t lda, hipStream_t stream);
+void launch_add_diag(double* A, int64_t n, int64_t lda, double shift, hipStream_t stream);
+void launch_fill(double* p, size_t n, double v, hipStream_t stream);
+
+// ---------------------------------------------------------------- TRSV (trsv.hip)
+// x = L' \ (L \ y) with pre-inverted diagonal blocks.  Workspace sized by trsv_workspace_elems.
+struct TrsvPlan {
+  int64_t n, ldl;
+  int32_t nb;              // diagonal block size
+  int32_t nblk;
+  const double* L;
+  const double* dinv;      // [nblk][nb*nb] inverted diagonal blocks (lower, column-major, ld = nb)
+};
+int trsv_build(const double* L, int64_t n, int64_t ldl, double** dinv_out, TrsvPlan* plan, hipStream_t stream);
+void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, double* work, const Ctrl* ctrl,
+                      hipStream_t stream);
+size_t trsv_workspace_elems(const TrsvPlan& p);
+
+}  // namespace admm

@@ -1,0 +1,144 @@
+// loop_kernels.h -- argument blocks of the per-iteration fused kernels (loop_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace admm {
+
+// z-prox flavours (getProxOps.m): the argument is always v = (Ax^ + u) - c
+enum ProxKind : int32_t {
+  PROX_SOFT = 0,   // sign(v).*max(abs(v)-t,0)                         933-938
+  PROX_HUBER = 1,  // (rho*v + soft(v, 1+1/rho))/(1+rho)               1529-1539
+  PROX_HINGE = 2,  // v + ell.*max(min(1-ell.*v, C/rho),0)             1084-1096
+  PROX_01 = 3,     // ell.*minz01(ell.*v, rho/C)                       1100, 1158-1180
+  PROX_BOX = 4     // min(ub,max(lb,v))                                1470-1474
+};
+
+// what the NEXT x-update's right-hand side is, written by the prox/extrapolation kernel
+enum RhsKind : int32_t {
+  RHS_NONE = 0,
+  RHS_RHO_DTS = 1,   // y = rho*(zx-ux) + Dts           lasso   getProxOps.m:1195
+  RHS_RHO_MINUS_Q = 2,  // y = rho*(zx-ux) - q          QP      getProxOps.m:1455
+  RHS_DIFF = 3,      // y = zx-ux                       basis pursuit 1031
+  RHS_T1 = 4         // t1 = c + zx - ux (then D'*t1)   LAD/Huber/SVM 1514, 1067
+};
+
+// z-side objective terms accumulated by the prox kernel
+enum ObjZKind : int32_t { OBJZ_NONE = 0, OBJZ_ABS = 1, OBJZ_HUBER = 2 };
+// Ax-side / x-side terms
+enum ObjXKind : int32_t { OBJX_NONE = 0, OBJX_HINGE = 1, OBJX_ZEROONE = 2, OBJX_ABS = 3 };
+
+// reduction slots (per-block partials, summed in block order by the finalize kernel)
+enum Slot : int32_t {
+  S_R2 = 0,    // ||Ax + Bz - c||^2                    admm.m:621
+  S_AX2 = 1,   // ||Ax||^2                             admm.m:649
+  S_Z2 = 2,    // ||Bz||^2 = ||z||^2
+  S_DZ2 = 3,   // ||z - zprev||^2                      admm.m:624 (A=I), 305
+  S_U2 = 4,    // ||u||^2                              admm.m:654 (A=I)
+  S_DU2 = 5,   // ||u - uprev||^2                      admm.m:306
+  S_OBJZ = 6,
+  S_OBJX = 7,
+  S_DUH2 = 8,  // ||u - uhat||^2                       admm.m:572
+  S_DZV2 = 9,  // ||z - v||^2                          admm.m:573
+  S_COUNT = 10
+};
+
+struct ProxArgs {
+  int64_t len;             // nB = m (B = -I)
+  const double* axsrc;     // Ax: [naxpart][axld] partials (naxpart >= 1)
+  int32_t naxpart;
+  int64_t axld;
+  double* x_out;           // A = I: x_i = sum of partials is stored here (may alias axsrc when naxpart == 1)
+  const double* c;         // nullable (c = 0)
+  const double* ell;
+  const double* lb;
+  const double* ub;
+  double* z;
+  double* u;
+  double* uhat;            // fast only
+  double* v;               // fast only
+  double* zprev;           // fast only (alg 2 needs it after the prox)
+  double* uprev;           // fast only
+  double* dz;              // A = D: z - zprev for the dual residual
+  double* rhs;             // y / t1 for the next x-update (len elements)
+  const double* rhs_add;   // Dts or q
+  double* zhist;           // [len][maxiters] or null
+  double* uhist;
+  double* xhist;           // A = I only ([len][maxiters]) or null
+  double* vhist;           // fast only
+  double* uhathist;        // fast only
+  double* part;            // [S_COUNT][kMaxPartBlocks]
+  double rho, relax, t;    // t: soft threshold | C/rho (hinge) | rho/C (01)
+  int32_t prox;
+  int32_t rhs_kind;
+  int32_t alg;             // 0 plain, 1 fast (strong), 2 accelerated (weak)
+  int32_t objz, objx;
+  int32_t a_identity;
+};
+
+struct ExtrapArgs {  // alg 2 second phase (admm.m:576-591) -> v, uhat and the next rhs
+  int64_t len;
+  const double* z;
+  const double* u;
+  const double* zprev;
+  const double* uprev;
+  const double* c;
+  double* v;
+  double* uhat;
+  double* rhs;
+  const double* rhs_add;
+  double* vhist;
+  double* uhathist;
+  double rho;
+  int32_t rhs_kind;
+};
+
+struct FinArgs {
+  int64_t len;             // nB
+  int64_t nA;
+  const double* part;      // [S_COUNT][kMaxPartBlocks]
+  int32_t nblk;            // partial blocks used by the prox kernel
+  const double* g;         // A = D: [3][ldg] = D'*[t1, dz, u]; null when A = I
+  int64_t ldg;
+  const double* x;         // A = D: current x (history copy, ||x||^2)
+  double* xhist;
+  const double* objpart;   // extra objective partials (e.g. ||Dx-s||^2 blocks) or null
+  int32_t nobjpart;
+  double obj_scale_part;   // multiplies sum(objpart)
+  double obj_scale_z;      // multiplies S_OBJZ
+  double obj_scale_x;      // multiplies S_OBJX
+  double obj_half_xnorm;   // adds this * ||x||^2
+  double obj_const;
+  double cnorm;            // ||c||
+  double rho, rhoH;
+  double abstol, reltol, Hnormtol, convtol, restart, dvaltol;
+  int32_t alg, a_identity, nodualerror, objevals, use_h, convtest, stopcond, domaxiters, maxiters;
+  double* pnorm;
+  double* dnorm;
+  double* perr;
+  double* derr;
+  double* objv;
+  double* hnorm;
+  double* avals;
+  double* dvals;
+  double* restarted;
+  Ctrl* ctrl;
+};
+
+void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+void launch_fast_decide(const FinArgs& a, hipStream_t stream);   // alg 2: d, restart decision, alpha
+void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream);
+void launch_finalize(const FinArgs& a, hipStream_t stream);
+// rhs for the very first x-update from (zx, ux): same formulas as the fused epilogue
+void launch_initial_rhs(int64_t len, int rhs_kind, double rho, const double* zx, const double* ux, const double* c,
+                        const double* rhs_add, double* rhs, hipStream_t stream);
+// sum of squares of (sum_c part[c][i] - s[i]) per block -> objpart[block]; returns blocks used
+void launch_residual_sq(const double* part, int32_t nchunk, int64_t ld, const double* s, int64_t len, double* objpart,
+                        int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
+// objpart[block] = sum_i x_i*(0.5*(sum_c part[c][i]) + q_i)   (1/2 x'Px + q'x, quadraticprogram.m:242)
+void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const double* x, const double* q,
+                         int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
+// x = alpha*(sum_c part[c][i]) + beta*y[i] + add[i]  (add/y nullable)
+void launch_combine(const double* part, int32_t nchunk, int64_t ld, double alpha, const double* y, double beta,
+                    const double* add, double* x, int64_t len, const Ctrl* ctrl, hipStream_t stream);
+
+}  // namespace admm

@@ -1,0 +1,466 @@
+// loop_kernels.hip -- the per-iteration vector work of the ADMM loop as fused kernels.
+//
+//   prox kernel     : admm.m:515-560 (relaxation, z-prox, u-update), 563-569 (fast ADMM
+//                     extrapolation), 608-610 (history), and every partial sum needed by
+//                     621-624 / 648-654 / 305-306 / 572-573, plus the NEXT x-update's rhs
+//                     (getProxOps.m:1195, 1455, 1031, 1514, 1067) -- one pass over the vectors.
+//   finalize kernel : one workgroup; sums the block partials in fixed order (bitwise
+//                     reproducible), forms pnorm/dnorm/perr/derr/Hnormsq/objective, runs the
+//                     convergence test (686-702) and the stop logic (706-722) on the device.
+// All kernels no-op once ctrl->stop is set, so the host can enqueue ahead of the stop test.
+#include "loop_kernels.h"
+
+namespace admm {
+
+__device__ __forceinline__ double soft(double v, double t) {
+  // sign(v).*subplus(abs(v) - t)   getProxOps.m:937
+  const double a = fabs(v) - t;
+  const double p = a > 0.0 ? a : 0.0;
+  return (v > 0.0) ? p : ((v < 0.0) ? -p : 0.0 * p);
+}
+
+__device__ __forceinline__ double huber_cvx(double x) {
+  const double a = fabs(x);
+  return a <= 1.0 ? x * x : 2.0 * a - 1.0;
+}
+
+__device__ __forceinline__ void block_reduce_slots(double (&acc)[S_COUNT], double* part) {
+  __shared__ double sred[4][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    part[s * kMaxPartBlocks + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+
+  double kcoef = 0.0;
+  if (a.alg == 1) {  // admm.m:504, 567: aprev = acurr; acurr = (1+sqrt(1+4 aprev^2))/2
+    const double aprev = ctrl->acurr;
+    const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+    kcoef = (aprev - 1.0) / acn;
+  }
+
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double ax = 0.0;
+    for (int32_t cidx = 0; cidx < a.naxpart; ++cidx) ax += a.axsrc[static_cast<int64_t>(cidx) * a.axld + i];
+    if (a.a_identity) {
+      if (a.x_out) a.x_out[i] = ax;
+      if (a.xhist) a.xhist[it * a.len + i] = ax;
+    }
+    const double zp = a.z[i];
+    const double u_old = a.u[i];
+    const double uo = (a.alg == 0) ? u_old : a.uhat[i];
+    const double ci = a.c ? a.c[i] : 0.0;
+    // admm.m:517  Axhat = relax*A(x) - (1-relax)*(B(zprev) - c),  B = -1
+    const double axh = (a.relax != 1.0) ? a.relax * ax - (1.0 - a.relax) * ((-zp) - ci) : ax;
+    const double v = (axh + uo) - ci;
+    double zn;
+    switch (a.prox) {
+      case PROX_SOFT:
+        zn = soft(v, a.t);
+        break;
+      case PROX_HUBER:
+        zn = 1.0 / (1.0 + a.rho) * (a.rho * v + soft(v, 1.0 + 1.0 / a.rho));
+        break;
+      case PROX_HINGE: {
+        const double l = a.ell[i];
+        const double lv = l * v;
+        zn = v + l * fmax(fmin(1.0 - lv, a.t), 0.0);
+        break;
+      }
+      case PROX_01: {
+        const double l = a.ell[i];
+        const double s = l * v;
+        const double y = ((s >= 1.0) || (s < (1.0 - sqrt(2.0 / a.t)))) ? s : 1.0;
+        zn = l * y;
+        break;
+      }
+      default:  // PROX_BOX
+        zn = fmin(a.ub[i], fmax(a.lb[i], v));
+        break;
+    }
+    const double Bz = -zn;
+    const double un = uo + ((axh + Bz) - ci);  // admm.m:542-550
+    const double r = (ax + Bz) - ci;           // admm.m:621 uses Ax, not Axhat
+    const double dzv = zn - zp;
+    acc[S_R2] += r * r;
+    acc[S_AX2] += ax * ax;
+    acc[S_Z2] += zn * zn;
+    acc[S_DZ2] += dzv * dzv;
+    acc[S_U2] += un * un;
+    const double du = un - u_old;
+    acc[S_DU2] += du * du;
+    if (a.objz == OBJZ_ABS) acc[S_OBJZ] += fabs(zn);
+    else if (a.objz == OBJZ_HUBER) acc[S_OBJZ] += huber_cvx(zn);
+    if (a.objx == OBJX_HINGE) acc[S_OBJX] += fmax(1.0 - a.ell[i] * ax, 0.0);
+    else if (a.objx == OBJX_ZEROONE) {
+      const double q = 1.0 - a.ell[i] * ax;
+      acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
+    } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
+
+    a.z[i] = zn;
+    a.u[i] = un;
+    if (a.dz) a.dz[i] = dzv;
+    if (a.zhist) a.zhist[it * a.len + i] = zn;
+    if (a.uhist) a.uhist[it * a.len + i] = un;
+
+    double zx = zn, ux = un;
+    if (a.alg == 1) {  // admm.m:568-569
+      zx = zn + kcoef * (zn - zp);
+      ux = un + kcoef * (un - u_old);
+      a.v[i] = zx;
+      a.uhat[i] = ux;
+      if (a.vhist) a.vhist[it * a.len + i] = zx;
+      if (a.uhathist) a.uhathist[it * a.len + i] = ux;
+    } else if (a.alg == 2) {  // decision needs d first: keep what the extrapolation kernel needs
+      const double vo = a.v[i];
+      const double duh = un - uo, dzv2 = zn - vo;
+      acc[S_DUH2] += duh * duh;
+      acc[S_DZV2] += dzv2 * dzv2;
+      a.zprev[i] = zp;
+      a.uprev[i] = u_old;
+    }
+    if (a.alg != 2 && a.rhs) {
+      switch (a.rhs_kind) {
+        case RHS_RHO_DTS:
+          a.rhs[i] = a.rho * (zx - ux) + a.rhs_add[i];
+          break;
+        case RHS_RHO_MINUS_Q:
+          a.rhs[i] = a.rho * (zx - ux) - a.rhs_add[i];
+          break;
+        case RHS_DIFF:
+          a.rhs[i] = zx - ux;
+          break;
+        case RHS_T1:
+          a.rhs[i] = (ci + zx) - ux;
+          break;
+        default:
+          break;
+      }
+    }
+  }
+  block_reduce_slots(acc, a.part);
+}
+
+void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.len, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(prox_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
+// ---------------------------------------------------------------- alg 2: decide + extrapolate
+__device__ __forceinline__ double sum_slot(const double* part, int slot, int nblk, double* scratch) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += part[slot * kMaxPartBlocks + b];
+  return block_sum(s, scratch);
+}
+
+__global__ __launch_bounds__(kBlock) void fast_decide_kernel(FinArgs a) {
+  Ctrl* ctrl = a.ctrl;
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  const double s_duh = sum_slot(a.part, S_DUH2, a.nblk, scratch);
+  const double s_dzv = sum_slot(a.part, S_DZV2, a.nblk, scratch);
+  if (threadIdx.x == 0) {
+    const double aprev = ctrl->acurr;  // admm.m:504
+    const double dprev = ctrl->d;      // admm.m:509
+    double d = 1.0 / a.rho * s_duh + a.rho * s_dzv;  // admm.m:572-573 (B = -I)
+    double acn, coef, rst;
+    if (d < a.restart * dprev) {  // admm.m:576-582
+      acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+      coef = (aprev - 1.0) / acn;
+      rst = 0.0;
+    } else {  // admm.m:583-591
+      acn = 1.0;
+      coef = 0.0;
+      rst = 1.0;
+      d = dprev / a.restart;
+    }
+    ctrl->aprev = aprev;
+    ctrl->acurr = acn;
+    ctrl->dprev = dprev;
+    ctrl->d = d;
+    ctrl->coef = coef;
+    ctrl->restart_flag = rst;
+  }
+}
+
+void launch_fast_decide(const FinArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(fast_decide_kernel, dim3(1), dim3(kBlock), 0, stream, a);
+}
+
+__device__ __forceinline__ double rhs_value(int kind, double rho, double zx, double ux, double ci, double add) {
+  switch (kind) {
+    case RHS_RHO_DTS:
+      return rho * (zx - ux) + add;
+    case RHS_RHO_MINUS_Q:
+      return rho * (zx - ux) - add;
+    case RHS_DIFF:
+      return zx - ux;
+    case RHS_T1:
+      return (ci + zx) - ux;
+    default:
+      return 0.0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void extrapolate_kernel(ExtrapArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  const double coef = ctrl->coef;
+  const bool rst = ctrl->restart_flag != 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double z = a.z[i], u = a.u[i], zp = a.zprev[i], up = a.uprev[i];
+    const double vn = rst ? zp : z + coef * (z - zp);
+    const double uh = rst ? up : u + coef * (u - up);
+    a.v[i] = vn;
+    a.uhat[i] = uh;
+    if (a.vhist) a.vhist[it * a.len + i] = vn;
+    if (a.uhathist) a.uhathist[it * a.len + i] = uh;
+    if (a.rhs)
+      a.rhs[i] = rhs_value(a.rhs_kind, a.rho, vn, uh, a.c ? a.c[i] : 0.0, a.rhs_add ? a.rhs_add[i] : 0.0);
+  }
+}
+
+void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(extrapolate_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
+__global__ __launch_bounds__(kBlock) void initial_rhs_kernel(int64_t len, int kind, double rho,
+                                                             const double* __restrict__ zx,
+                                                             const double* __restrict__ ux,
+                                                             const double* __restrict__ c,
+                                                             const double* __restrict__ add,
+                                                             double* __restrict__ rhs) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    rhs[i] = rhs_value(kind, rho, zx[i], ux[i], c ? c[i] : 0.0, add ? add[i] : 0.0);
+}
+
+void launch_initial_rhs(int64_t len, int rhs_kind, double rho, const double* zx, const double* ux, const double* c,
+                        const double* rhs_add, double* rhs, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(initial_rhs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, len, rhs_kind,
+                     rho, zx, ux, c, rhs_add, rhs);
+}
+
+// ---------------------------------------------------------------- finalize
+__global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
+  Ctrl* ctrl = a.ctrl;
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  __shared__ double S[S_COUNT + 4];
+  const int it = ctrl->iter;
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double v = sum_slot(a.part, s, a.nblk, scratch);
+    if (threadIdx.x == 0) S[s] = v;
+  }
+  double ng2 = 0.0, ng3 = 0.0, nx2 = 0.0, objp = 0.0;
+  if (a.g && !a.nodualerror) {
+    double s2 = 0.0, s3 = 0.0;
+    for (int64_t j = threadIdx.x; j < a.nA; j += blockDim.x) {
+      const double g2 = a.g[a.ldg + j], g3 = a.g[2 * a.ldg + j];
+      s2 += g2 * g2;
+      s3 += g3 * g3;
+    }
+    ng2 = block_sum(s2, scratch);
+    ng3 = block_sum(s3, scratch);
+  }
+  if (a.x) {
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < a.nA; j += blockDim.x) {
+      const double xv = a.x[j];
+      s += xv * xv;
+      if (a.xhist) a.xhist[static_cast<int64_t>(it) * a.nA + j] = xv;
+    }
+    nx2 = block_sum(s, scratch);
+  }
+  if (a.objpart) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < a.nobjpart; b += blockDim.x) s += a.objpart[b];
+    objp = block_sum(s, scratch);
+  }
+  if (threadIdx.x != 0) return;
+
+  const int i1 = it + 1;  // 1-based iteration number (admm.m loop variable)
+  const double NaN = __longlong_as_double(0x7ff8000000000000LL);
+  double hn = 0.0;
+  if (a.use_h) {  // admm.m:305-306 with w = [x; z; rho*u]: rho*||dz||^2 + rho*||rho*du||^2
+    hn = a.rhoH * S[S_DZ2] + a.rhoH * (a.rho * a.rho) * S[S_DU2];
+    a.hnorm[it] = hn;
+  }
+  if (a.objevals && a.objv) {
+    a.objv[it] = a.obj_scale_part * objp + a.obj_scale_z * S[S_OBJZ] + a.obj_scale_x * S[S_OBJX] +
+                 a.obj_half_xnorm * nx2 + a.obj_const;
+  }
+  bool stop = false;
+  if (a.alg == 2) {
+    a.avals[it] = ctrl->acurr;
+    a.dvals[it] = ctrl->d;
+    a.restarted[it] = ctrl->restart_flag;
+    // admm.m:706: abs(d - dprev) <= DVALTOL*dprev
+    if (i1 >= 2 && fabs(ctrl->d - ctrl->dprev) <= a.dvaltol * ctrl->dprev) stop = true;
+  } else {
+    double coef = 0.0;
+    if (a.alg == 1) {
+      const double aprev = ctrl->acurr;
+      const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+      coef = (aprev - 1.0) / acn;
+      ctrl->aprev = aprev;
+      ctrl->acurr = acn;
+      ctrl->coef = coef;
+      a.avals[it] = acn;
+    }
+    const double pn = sqrt(S[S_R2]);
+    double dn, de;
+    if (a.nodualerror) {
+      dn = NaN;
+      de = NaN;
+    } else {
+      const double base = a.a_identity ? sqrt(S[S_DZ2]) : sqrt(ng2);
+      // alg 0: ||rho*At(B(z - zprev))||; alg 1: rho*||At(B(z - v))|| with z - v = -coef*(z - zprev)
+      dn = (a.alg == 0) ? a.rho * base : a.rho * (fabs(coef) * base);
+      const double un = a.a_identity ? sqrt(S[S_U2]) : sqrt(ng3);
+      de = sqrt(static_cast<double>(a.len)) * a.abstol + a.reltol * (a.rho * un);
+    }
+    const double pe = sqrt(static_cast<double>(a.len)) * a.abstol +
+                      a.reltol * fmax(fmax(sqrt(S[S_AX2]), sqrt(S[S_Z2])), a.cnorm);
+    a.pnorm[it] = pn;
+    a.dnorm[it] = dn;
+    a.perr[it] = pe;
+    a.derr[it] = de;
+    // admm.m:710-713
+    if ((a.stopcond == ADMM_STOP_STANDARD || a.stopcond == ADMM_STOP_BOTH) && !a.domaxiters && pn < pe &&
+        (a.nodualerror || dn < de))
+      stop = true;
+  }
+  if (a.use_h) {
+    if (a.convtest && i1 >= 2) {  // admm.m:686-701
+      const double H2 = a.hnorm[it], H1 = a.hnorm[it - 1];
+      if (a.alg == 0 && H1 > 2.220446049250313e-16 && H2 > H1 && !((H2 - H1) <= H1 * a.convtol)) {
+        ctrl->convfail = i1;
+        ctrl->steps = i1;
+        ctrl->iter = i1;
+        ctrl->stop = 1;
+        return;
+      }
+    }
+    // admm.m:719-722
+    if ((a.stopcond == ADMM_STOP_HNORM || a.stopcond == ADMM_STOP_BOTH) && !a.domaxiters && i1 > 2 &&
+        hn <= a.Hnormtol)
+      stop = true;
+  }
+  ctrl->iter = i1;
+  ctrl->steps = i1;
+  if (stop || i1 >= a.maxiters) ctrl->stop = 1;
+}
+
+void launch_finalize(const FinArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, a);
+}
+
+// ---------------------------------------------------------------- small helpers
+__global__ __launch_bounds__(kBlock) void residual_sq_kernel(const double* __restrict__ part, int32_t nchunk,
+                                                             int64_t ld, const double* __restrict__ s, int64_t len,
+                                                             double* __restrict__ objpart,
+                                                             const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double y = 0.0;
+    for (int32_t c = 0; c < nchunk; ++c) y += part[static_cast<int64_t>(c) * ld + i];
+    const double r = y - s[i];
+    acc += r * r;
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) objpart[blockIdx.x] = t;
+}
+
+void launch_residual_sq(const double* part, int32_t nchunk, int64_t ld, const double* s, int64_t len, double* objpart,
+                        int* nblk_out, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(residual_sq_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, part, nchunk,
+                     ld, s, len, objpart, ctrl);
+}
+
+__global__ __launch_bounds__(kBlock) void qp_objective_kernel(const double* __restrict__ part, int32_t nchunk,
+                                                              int64_t ld, const double* __restrict__ x,
+                                                              const double* __restrict__ q, int64_t len,
+                                                              double* __restrict__ objpart,
+                                                              const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double y = 0.0;
+    for (int32_t c = 0; c < nchunk; ++c) y += part[static_cast<int64_t>(c) * ld + i];
+    acc += x[i] * (0.5 * y + q[i]);
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) objpart[blockIdx.x] = t;
+}
+
+void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const double* x, const double* q,
+                         int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(qp_objective_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, part, nchunk,
+                     ld, x, q, len, objpart, ctrl);
+}
+
+__global__ __launch_bounds__(kBlock) void combine_kernel(const double* __restrict__ part, int32_t nchunk, int64_t ld,
+                                                         double alpha, const double* __restrict__ y, double beta,
+                                                         const double* __restrict__ add, double* __restrict__ x,
+                                                         int64_t len, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double s = 0.0;
+    for (int32_t c = 0; c < nchunk; ++c) s += part[static_cast<int64_t>(c) * ld + i];
+    double v = alpha * s;
+    if (y) v += beta * y[i];
+    if (add) v += add[i];
+    x[i] = v;
+  }
+}
+
+void launch_combine(const double* part, int32_t nchunk, int64_t ld, double alpha, const double* y, double beta,
+                    const double* add, double* x, int64_t len, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(combine_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, part, nchunk, ld,
+                     alpha, y, beta, add, x, len, ctrl);
+}
+
+}  // namespace admm

@@ -1,0 +1,152 @@
+// trsv.hip -- x = L' \ (L \ y): the cached-factor x-update (getProxOps.m:1200 `U \ (L \ y)`,
+// 1514 `Rt \ (R \ .)`, 1455, 1247) on a dense lower Cholesky factor.
+//
+// v1 structure: blocked substitution with pre-inverted 64x64 diagonal blocks (so each
+// diagonal step is a tiny GEMV, no in-kernel dependency chain).  One launch per block
+// column and sweep: every workgroup recomputes the 64-vector of the current block from L2
+// (32 KiB) and then streams its share of the off-diagonal panel from HBM with coalesced
+// loads -- forward: rows below the block (column-major => lanes along rows); backward:
+// columns left of the block (lanes along the 64 contiguous rows of each column, shuffle
+// reduce).  No inter-workgroup communication inside a launch.
+#include "kernels.h"
+
+namespace admm {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+constexpr int TB = 64;  // diagonal block size (matches dense.hip NB)
+
+// w_k = inv(L_kk) * y[k0:k0+nb] into LDS sw[TB]; all 256 threads cooperate.
+__device__ __forceinline__ void diag_apply_fwd(const double* __restrict__ dinv, const double* __restrict__ y,
+                                               int64_t k0, int nb, double* sw, double* spart) {
+  const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+  double s = 0.0;
+#pragma unroll 4
+  for (int c = part * 16; c < part * 16 + 16; ++c) {
+    if (c < nb && c <= i) s = __builtin_fma(dinv[i + c * TB], y[k0 + c], s);
+  }
+  spart[part * TB + i] = s;
+  __syncthreads();
+  if (threadIdx.x < TB) sw[i] = spart[i] + spart[TB + i] + spart[2 * TB + i] + spart[3 * TB + i];
+  __syncthreads();
+}
+
+// x_k = inv(L_kk)' * w[k0:k0+nb]
+__device__ __forceinline__ void diag_apply_bwd(const double* __restrict__ dinv, const double* __restrict__ w,
+                                               int64_t k0, int nb, double* sx, double* spart) {
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  double s = 0.0;
+#pragma unroll 4
+  for (int i = part * 16; i < part * 16 + 16; ++i) {
+    if (i < nb && i >= c) s = __builtin_fma(dinv[i + c * TB], w[k0 + i], s);
+  }
+  spart[part * TB + c] = s;
+  __syncthreads();
+  if (threadIdx.x < TB) sx[c] = spart[c] + spart[TB + c] + spart[2 * TB + c] + spart[3 * TB + c];
+  __syncthreads();
+}
+
+// Forward step k: wout[k0:k0+nb] = w_k; y[i] -= L[i, k0:k0+nb] * w_k for i >= k0+nb.
+__global__ __launch_bounds__(kBlock) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
+                                                               int64_t k0, int nb, const double* __restrict__ dinv,
+                                                               double* __restrict__ y, double* __restrict__ wout,
+                                                               const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double sw[TB];
+  __shared__ double spart[4 * TB];
+  diag_apply_fwd(dinv, y, k0, nb, sw, spart);
+  if (blockIdx.x == 0 && threadIdx.x < nb) wout[k0 + threadIdx.x] = sw[threadIdx.x];
+  const int64_t i = k0 + nb + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) {
+    const double* p = L + i + k0 * ld;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= nb; c += 4) {
+      s0 = __builtin_fma(p[(c + 0) * ld], sw[c + 0], s0);
+      s1 = __builtin_fma(p[(c + 1) * ld], sw[c + 1], s1);
+      s2 = __builtin_fma(p[(c + 2) * ld], sw[c + 2], s2);
+      s3 = __builtin_fma(p[(c + 3) * ld], sw[c + 3], s3);
+    }
+    for (; c < nb; ++c) s0 = __builtin_fma(p[c * ld], sw[c], s0);
+    y[i] -= (s0 + s1) + (s2 + s3);
+  }
+}
+
+// Backward step k: x[k0:k0+nb] = x_k; w[j] -= L[k0:k0+nb, j]' * x_k for j < k0.
+// 32 lanes per column (16-B loads over the 64 contiguous rows), 8 columns per block pass.
+__global__ __launch_bounds__(kBlock) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
+                                                               int64_t k0, int nb, const double* __restrict__ dinv,
+                                                               double* __restrict__ w, double* __restrict__ x,
+                                                               const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double sx[TB];
+  __shared__ double spart[4 * TB];
+  diag_apply_bwd(dinv, w, k0, nb, sx, spart);
+  if (blockIdx.x == 0 && threadIdx.x < nb) x[k0 + threadIdx.x] = sx[threadIdx.x];
+  const int half = threadIdx.x & 31;        // row pair within the block column
+  const int cslot = threadIdx.x >> 5;       // 0..7
+  const int r = 2 * half;
+  const double x0 = (r < nb) ? sx[r] : 0.0, x1 = (r + 1 < nb) ? sx[r + 1] : 0.0;
+  const int64_t jbase = static_cast<int64_t>(blockIdx.x) * 64;
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int64_t j = jbase + pass * 8 + cslot;
+    double s = 0.0;
+    if (j < k0) {
+      const double* p = L + k0 + r + j * ld;
+      if (r + 1 < nb) {
+        const double2_t d = *reinterpret_cast<const double2_t*>(p);
+        s = d.x * x0 + d.y * x1;
+      } else if (r < nb) {
+        s = p[0] * x0;
+      }
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (half == 0 && j < k0) w[j] -= s;
+  }
+}
+
+int trsv_build(const double* L, int64_t n, int64_t ldl, double** dinv_out, TrsvPlan* plan, hipStream_t stream) {
+  const int64_t nblk = ceil_div(n, TB);
+  double* dinv = *dinv_out;
+  if (!dinv) {
+    ADMM_HIP_TRY(hipMalloc(&dinv, sizeof(double) * nblk * TB * TB));
+    launch_trtri_diag(L, n, ldl, dinv, stream);
+    *dinv_out = dinv;
+  }
+  plan->n = n;
+  plan->ldl = ldl;
+  plan->nb = TB;
+  plan->nblk = static_cast<int32_t>(nblk);
+  plan->L = L;
+  plan->dinv = dinv;
+  return ADMM_OK;
+}
+
+size_t trsv_workspace_elems(const TrsvPlan& p) { return static_cast<size_t>(round_up(p.n, 2)) * 2; }
+
+// work: 2*n doubles (scratch copy of y, and w)
+void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, double* work, const Ctrl* ctrl,
+                      hipStream_t stream) {
+  const int64_t n = p.n;
+  double* yy = work;
+  double* w = work + round_up(n, 2);
+  (void)hipMemcpyAsync(yy, y, sizeof(double) * n, hipMemcpyDeviceToDevice, stream);
+  for (int64_t k = 0; k < p.nblk; ++k) {
+    const int64_t k0 = k * TB;
+    const int nb = static_cast<int>((n - k0 < TB) ? n - k0 : TB);
+    const int64_t rows = n - k0 - nb;
+    const unsigned blocks = static_cast<unsigned>(rows > 0 ? ceil_div(rows, kBlock) : 1);
+    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks), dim3(kBlock), 0, stream, p.L, p.ldl, n, k0, nb,
+                       p.dinv + k * TB * TB, yy, w, ctrl);
+  }
+  for (int64_t k = p.nblk - 1; k >= 0; --k) {
+    const int64_t k0 = k * TB;
+    const int nb = static_cast<int>((n - k0 < TB) ? n - k0 : TB);
+    const unsigned blocks = static_cast<unsigned>(k0 > 0 ? ceil_div(k0, 64) : 1);
+    hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(blocks), dim3(kBlock), 0, stream, p.L, p.ldl, n, k0, nb,
+                       p.dinv + k * TB * TB, w, x, ctrl);
+  }
+}
+
+}  // namespace admm

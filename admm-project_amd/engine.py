@@ -1,0 +1,150 @@
+"""Engine: Python owner of one ``admm_engine`` handle (C ABI, include/admm_engine.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_STOPCOND = {"standard": L.STOP_STANDARD, "hnorm": L.STOP_HNORM, "both": L.STOP_BOTH, "none": L.STOP_NONE}
+
+
+def _f64(a, order="F"):
+    return np.require(np.asarray(a, dtype=np.float64), dtype=np.float64, requirements=[order, "A"])
+
+
+class Engine:
+    """Device-resident problem (data + cached factor) and its iteration loop."""
+
+    def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
+                 lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
+                 device=0, slices=None, comm=None):
+        lib = L.load()
+        L.require_device()
+        d = L.ProblemDesc()
+        lib.admm_problem_desc_default(C.byref(d))
+        d.problem = problem
+        keep = []  # arrays must outlive the create call
+
+        def vec(a):
+            a = _f64(a).reshape(-1)
+            keep.append(a)
+            return L.as_dp(a)
+
+        if D is not None:
+            Dm = _f64(D)
+            if Dm.ndim != 2:
+                raise ValueError("D must be a matrix")
+            keep.append(Dm)
+            d.m, d.n = Dm.shape
+            d.D = L.as_dp(Dm)
+            d.ldD = Dm.shape[0]
+        if P is not None:
+            Pm = _f64(P)
+            keep.append(Pm)
+            d.n = Pm.shape[0]
+            if D is None:
+                d.m = Pm.shape[0]
+            d.P = L.as_dp(Pm)
+        if s is not None:
+            d.s = vec(s)
+        if ell is not None:
+            d.ell = vec(ell)
+        if q is not None:
+            d.q = vec(q)
+        if lb is not None:
+            d.lb = vec(lb)
+        if ub is not None:
+            d.ub = vec(ub)
+        if Lfactor is not None:
+            Lm = _f64(Lfactor)
+            keep.append(Lm)
+            d.L = L.as_dp(Lm)
+        d.lambda_ = float(lam)
+        d.C = float(Cval)
+        d.r = float(r)
+        d.rho = float(rho)
+        d.loss = int(loss)
+        d.userelax = int(userelax)
+        d.xsolve = int(xsolve)
+        d.mem = L.MEM_HOST
+        d.device = int(device)
+        if slices is not None:
+            sl = np.ascontiguousarray(np.asarray(slices, dtype=np.int64))
+            keep.append(sl)
+            d.nslices = sl.size
+            d.slices = sl.ctypes.data_as(C.POINTER(C.c_int64))
+        if comm is not None:
+            d.comm = comm.handle
+        self._comm = comm
+        h = C.c_void_p()
+        L.check(lib.admm_engine_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.problem = problem
+        self.m, self.n = int(d.m), int(d.n)
+        del keep
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.admm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def setup_seconds(self):
+        v = C.c_double(0)
+        L.check(self._lib.admm_engine_setup_seconds(self._h, C.byref(v)))
+        return v.value
+
+    def set_profiling(self, on):
+        L.check(self._lib.admm_engine_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_time(self, which):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        L.check(self._lib.admm_engine_kernel_time(self._h, which, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    # ------------------------------------------------------------------ run / fetch
+    def run(self, *, rho=1.0, maxiters=1000, domaxiters=0, relax=1.0, fast=L.FAST_OFF, objevals=0, convtest=0,
+            convtol=1e-10, stopcond="standard", nodualerror=0, abstol=1e-5, reltol=1e-3, Hnormtol=1e-6,
+            restart=0.999, dvaltol=1e-8, record_history=1, check_every=0, x0=None, z0=None, u0=None):
+        o = L.Options()
+        self._lib.admm_options_default(C.byref(o))
+        o.rho, o.relax, o.abstol, o.reltol = float(rho), float(relax), float(abstol), float(reltol)
+        o.Hnormtol, o.convtol, o.restart, o.dvaltol = float(Hnormtol), float(convtol), float(restart), float(dvaltol)
+        o.maxiters = int(maxiters)
+        o.domaxiters = int(bool(domaxiters))
+        o.fast = int(fast)
+        o.objevals = int(bool(objevals))
+        o.convtest = int(bool(convtest))
+        o.stopcond = _STOPCOND[stopcond]
+        o.nodualerror = int(bool(nodualerror))
+        o.record_history = int(bool(record_history))
+        o.check_every = int(check_every)
+        keep = []
+        for name, val in (("x0", x0), ("z0", z0), ("u0", u0)):
+            if val is not None:
+                a = _f64(val).reshape(-1)
+                keep.append(a)
+                setattr(o, name, L.as_dp(a))
+        s = L.RunSummary()
+        L.check(self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s)))
+        self.last = s
+        return s
+
+    def fetch(self, field, count, shape=None):
+        out = np.empty(int(count), dtype=np.float64)
+        written = C.c_size_t(0)
+        L.check(self._lib.admm_engine_fetch(self._h, field, L.as_dp(out), out.size, C.byref(written)))
+        out = out[:written.value]
+        if shape is not None:
+            out = out.reshape(shape, order="F")
+        return out

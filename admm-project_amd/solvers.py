@@ -1,0 +1,222 @@
+"""Problem solvers with the reference's signatures (/root/reference/solvers/*.m).
+
+Each function is the host half of the corresponding MATLAB solver: validate arguments,
+hand the data to ``getproxops`` (which uploads it and builds the cached factor on the
+GPU), set the constraint fields of ``options`` exactly as the reference does, call
+``admm`` and add ``solverruntime``.  The objective handles the reference installs in
+``options.obj`` are realised by device kernels; ``options['obj']`` is therefore a marker.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .api import admm, getproxops
+from .errorcheck import is_nonnegative_real, is_positive_real
+
+__all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit"]
+
+_ENGINE_OBJ = "<engine-native objective>"
+
+
+def _matrix(D, name):
+    D = np.asarray(D, dtype=np.float64)
+    if D.ndim != 2:
+        raise ValueError(f"Argument {name} is not a matrix!")
+    return D
+
+
+def _colvec(s, name):
+    s = np.asarray(s, dtype=np.float64)
+    if s.ndim == 2 and 1 in s.shape:
+        s = s.reshape(-1)
+    if s.ndim != 1:
+        raise ValueError(f"Argument {name} is not a vector!")
+    return s
+
+
+def _engine_args(options, args):
+    for key in ("xsolve", "device"):
+        if key in options:
+            args[key] = options[key]
+    return args
+
+
+def lasso(D, s, lam, options=None):
+    """results = lasso(D, s, lambda, options)   (solvers/lasso.m:77-245)
+
+    minimise 1/2*||D*x - s||_2^2 + lambda*||x||_1.  Setup on the device: Dts = D'*s,
+    L = chol(D'*D + rho*I) (tall) or chol(D*D'/rho + I) (fat) (lasso.m:160-176).
+    """
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    lam = is_nonnegative_real(lam, "lambda")
+    D = _matrix(D, "D")
+    s = _colvec(s, "s")
+    rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
+    if options.get("parallel", "none") in ("both", "zming", "xminf"):  # lasso.m:144-156
+        raise NotImplementedError("consensus lasso (options.parallel) is not engine-native yet")
+    m, n = D.shape
+    if s.size != m:
+        raise ValueError("The number of rows in argument D do not match size of s!")
+    args = _engine_args(options, dict(D=D, s=s, m=m, n=n, parallel=0, rho=rho))
+    args["lambda"] = lam
+    minx, minz, _ = getproxops("LASSO", args)
+    options["obj"] = _ENGINE_OBJ  # lasso.m:227  0.5*sum((D*x - s).^2) + lambda*norm(z,1)
+    options.update(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, parallel="none")  # lasso.m:232-239
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def _lad_like(kind, D, s, options):
+    if not isinstance(options, dict):
+        raise TypeError("Argument options is not a struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    D = _matrix(D, "D")
+    s = _colvec(s, "s")
+    m, n = D.shape
+    if s.size != m:
+        raise ValueError("The number of rows in argument D do not match size of s!")
+    args = _engine_args(options, dict(D=D, s=s))
+    if options.get("relax", 1) != 1:  # lad.m:124-126, huberfit.m:156-158
+        args["userelax"] = 1
+    minx, minz, _ = getproxops(kind, args)
+    options.update(A=D, B=-1, c=s, m=m, nA=n, nB=m)  # lad.m:140-145
+    options["obj"] = _ENGINE_OBJ  # lad.m:148 norm(z,1) | huberfit.m:180 1/2*sum(huber(z))
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def lad(D, s, options=None):
+    """results = lad(D, s, options)   (solvers/lad.m:51-154): minimise ||D*x - s||_1."""
+    return _lad_like("lad", D, s, options if options is not None else {})
+
+
+def huberfit(D, s, options=None):
+    """results = huberfit(D, s, options)   (solvers/huberfit.m:83-186): 1/2*sum(huber(D*x - s))."""
+    return _lad_like("huberfit", D, s, options if options is not None else {})
+
+
+def unwrappedadmm(zming, D, options=None):
+    """results = unwrappedadmm(zming, D, options)   (solvers/unwrappedadmm.m:1-143)
+
+    Transpose-reduction ADMM: minimise g(z) s.t. D*x = z with x = D^+ (z - u)
+    (unwrappedadmm.m:76-78).  Forces maxiters=1000, stopcond='both', nodualerror=1
+    (unwrappedadmm.m:90-92).  Deviation q14 (documented): explicit options.x0/z0/u0 win
+    over the reference's unconditional ``rand`` so that runs are reproducible.
+    """
+    options = dict(options or {})
+    D = _matrix(D, "D")
+    m, n = D.shape
+    if options.get("parallel", "none") in ("xminf", "zming", "both"):
+        raise NotImplementedError("row-sharded unwrapped ADMM: use admm_project_amd.parallel")
+    prob = zming.problem
+    from .api import ProxOp
+    xminf = ProxOp(prob, "x")
+    options.update(A=D, At=D.T, B=-1, nB=m, c=0, m=m)
+    rng = np.random.default_rng()
+    for key, size in (("x0", n), ("z0", m), ("u0", m)):  # unwrappedadmm.m:87-89
+        if key not in options:
+            options[key] = rng.random(size)
+    options["maxiters"] = 1000
+    options["stopcond"] = "both"
+    options["nodualerror"] = 1
+    return admm(xminf, zming, options)
+
+
+def linearsvm(D, ell, C, options=None):
+    """results = linearsvm(D, ell, C, options)   (solvers/linearsvm.m:92-246)."""
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    if not np.isscalar(C) or np.real(C) < 0:  # linearsvm.m:270-274
+        raise ValueError("Given regularization parameter C is not a nonnegative number!")
+    C = float(np.real(C))
+    ell = _colvec(ell, "ell")
+    D = _matrix(D, "D")
+    if D.shape[0] != ell.size:
+        raise ValueError("Product ell*D is not possible; sizes incompatible!")
+    loss = options.get("lossfunction", "hinge")  # linearsvm.m:154-158
+    args = _engine_args(options, dict(D=D, Dt=None, ell=ell, C=C, lossfunction=loss))
+    _, minz, _ = getproxops("LinearSVM", args)
+    options["obj"] = _ENGINE_OBJ  # linearsvm.m:231-237
+    results = unwrappedadmm(minz, D, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def quadraticprogram(P, q, r, cons1, cons2, options=None):
+    """results = quadraticprogram(P, q, r, cons1, cons2, options)  (solvers/quadraticprogram.m:99-246)
+
+    Only the 'bounded' form (cons1 = lb, cons2 = ub vectors) is engine-native.
+    """
+    if not isinstance(options, dict):
+        raise TypeError("Argument options is not a struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    P = _matrix(P, "P")
+    if P.shape[0] != P.shape[1]:
+        raise ValueError("Argument P is not a square matrix!")
+    q = _colvec(q, "q")
+    if q.size != P.shape[0]:
+        raise ValueError("The dimensions of square matrix P and vector q do not match!")
+    c1, c2 = np.asarray(cons1, dtype=np.float64), np.asarray(cons2, dtype=np.float64)
+    if not (c1.ndim <= 1 or 1 in c1.shape) or not (c2.ndim <= 1 or 1 in c2.shape):
+        raise NotImplementedError("standard-form QP (matrix constraint) is not engine-native")
+    lb, ub = c1.reshape(-1), c2.reshape(-1)
+    if lb.size != ub.size:
+        raise ValueError("Lengths of lower and upper bound constraints on solution x do not match!")
+    if lb.size != P.shape[0]:
+        raise ValueError("Bound vectors do not match predicted length of solution x!")
+    if np.array_equal(np.maximum(lb, ub), lb):  # quadraticprogram.m:319-322 swap
+        lb, ub = ub, lb
+    elif not np.array_equal(np.maximum(lb, ub), ub):
+        raise ValueError("Given constraint variables do not specify an upper and lower bound on solution x!")
+    n = P.shape[0]
+    rho = float(options.get("rho", 1.0))
+    args = _engine_args(options, dict(P=P, q=q, lb=lb, ub=ub, rho=rho, n=n, constraint="bounded", r=float(r)))
+    minx, minz, _ = getproxops("quadraticprogram", args)
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = _ENGINE_OBJ  # quadraticprogram.m:242
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def basispursuit(D, s, options=None):
+    """results = basispursuit(D, s, options)   (solvers/basispursuit.m:52-145).
+
+    The projector P = I - D'(DD')^-1 D and q = D'(DD')^-1 s (basispursuit.m:116-120) are a
+    one-time m x m solve done on the host (cold path); the per-iteration n x n GEMV and the
+    shrinkage run on the device.
+    """
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    D = _matrix(D, "D")
+    s = _colvec(s, "s")
+    mD, nD = D.shape
+    if mD == nD and mD == s.size:
+        raise ValueError("Square matrix problem Dx = s; don't need Basis Pursuit to solve this!")
+    if mD > nD and mD == s.size:
+        raise ValueError("Overdetermined system Dx = s; use Unwrapped ADMM solver instead.")
+    if mD != s.size:
+        raise ValueError("The number of rows in matrix D must match the number of rows in signal vector s!")
+    n = nD
+    DDt = D @ D.T
+    P = np.eye(n) - D.T @ np.linalg.solve(DDt, D)
+    q = D.T @ np.linalg.solve(DDt, s)
+    minx, minz, _ = getproxops("BasisPursuit", _engine_args(options, dict(P=P, q=q)))
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+    options["obj"] = _ENGINE_OBJ  # basispursuit.m:140 norm(x,1)
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results

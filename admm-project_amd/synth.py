@@ -131,10 +131,13 @@ def qp_bounded_problem(seed=0, n=2 ** 7):
 
 
 def basispursuit_problem(seed=0, rows=2 ** 6, cols=2 ** 7):
-    """testers/basispursuittest.m:109-117 shape: fat D, sparse planted x, s = D*x."""
+    """testers/basispursuittest.m:106-109: fat D, s = D*testx.  The reference asks for
+    ``sprandn(cols, 1, 0.1*cols)``, i.e. a density of 0.1*cols >= 1 for cols >= 10, which
+    saturates at a fully dense N(0,1) vector; ``density`` is restated as min(1, 0.1*cols)."""
     rng = np.random.default_rng(seed)
     D = np.asfortranarray(rng.standard_normal((rows, cols)))
-    testx = np.where(rng.random(cols) < 0.1, rng.standard_normal(cols), 0.0)
+    density = min(1.0, 0.1 * cols)
+    testx = np.where(rng.random(cols) < density, rng.standard_normal(cols), 0.0)
     return dict(D=D, s=D @ testx, testx=testx)
 
 

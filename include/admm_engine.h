@@ -1,0 +1,218 @@
+/*
+ * admm_engine.h -- C ABI of libadmm_hip.so, the MI355X (gfx950) ADMM iteration engine.
+ *
+ * Drop-in boundary for the hot path of PeterSutor/ADMM-Project: the loop of
+ * `results = admm(xminf, zming, options)` (reference admm.m:24, loop 496-743) when
+ * both prox handles come from `getproxops(problem, args)` (getProxOps.m:13).  The
+ * reference has no native layer at all; these are the entry points a MEX (or ctypes)
+ * binding for that path binds -- see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions: plain C, no C++/torch types.  All matrices are column-major fp64
+ * (MATLAB layout).  Every function returns 0 on success and a negative ADMM_E_* code
+ * on failure; admm_last_error() returns the thread-local message.  An engine handle
+ * is not re-entrant; one host thread drives one device.
+ */
+#ifndef ADMM_ENGINE_H
+#define ADMM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADMM_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------ */
+enum {
+  ADMM_OK = 0,
+  ADMM_E_INVALID = -1,     /* bad argument (mirrors the reference's error() calls) */
+  ADMM_E_UNSUPPORTED = -2, /* valid in the reference, not engine-native (yet) */
+  ADMM_E_DEVICE = -3,      /* HIP runtime / no GPU */
+  ADMM_E_NUMERIC = -4,     /* Cholesky breakdown (matrix not positive definite) */
+  ADMM_E_COMM = -5,        /* RCCL */
+  ADMM_E_CAPACITY = -6     /* destination buffer too small */
+};
+
+/* ---- problem kinds: the cases of getproxops' switch (getProxOps.m:52-917) ---- */
+enum {
+  ADMM_PROB_LASSO = 1,            /* getProxOps.m:313-456 serial; x: 1192-1206, z: 455 */
+  ADMM_PROB_LASSO_CONSENSUS = 2,  /* getProxOps.m:383-442, 1217-1343 (args.parallel=1) */
+  ADMM_PROB_LAD = 3,              /* getProxOps.m:753-811, x: 1511-1515 */
+  ADMM_PROB_HUBERFIT = 4,         /* getProxOps.m:814-912, z: 1529-1539 */
+  ADMM_PROB_LINEARSVM = 5,        /* getProxOps.m:202-310, 1062-1180 */
+  ADMM_PROB_TOTALVARIATION = 6,   /* getProxOps.m:145-199, 1044-1048 */
+  ADMM_PROB_QP_BOUNDED = 7,       /* getProxOps.m:631-641, 1441-1474 */
+  ADMM_PROB_BASISPURSUIT = 8      /* getProxOps.m:98-142, 1027-1032 */
+};
+
+/* linear-SVM loss (getProxOps.m:1094: anything but '01' runs the hinge prox) */
+enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1 };
+
+/* how the cached-factor x-update is applied every iteration */
+enum {
+  ADMM_XSOLVE_AUTO = 0,
+  ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form) */
+  ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once */
+  ADMM_XSOLVE_CG = 3       /* matrix-free conjugate gradients on (D'D + rho I), A-streaming */
+};
+
+/* where the desc's data pointers live */
+enum { ADMM_MEM_HOST = 0, ADMM_MEM_DEVICE = 1 };
+
+/* stopcond (admm.m:69, 710-722) */
+enum { ADMM_STOP_STANDARD = 0, ADMM_STOP_HNORM = 1, ADMM_STOP_BOTH = 2,
+       ADMM_STOP_NONE = 3 /* any other string: the reference's strcmp chain matches nothing */ };
+
+/* fast ADMM flavour (admm.m:63-64, 267-298) */
+enum { ADMM_FAST_OFF = 0, ADMM_FAST_WEAK = 2 /* accelerated, alg 2 */, ADMM_FAST_STRONG = 1 /* alg 1 */ };
+
+typedef struct admm_engine admm_engine; /* opaque */
+typedef struct admm_comm admm_comm;     /* opaque RCCL communicator wrapper */
+
+/*
+ * Problem description = what lasso.m:181-189 / lad.m:129-134 / huberfit.m:161-166 /
+ * linearsvm.m:210-214 / totalvariation.m:139-144 / quadraticprogram.m:212-218 pass to
+ * getproxops in `args`, as flat pointers.  Unused pointers are NULL.  With
+ * ADMM_MEM_HOST the engine copies everything at create (caller may free afterwards);
+ * with ADMM_MEM_DEVICE the big matrix D (or P) is borrowed and must outlive the engine.
+ */
+typedef struct admm_problem_desc {
+  int32_t struct_size; /* sizeof(admm_problem_desc), for ABI evolution */
+  int32_t problem;     /* ADMM_PROB_* */
+  int64_t m, n;        /* rows / columns of D (local rows when row-sharded); P is n x n */
+  const double* D;     /* m x n, column-major */
+  int64_t ldD;         /* leading dimension of D (>= m) */
+  const double* s;     /* length m (LAD/Huber/lasso) or n (total variation signal) */
+  const double* ell;   /* length m, labels +-1 (linear SVM) */
+  const double* P;     /* n x n: QP matrix, or basis-pursuit projector */
+  const double* q;     /* length n: QP linear term, or basis-pursuit offset */
+  const double* lb;    /* length n (QP bounded) */
+  const double* ub;    /* length n (QP bounded) */
+  const double* L;     /* optional precomputed lower Cholesky factor (args.L, lasso.m:183) */
+  double lambda;       /* lasso / TV regularisation */
+  double C;            /* SVM regularisation */
+  double r;            /* QP constant term */
+  double rho;          /* rho the cached factor is built for (args.rho) */
+  int32_t loss;        /* ADMM_LOSS_* */
+  int32_t userelax;    /* args.userelax (lad.m:124-126) */
+  int32_t xsolve;      /* ADMM_XSOLVE_* */
+  int32_t mem;         /* ADMM_MEM_* */
+  int32_t device;      /* HIP device ordinal */
+  int32_t nslices;     /* consensus lasso: number of LOCAL row slices (>=1) */
+  const int64_t* slices; /* their sizes (sum == m), slicemaker order (errorcheck.m:216-267) */
+  admm_comm* comm;     /* NULL = single device; else rows are sharded across the ranks */
+  double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
+  int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
+  int32_t reserved0;
+} admm_problem_desc;
+
+/* POD mirror of the `options` struct read by admm.m:51-76 (defaults: setopt, 780-971). */
+typedef struct admm_options {
+  int32_t struct_size;
+  int32_t maxiters;     /* default 1000 (admm.m:58, 334-339) */
+  double rho;           /* default 1.0 */
+  double relax;         /* default 1.0 (admm.m:60, 515-532) */
+  double abstol;        /* default 1e-5 */
+  double reltol;        /* default 1e-3 */
+  double Hnormtol;      /* default 1e-6 (accepts the reference's Hreltol spelling host-side) */
+  double convtol;       /* default 1e-10 */
+  double restart;       /* default 0.999 */
+  double dvaltol;       /* default 1e-8 */
+  int32_t domaxiters;   /* default 0 */
+  int32_t fast;         /* ADMM_FAST_* */
+  int32_t objevals;     /* default 0 */
+  int32_t convtest;     /* default 0 */
+  int32_t stopcond;     /* ADMM_STOP_* */
+  int32_t nodualerror;  /* default 0 */
+  int32_t record_history; /* 1 = keep xvals/zvals/uvals like admm.m:608-610; 0 = perf opt-out */
+  int32_t check_every;  /* iterations enqueued between host polls of the device stop flag (0 = auto) */
+  const double* x0;     /* optional warm start, HOST pointers (admm.m:252-254) */
+  const double* z0;
+  const double* u0;
+} admm_options;
+
+typedef struct admm_run_summary {
+  int32_t steps;               /* results.steps (admm.m:746) */
+  int32_t stopped_early;       /* 1 if a stop condition fired before maxiters */
+  int32_t convtest_failed_at;  /* >0: iteration where the H-norm monotonicity test aborted (admm.m:686-701) */
+  int32_t reserved;
+  double runtime_s;            /* loop only: tic admm.m:315 .. toc admm.m:756 */
+  double objopt;               /* results.objopt (admm.m:752-754), NaN if not evaluated */
+} admm_run_summary;
+
+/* result fields for admm_engine_fetch (reference names: admm.m:257-259, 582-616, 648-656, 681-682, 746-754) */
+enum {
+  ADMM_F_XOPT = 1, ADMM_F_ZOPT = 2, ADMM_F_UOPT = 3,
+  ADMM_F_XVALS = 4, ADMM_F_ZVALS = 5, ADMM_F_UVALS = 6, /* len x steps, column-major */
+  ADMM_F_PNORM = 7, ADMM_F_DNORM = 8, ADMM_F_PERR = 9, ADMM_F_DERR = 10,
+  ADMM_F_OBJEVALS = 11, ADMM_F_HNORMSQ = 12,
+  ADMM_F_AVALS = 13, ADMM_F_DVALS = 14, ADMM_F_RESTARTED = 15,
+  ADMM_F_VVALS = 16, ADMM_F_UHATVALS = 17,
+  ADMM_F_ZCONSENSUS = 18, /* consensus lasso: the true consensus z (the z handed to admm is 0, q9) */
+  ADMM_F_FACTOR = 19,     /* n x n (or m x m, fat lasso) lower Cholesky factor */
+  ADMM_F_CG_ITERS = 20    /* ADMM_XSOLVE_CG: inner iterations used per x-update */
+};
+
+/* ---- library ---------------------------------------------------------------- */
+int admm_abi_version(void);
+const char* admm_last_error(void);
+int admm_device_count(int* count);
+/* name[cap] gets the gcnArchName; hbm_bytes/cus may be NULL */
+int admm_device_info(int device, char* name, size_t cap, int64_t* hbm_bytes, int32_t* cus);
+
+/* ---- engine lifecycle --------------------------------------------------------
+ * create   = the solver's one-time setup + getproxops (lasso.m:160-192, lad.m:129-137, ...):
+ *            uploads data, builds Gram matrix / Cholesky factor / pseudo-inverse on device.
+ * run      = admm(minx, minz, options): the iteration loop, entirely on device.
+ * fetch    = copy one results.* field into caller memory (MEX: mxGetPr of the output).
+ */
+void admm_options_default(admm_options* opts);
+void admm_problem_desc_default(admm_problem_desc* desc);
+int admm_engine_create(const admm_problem_desc* desc, admm_engine** out);
+int admm_engine_run(admm_engine* eng, const admm_options* opts, admm_run_summary* summary);
+int admm_engine_fetch(admm_engine* eng, int field, double* dst, size_t cap, size_t* written);
+/* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */
+int admm_engine_setup_seconds(admm_engine* eng, double* seconds);
+/* per-kernel timing of the last run, measured with HIP events on the engine's stream:
+ * which = ADMM_K_*; returns total milliseconds and launch count */
+enum { ADMM_K_XSOLVE = 0, ADMM_K_GEMV_N = 1, ADMM_K_GEMV_T = 2, ADMM_K_PROX = 3, ADMM_K_FINALIZE = 4, ADMM_K_COUNT = 5 };
+int admm_engine_kernel_time(admm_engine* eng, int which, double* total_ms, int64_t* launches);
+/* turn per-kernel event timing on/off for subsequent runs (off by default) */
+int admm_engine_set_profiling(admm_engine* eng, int enabled);
+void admm_engine_destroy(admm_engine* eng);
+
+/* ---- stand-alone operators (kernel-level entry points; HOST pointers) ---------
+ * The building blocks of the loop, callable on their own: used by the parity tests
+ * and by bindings that run a user-supplied prox on the host but want the heavy
+ * linear algebra on the device.  Each cites the reference op it replaces.
+ */
+/* y = D*x  (admm.m:120 `A*v`; getProxOps.m:810, 1088) */
+int admm_op_gemv_n(const double* D, int64_t m, int64_t n, int64_t ldD, const double* x, double* y);
+/* G(:,k) = D'*V(:,k), k < nrhs <= 4  (admm.m:119/167 `At*v`; getProxOps.m:1514) */
+int admm_op_gemv_t(const double* D, int64_t m, int64_t n, int64_t ldD, const double* V, int64_t ldV,
+                   int32_t nrhs, double* G, int64_t ldG);
+/* W = D'*D (+ shift on the diagonal), n x n  (lasso.m:168, lad.m:134, unwrappedadmm.m:115) */
+int admm_op_gram(const double* D, int64_t m, int64_t n, int64_t ldD, double shift, double* W);
+/* in place lower Cholesky of the n x n SPD matrix A (chol(.,'lower'), lasso.m:168) */
+int admm_op_cholesky(double* A, int64_t n, int64_t ldA);
+/* x = L' \ (L \ y)  (getProxOps.m:1200, 1514) */
+int admm_op_trsv_pair(const double* L, int64_t n, int64_t ldL, const double* y, double* x);
+/* soft threshold sign(v).*max(abs(v)-t,0)  (getProxOps.m:933-938) */
+int admm_op_soft_threshold(const double* v, int64_t n, double t, double* out);
+
+/* ---- multi-GPU (one process per GPU; rows of D sharded; RCCL over xGMI) --------
+ * unique id is created on rank 0 and handed to the other ranks by the host
+ * (torch.distributed / MPI / a file).  errorcheck.m:216-267 defines the row partition.
+ */
+#define ADMM_COMM_ID_BYTES 128
+int admm_comm_unique_id(char id[ADMM_COMM_ID_BYTES]);
+int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int device, admm_comm** out);
+int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count); /* host convenience/test */
+void admm_comm_destroy(admm_comm* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMM_ENGINE_H */

@@ -1,0 +1,91 @@
+"""Generate the golden fixtures in this directory from the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+Each ``*.npz`` holds the inputs of one small problem and the oracle's complete
+per-iteration outputs (x, z, u histories, residual norms, tolerances, objective, H-norm).
+The oracle itself is a restatement of the MATLAB reference, which stores no golden
+vectors and cannot be executed here (no MATLAB/Octave): these fixtures pin the *oracle's*
+behaviour over time and give the GPU tests a reference that needs nothing but NumPy.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import admm_project_amd as ap  # noqa: E402
+from oracle import solvers_ref as S  # noqa: E402
+
+KEYS = ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq", "avals", "dvals",
+        "restarted", "vvals", "uhatvals", "xopt", "zopt", "uopt")
+
+
+def pack(results, hist_limit=None):
+    out = {"steps": np.int64(results["steps"])}
+    for k in KEYS:
+        if k in results:
+            v = np.asarray(results[k])
+            if hist_limit is not None and k.endswith("vals") or (hist_limit is not None and v.ndim == 1
+                                                                 and v.size == results["steps"]):
+                v = v[..., :hist_limit]  # keep only the first iterations of a long run
+            out["out_" + k] = v
+    if "objopt" in results:
+        out["out_objopt"] = np.float64(results["objopt"])
+    return out
+
+
+def save(name, inputs, options, results, hist_limit=None):
+    d = {("in_" + k): np.asarray(v) for k, v in inputs.items()}
+    d.update({("opt_" + k): np.asarray(v) for k, v in options.items()})
+    d.update(pack(results, hist_limit))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: steps={results['steps']}")
+
+
+def main():
+    p = ap.synth.lasso_problem(0, 256, 64)
+    o = dict(objevals=1)
+    save("lasso_tall_256x64", dict(D=p["D"], s=p["s"], lam=p["lam"], testx=p["testx"]), o,
+         S.lasso(p["D"], p["s"], p["lam"], o))
+    o = dict(objevals=1, relax=1.6, convtest=1)
+    save("lasso_tall_relax", dict(D=p["D"], s=p["s"], lam=p["lam"]), o, S.lasso(p["D"], p["s"], p["lam"], o))
+    for ft in ("weak", "strong"):
+        o = dict(objevals=1, fast=1, fasttype=ft, maxiters=60, stopcond="both")
+        save(f"lasso_fast_{ft}", dict(D=p["D"], s=p["s"], lam=p["lam"]), o, S.lasso(p["D"], p["s"], p["lam"], o))
+    p = ap.synth.lasso_problem(1, 32, 256)
+    o = dict(objevals=1)
+    save("lasso_fat_32x256", dict(D=p["D"], s=p["s"], lam=p["lam"]), o, S.lasso(p["D"], p["s"], p["lam"], o))
+
+    p = ap.synth.lad_problem(0, 512, 64)
+    o = dict(objevals=1, convtest=1)
+    save("lad_512x64", dict(D=p["D"], s=p["s"], xtrue=p["xtrue"]), o, S.lad(p["D"], p["s"], o))
+    o = dict(objevals=1, relax=1.5)
+    save("lad_512x64_relax", dict(D=p["D"], s=p["s"]), o, S.lad(p["D"], p["s"], o))
+    p = ap.synth.huber_problem(0, 512, 64)
+    o = dict(objevals=1, convtest=1)
+    save("huber_512x64", dict(D=p["D"], s=p["s"], testx=p["testx"]), o, S.huberfit(p["D"], p["s"], o))
+
+    p = ap.synth.svm_problem(0, 128, 128)
+    for loss in ("hinge", "01"):
+        # the discontinuous 0-1 prox trips the H-norm monotonicity test (admm.m:692) -> no convtest there
+        o = dict(objevals=1, convtest=int(loss == "hinge"), lossfunction=loss, x0=p["x0"], z0=p["z0"], u0=p["u0"])
+        r = S.linearsvm(p["D"], p["ell"], p["C"], o)
+        save(f"svm_{loss}_256x2", dict(D=p["D"], ell=p["ell"], C=p["C"]), o, r,
+             hist_limit=40 if loss == "01" else None)
+
+    p = ap.synth.qp_bounded_problem(0, 128)
+    o = dict(objevals=1, stopcond="both")
+    save("qp_bounded_128", dict(P=p["P"], q=p["q"], r=p["r"], lb=p["lb"], ub=p["ub"]), o,
+         S.quadraticprogram_bounded(p["P"], p["q"], p["r"], p["lb"], p["ub"], o))
+
+    p = ap.synth.basispursuit_problem(0, 32, 96)
+    o = dict(objevals=1)
+    save("basispursuit_32x96", dict(D=p["D"], s=p["s"]), o, S.basispursuit(p["D"], p["s"], o))
+
+
+if __name__ == "__main__":
+    main()
