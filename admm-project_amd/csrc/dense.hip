@@ -402,37 +402,38 @@ int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double*
                      dinv, n, X, ldx);
   for (int64_t b = NB; b < n; b *= 2) {
     const int64_t npair = ceil_div(n, 2 * b);
-    // pairs whose second block is empty have nothing to do; the guards make them no-ops
-    // T(p) = L21 * X11 -> stored at X[p*2b : +b, p*2b + b : +b]  (upper-right of the pair)
+    // Pairs whose second block is empty or ragged are handled by the GEMM's extent guards.
+    // The scratch holds T' = X11' * L21' (size rows(block1) x rows(block2)), which is exactly the
+    // shape of the pair's upper-right block even when block 2 is ragged.
     GemmArgs g{};
-    g.M = b;
-    g.N = b;
+    g.M = b;  // i: columns of X11
+    g.N = b;  // j: rows of L21
     g.K = b;
     g.alpha = 1.0;
     g.beta = 0.0;
-    g.A = L + b;  // L21 of pair 0: rows b.., cols 0..
-    g.lda = ldl;
-    g.strideA = 2 * b * (ldl + 1);
-    g.a_rows = n - b;
+    g.A = X;  // X11, used transposed (stored K x M)
+    g.lda = ldx;
+    g.strideA = 2 * b * (ldx + 1);
+    g.a_rows = n;
     g.a_cols = n;
     g.shrinkA_r = 2 * b;
     g.shrinkA_c = 2 * b;
-    g.B = X;  // X11
-    g.ldb = ldx;
-    g.strideB = 2 * b * (ldx + 1);
-    g.b_rows = n;
+    g.B = L + b;  // L21 (rows b.., cols 0..), used transposed (stored N x K)
+    g.ldb = ldl;
+    g.strideB = 2 * b * (ldl + 1);
+    g.b_rows = n - b;
     g.b_cols = n;
     g.shrinkB_r = 2 * b;
     g.shrinkB_c = 2 * b;
-    g.C = X + b * ldx;  // upper-right block
+    g.C = X + b * ldx;  // upper-right block of the pair
     g.ldc = ldx;
     g.strideC = 2 * b * (ldx + 1);
     g.c_rows = n;
     g.c_cols = n - b;
     g.shrinkC_r = 2 * b;
     g.shrinkC_c = 2 * b;
-    launch_gemm_args(0, 0, g, static_cast<int>(npair), stream);
-    // X21 = -X22 * T
+    launch_gemm_args(1, 1, g, static_cast<int>(npair), stream);
+    // X21 = -X22 * T = -X22 * (T')'
     GemmArgs h{};
     h.M = b;
     h.N = b;
@@ -446,7 +447,7 @@ int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double*
     h.a_cols = n - b;
     h.shrinkA_r = 2 * b;
     h.shrinkA_c = 2 * b;
-    h.B = X + b * ldx;  // T
+    h.B = X + b * ldx;  // T' (stored N x K)
     h.ldb = ldx;
     h.strideB = 2 * b * (ldx + 1);
     h.b_rows = n;
@@ -460,7 +461,7 @@ int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double*
     h.c_cols = n;
     h.shrinkC_r = 2 * b;
     h.shrinkC_c = 2 * b;
-    launch_gemm_args(0, 0, h, static_cast<int>(npair), stream);
+    launch_gemm_args(0, 1, h, static_cast<int>(npair), stream);
     // X11 of the next level must be strictly lower-triangular again: clear the scratch
     hipLaunchKernelGGL(zero_scratch_kernel, dim3(static_cast<unsigned>(b), static_cast<unsigned>(npair)),
                        dim3(kBlock), 0, stream, X, n, ldx, b);

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ADMM engine (driver contract: see README/DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): lasso.m on synthetic dense D 100000 x 10000 fp64, rho = 1,
+lassotest.m:109-122 recipe, fixed work via the reference's own switch domaxiters=1
+(admm.m:59, 711).  A "step" is one ADMM iteration (admm.m:496-743) with D, the cached factor
+and all iterates resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=100000)
+    ap.add_argument("--cols", type=int, default=10000)
+    ap.add_argument("--xsolve", default="inverse", choices=["trsv", "inverse"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the objevals=1 and A-streaming side measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    """One process per GPU (torch.distributed, backend nccl == RCCL).  Returns (rank, world, dist|None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return 0, 1, 0, None
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return rank, world, local, dist
+
+
+def sync_all(dist, ap_mod):
+    if dist is not None:
+        import torch
+
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def timed_run(eng, dist, steps, **kw):
+    """barrier + sync, EXACTLY `steps` iterations, sync + barrier; MAX over ranks."""
+    sync_all(dist, None)
+    t0 = time.perf_counter()
+    s = eng.run(maxiters=steps, domaxiters=1, record_history=0, **kw)
+    sync_all(dist, None)  # eng.run returns only after its stream has drained
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert s.steps == steps, (s.steps, steps)
+    return dt, s
+
+
+def cpu_baseline(p, factor, seconds, rho):
+    """The oracle's lasso loop (same algorithm and operation order as the reference: two
+    triangular solves with the cached factor per iteration) on the host cores.  The factor is the
+    one built on the GPU, handed over through args.L exactly as lasso.m:183 hands it to getproxops."""
+    from oracle import admm as ref_admm
+    from oracle import getproxops as ref_getproxops
+
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    D, s, lam = p["D"], p["s"], p["lam"]
+    m, n = D.shape
+    args = dict(D=D, Dts=D.T @ s, L=factor, U=factor.T, m=m, n=n, parallel=0, rho=rho)
+    args["lambda"] = lam
+    minx, minz, _ = ref_getproxops("LASSO", args)
+    base = dict(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, domaxiters=1, rho=rho)
+    t0 = time.perf_counter()
+    ref_admm(minx, minz, dict(base, maxiters=2))
+    per = (time.perf_counter() - t0) / 2
+    k = int(max(3, min(500, seconds / max(per, 1e-6))))
+    r = ref_admm(minx, minz, dict(base, maxiters=k))
+    return dict(value=k / r["runtime"], unit="iterations/s", cores=int(threads), kind="port",
+                sample=f"{k} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
+                       f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves, factor taken from the GPU setup); "
+                       f"loop only, as results.runtime")
+
+
+def main():
+    a = parse()
+    rank, world, local, dist = dist_setup(a.gpus)
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    import admm_project_amd as ap
+
+    L = ap._lib
+    L.require_device()
+    if world > 1:
+        raise SystemExit("bench.py: row-sharded multi-GPU engines are not wired into the bench yet")
+
+    m, n = a.rows, a.cols
+    rho = 1.0
+    t0 = time.perf_counter()
+    p = ap.synth.lasso_problem(seed=1, rows=m, cols=n)
+    t_gen = time.perf_counter() - t0
+
+    xs = {"trsv": L.XSOLVE_TRSV, "inverse": L.XSOLVE_INVERSE}[a.xsolve]
+    eng = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local)
+    setup_s = eng.setup_seconds
+
+    # ---- headline: objevals = 0 ----------------------------------------------------------
+    timed_run(eng, dist, max(1, a.warmup), rho=rho)
+    eng.set_profiling(True)
+    dt, _ = timed_run(eng, dist, a.steps, rho=rho)
+    eng.set_profiling(False)
+    xs_ms, xs_cnt = eng.kernel_time(L.K_XSOLVE)
+    value = a.steps / dt
+    if a.xsolve == "inverse":
+        alg_bytes = 8.0 * n * n  # one pass over the symmetric n x n inverse (full storage)
+        kname = "gemv_n_kernel (x = inv(D'D+rho I) * y)"
+    else:
+        alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
+        kname = "trsv_fwd/bwd_step kernels (x = L'\\(L\\y))"
+    xs_avg_ms = xs_ms / max(1, xs_cnt)
+    achieved = alg_bytes / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
+    out = {
+        "metric": "ADMM iterations/sec (lasso 100k x 10k, fp64)", "value": value, "unit": "iterations/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"lasso.m cached-factor loop, D {m}x{n} fp64, rho=1, lassotest.m recipe seed=1, "
+                               f"domaxiters=1, objevals=0, xsolve={a.xsolve}",
+                   "rows": m, "cols": n, "rho": rho, "parallelism": f"rows{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": xs_avg_ms, "launches": xs_cnt},
+        "setup_seconds": setup_s, "datagen_seconds": t_gen,
+        "achieved_hbm_GBs_whole_iteration": (alg_bytes + 8.0 * 21 * n) * a.steps / dt / 1e9,
+    }
+
+    # ---- side measurements (same resident data) --------------------------------------------
+    if not a.no_extras:
+        k1 = max(5, a.steps // 4)
+        timed_run(eng, dist, 2, rho=rho, objevals=1)
+        eng.set_profiling(True)
+        dt1, _ = timed_run(eng, dist, k1, rho=rho, objevals=1)
+        eng.set_profiling(False)
+        gn_ms, gn_cnt = eng.kernel_time(L.K_GEMV_N)
+        gbs = 8.0 * m * n / (gn_ms / max(1, gn_cnt) * 1e-3) / 1e9 if gn_cnt else 0.0
+        out["objevals1"] = {"iters_per_s": k1 / dt1, "ms_per_step": dt1 / k1 * 1e3,
+                            "gemv_n_GBs": gbs, "gemv_n_frac": gbs / HBM_PEAK_GBS,
+                            "gemv_n_avg_ms": gn_ms / max(1, gn_cnt),
+                            "note": "lassotest.m:131 sets objevals=1: one extra D*x pass (8mn B) per iteration; "
+                                    "timing includes the residual-norm kernel"}
+
+    factor = None
+    if not a.no_cpu_baseline:
+        factor = eng.fetch(L.F_FACTOR, n * n, (n, n))
+    eng.close()
+
+    if not a.no_extras:
+        # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
+        # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes.
+        lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local)
+        k2 = max(5, a.steps // 8)
+        timed_run(lad, dist, 2)
+        lad.set_profiling(True)
+        dt2, _ = timed_run(lad, dist, k2)
+        lad.set_profiling(False)
+        gn_ms, gn_cnt = lad.kernel_time(L.K_GEMV_N)
+        gt_ms, gt_cnt = lad.kernel_time(L.K_GEMV_T)
+        pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
+        gbs = 16.0 * m * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        out["a_streaming"] = {"workload": "lad.m on the same D,s: D*x + D'*[s+z-u, dz, u] per iteration (16mn B)",
+                              "iters_per_s": k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
+                              "AtAx_unit_ms": pair_ms, "AtAx_GBs": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                              "gemv_n_avg_ms": gn_ms / max(1, gn_cnt), "gemv_t_avg_ms": gt_ms / max(1, gt_cnt),
+                              "setup_seconds": lad.setup_seconds}
+        lad.close()
+
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,9 @@ def _setopt(options, name, default):
     called ``Hreltol``; we accept either spelling.
     """
     if name == "Hnormtol":
-        if "Hnormtol" in options and "Hreltol" in options:
+        # literal reference: the value is taken from Hreltol when Hnormtol is present (and
+        # errors when Hreltol is missing).  Stance D: either spelling sets the tolerance.
+        if "Hreltol" in options:
             return options["Hreltol"]
         if "Hnormtol" in options:
             return options["Hnormtol"]
