@@ -1,0 +1,268 @@
+// tv.hip -- 1-D total-variation ADMM kernels (solvers/totalvariation.m, getProxOps.m:145-199).
+//
+//   x-update  (getProxOps.m:1047)  x = (I + rho*D'D) \ (s + rho*D'(z-u)),  D = spdiags([1 -1],0:1,n,n)
+//   z-update  (getProxOps.m:199)   z = soft(u + D*x, lambda/rho),  then u += D*x - z  (admm.m:548)
+//
+// I + rho*D'D is the constant SPD tridiagonal [-rho, 1+rho*(1|2|..|2), -rho].  The reference
+// re-assembles and re-factors it sparsely every iteration; here its LDL' pivots are computed
+// once (host, O(n)) and each solve is two first-order recurrences
+//     forward   y_i = r_i + (rho/b_{i-1}) * y_{i-1}
+//     backward  x_i = y_i/b_i + (rho/b_i) * x_{i+1}
+// evaluated as block-parallel affine-map scans.  The recurrence multipliers are < 1 in
+// magnitude (strict diagonal dominance), so an element depends on anything further than H
+// positions away by less than 1e-18 relative: each workgroup warms up on an H-element halo
+// instead of waiting for its predecessor -- no inter-workgroup communication, pure streaming.
+// The D / D' stencils and the rhs assembly are fused into the sweeps and the prox kernel.
+#include "kernels.h"
+#include "loop_kernels.h"
+#include "tv.h"
+
+namespace admm {
+
+__device__ __forceinline__ double tv_pivot(const TvArgs& a, int64_t i) { return (i < a.nprefix) ? a.bprefix[i] : a.bstar; }
+
+// One sweep.  Logical position q in [0, count) maps to global index i = p0 + q (forward) or
+// p1 - 1 - q (backward); the scan always runs in increasing q with zero incoming carry.
+template <int E, bool BWD>
+__global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // padded: pos(q) = q + (q >> 4)
+  __shared__ double wA[4], wB[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t n = a.n;
+  const int64_t o0 = static_cast<int64_t>(blockIdx.x) * a.tile;
+  const int64_t o1 = (o0 + a.tile < n) ? o0 + a.tile : n;
+  int64_t p0, p1;
+  if (!BWD) {
+    p0 = (o0 - a.halo > 0) ? o0 - a.halo : 0;
+    p1 = o1;
+  } else {
+    p0 = o0;
+    p1 = (o1 + a.halo < n) ? o1 + a.halo : n;
+  }
+  const int count = static_cast<int>(p1 - p0);
+  const double rho = a.rho;
+
+  // ---- stage the per-element constant term r_q (coalesced global reads -> padded LDS)
+  for (int q = tid; q < count; q += kBlock) {
+    const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
+    double r;
+    if (!BWD) {  // r_i = s_i + rho*(D'(z-u))_i     getProxOps.m:1047
+      const double t = a.z[i] - a.u[i];
+      const double dt = (i > 0) ? t - (a.z[i - 1] - a.u[i - 1]) : t;
+      r = a.s[i] + rho * dt;
+    } else {
+      r = a.y[i] / tv_pivot(a, i);
+    }
+    lds[q + (q >> 4)] = r;
+  }
+  __syncthreads();
+
+  // ---- thread-local composite over its E consecutive positions: y_out = A*y_in + B
+  const int q0 = tid * E;
+  double A = 1.0, B = 0.0;
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = q0 + k;
+    if (q < count) {
+      const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
+      // forward: a_i = rho/b_{i-1} (a_0 = 0); backward: a_i = rho/b_i, 0 for the last row
+      double c;
+      if (!BWD) c = (i > 0) ? rho / tv_pivot(a, i - 1) : 0.0;
+      else c = (i < n - 1) ? rho / tv_pivot(a, i) : 0.0;
+      B = c * B + lds[q + (q >> 4)];
+      A = c * A;
+    }
+  }
+  // ---- exclusive scan of (A,B) across the block: wave shuffles, then the 4 wave totals
+  double sA = A, sB = B;  // inclusive within the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double pA = __shfl_up(sA, off, 64), pB = __shfl_up(sB, off, 64);
+    if (lane >= off) {
+      sB = sA * pB + sB;
+      sA = sA * pA;
+    }
+  }
+  if (lane == 63) {
+    wA[wid] = sA;
+    wB[wid] = sB;
+  }
+  __syncthreads();
+  // carry entering this wave = composition of the previous waves applied to 0
+  double carry = 0.0;
+  for (int w = 0; w < wid; ++w) carry = wA[w] * carry + wB[w];
+  // exclusive value for this thread: apply the inclusive prefix of the previous lane
+  double eA = __shfl_up(sA, 1, 64), eB = __shfl_up(sB, 1, 64);
+  if (lane == 0) {
+    eA = 1.0;
+    eB = 0.0;
+  }
+  double yin = eA * carry + eB;
+
+  // ---- recompute the thread's positions with the true incoming value, write results to LDS
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = q0 + k;
+    if (q < count) {
+      const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
+      double c;
+      if (!BWD) c = (i > 0) ? rho / tv_pivot(a, i - 1) : 0.0;
+      else c = (i < n - 1) ? rho / tv_pivot(a, i) : 0.0;
+      yin = c * yin + lds[q + (q >> 4)];
+      lds[q + (q >> 4)] = yin;
+    }
+  }
+  __syncthreads();
+  // ---- coalesced store of the owned range
+  const int64_t it = ctrl->iter;
+  for (int q = tid; q < count; q += kBlock) {
+    const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
+    if (i >= o0 && i < o1) {
+      const double v = lds[q + (q >> 4)];
+      if (!BWD) {
+        a.y[i] = v;
+      } else {
+        a.x[i] = v;
+        if (a.xhist) a.xhist[it * n + i] = v;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ double tv_soft(double v, double t) {
+  const double q = fabs(v) - t;
+  const double p = q > 0.0 ? q : 0.0;
+  return (v > 0.0) ? p : ((v < 0.0) ? -p : 0.0 * p);
+}
+
+// z/u update with the D stencil, every residual partial sum, and the D' stencils of the dual
+// residual (admm.m:624) and dual tolerance (admm.m:654).  Reads z,u (old) and writes zo,uo
+// (ping-pong) because element i also needs the NEW values of element i-1.
+__global__ __launch_bounds__(kBlock) void tv_prox_kernel(TvArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  const int64_t n = a.n;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double xi = a.x[i];
+    const double xn = (i + 1 < n) ? a.x[i + 1] : 0.0;
+    const double ax = (i + 1 < n) ? xi - xn : xi;  // D*x, last row is x_n (totalvariation.m:127)
+    const double zp = a.z[i], uo = a.u[i];
+    const double zn = tv_soft(uo + ax, a.thresh);  // getProxOps.m:199
+    const double Bz = -zn;
+    const double un = uo + (ax + Bz);              // admm.m:548 (c = 0)
+    const double r = ax + Bz;
+    const double dz = zn - zp;
+    // the same quantities for element i-1 (recomputed; feeds the D' stencils)
+    double dzm = 0.0, unm = 0.0;
+    if (i > 0) {
+      const double axm = a.x[i - 1] - xi;
+      const double zpm = a.z[i - 1], uom = a.u[i - 1];
+      const double znm = tv_soft(uom + axm, a.thresh);
+      unm = uom + (axm + (-znm));
+      dzm = znm - zpm;
+    }
+    const double g2 = dz - dzm;  // (D'(z - zprev))_i
+    const double g3 = un - unm;  // (D'u)_i
+    acc[S_R2] += r * r;
+    acc[S_AX2] += ax * ax;
+    acc[S_Z2] += zn * zn;
+    acc[S_DZ2] += dz * dz;
+    acc[S_U2] += un * un;
+    const double du = un - uo;
+    acc[S_DU2] += du * du;
+    acc[S_G2] += g2 * g2;
+    acc[S_G3] += g3 * g3;
+    if (a.objevals) {  // totalvariation.m:134-135
+      if (i + 1 < n) acc[S_OBJZ] += fabs(xn - xi);
+      const double e = xi - a.s[i];
+      acc[S_OBJX] += e * e;
+    }
+    a.zo[i] = zn;
+    a.uo[i] = un;
+    if (a.zhist) a.zhist[it * n + i] = zn;
+    if (a.uhist) a.uhist[it * n + i] = un;
+  }
+  // block partials
+  __shared__ double sred[4][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    a.part[s * kMaxPartBlocks + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------
+int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, int* halo, int* elems, int* tile) {
+  // LDL' pivots of I + rho*D'D:  b_1 = 1+rho, b_i = 1+2rho - rho^2/b_{i-1}
+  std::vector<double> b;
+  b.reserve(4096);
+  double cur = 1.0 + rho;
+  b.push_back(cur);
+  const int64_t cap = n < (1 << 20) ? n : (1 << 20);
+  int64_t stationary = -1;
+  for (int64_t i = 1; i < cap; ++i) {
+    const double nxt = (1.0 + 2.0 * rho) - rho * rho / cur;
+    if (nxt == cur) {
+      stationary = i;
+      break;
+    }
+    b.push_back(nxt);
+    cur = nxt;
+  }
+  if (stationary < 0 && cap < n)
+    return fail(ADMM_E_UNSUPPORTED, "total variation: tridiagonal pivots did not become stationary (rho too large)");
+  *bstar = cur;
+  *prefix = b;
+  const double amax = rho / cur;  // limiting multiplier; earlier ones are smaller or equal in effect
+  double worst = amax;
+  for (double bv : b) worst = (rho / bv > worst) ? rho / bv : worst;
+  if (!(worst < 1.0)) return fail(ADMM_E_NUMERIC, "total variation: matrix is not diagonally dominant");
+  const double h = std::log(1e-18) / std::log(worst);
+  int H = static_cast<int>(std::ceil(h));
+  if (H < 1) H = 1;
+  if (H <= 1024) {
+    *elems = 20;
+    *tile = 256 * 20 - 1024;
+  } else if (H <= 4096) {
+    *elems = 48;
+    *tile = 256 * 48 - 4096;
+  } else {
+    return fail(ADMM_E_UNSUPPORTED, "total variation: rho too large for the windowed tridiagonal solve");
+  }
+  *halo = H;
+  return ADMM_OK;
+}
+
+void launch_tv_sweep(const TvArgs& a, bool backward, const Ctrl* ctrl, hipStream_t stream) {
+  const unsigned blocks = static_cast<unsigned>(ceil_div(a.n, a.tile));
+  const int cap = a.elems * kBlock;
+  const size_t lds = static_cast<size_t>(cap + (cap >> 4) + 1) * sizeof(double);
+  if (a.elems == 20) {
+    if (backward) hipLaunchKernelGGL((tv_sweep_kernel<20, true>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+    else hipLaunchKernelGGL((tv_sweep_kernel<20, false>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+  } else {
+    if (backward) hipLaunchKernelGGL((tv_sweep_kernel<48, true>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+    else hipLaunchKernelGGL((tv_sweep_kernel<48, false>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+  }
+}
+
+void launch_tv_prox(const TvArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.n, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(tv_prox_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
+}  // namespace admm
