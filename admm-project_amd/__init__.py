@@ -9,6 +9,6 @@ from ._lib import AdmmError  # noqa: F401
 from .api import ProxOp, admm, getproxops  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .solvers import (basispursuit, huberfit, lad, lasso, linearsvm, quadraticprogram,  # noqa: F401
-                      unwrappedadmm)
+                      totalvariation, unwrappedadmm)
 
 __version__ = "0.1.0"

@@ -117,6 +117,11 @@ def getproxops(problem, args):
         eng = Engine(L.PROB_QP_BOUNDED, P=P, q=q, lb=_get(args, "lb"), ub=_get(args, "ub"),
                      rho=float(_get(args, "rho")), r=float(args.get("r", 0.0)), xsolve=xs, device=dev)
         prob = _Problem("quadraticprogram", eng, dict(A=1, c=0.0, nA=n, nB=n))
+    elif kind == "totalvariation":
+        sig = np.asarray(_get(args, "s"), dtype=np.float64).reshape(-1)
+        n = sig.size
+        eng = Engine(L.PROB_TOTALVARIATION, s=sig, lam=float(_get(args, "lambda")), nvec=n, device=dev)
+        prob = _Problem("totalvariation", eng, dict(A="D", c=0.0, nA=n, nB=n))
     elif kind == "basispursuit":
         P, q = _get(args, "P"), _get(args, "q")
         n = P.shape[0]

@@ -9,6 +9,7 @@
 
 #include "kernels.h"
 #include "loop_kernels.h"
+#include "tv.h"
 
 namespace admm {
 
@@ -94,7 +95,7 @@ struct admm_engine {
   // GEMV plans + partial buffers
   GemvNPlan planDN{};   // D*x
   GemvTPlan planDT{};   // D'*v
-  GemvNPlan planSq{};   // square nA x nA GEMV (Minv or P)
+  GemvTPlan planSq{};   // square symmetric nA x nA GEMV (Minv or P) run as column dots: M*v == M'*v
   double *partDN = nullptr, *partDT = nullptr, *partSq = nullptr;
 
   // iterates
@@ -102,6 +103,10 @@ struct admm_engine {
   int64_t ldg = 0;
   double *v = nullptr, *uhat = nullptr, *zprev = nullptr, *uprev = nullptr;
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
+  // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
+  double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
+  double* tv_bprefix = nullptr;
+  size_t tv_bprefix_cap = 0;
   double* part = nullptr;     // [S_COUNT][kMaxPartBlocks]
   double* objpart = nullptr;  // [kMaxPartBlocks]
   Ctrl* ctrl = nullptr;
@@ -245,8 +250,8 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
     (void)hipFree(X);
     for (auto& p : e->mem.ptrs)
       if (p == X) p = nullptr;
-    e->planSq = gemv_n_plan(nF, nF, ld);
-    ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+    e->planSq = gemv_t_plan(nF, nF, ld);
+    ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
   } else {
     double* dv = e->dinv;
     ADMM_TRY(trsv_build(W, nF, ld, &dv, &e->trsv, e->stream));
@@ -259,8 +264,8 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 // chunk partials in partSq unless `materialize`.
 void solve_factor(admm_engine* e, const double* y, double* out) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    launch_gemv_n(e->planSq, e->Minv, y, e->partSq, e->ctrl, e->stream);
-    launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldy, e->nF, out, e->ctrl, e->stream);
+    launch_gemv_t(e->planSq, e->Minv, y, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+    launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldg, e->nF, out, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
   }
@@ -472,8 +477,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       }
       E_TRY(factorize(e, W, n, ld, desc->L, mk));
       // the objective 1/2 x'Px + q'x + r needs P*x
-      e->planSq = gemv_n_plan(n, n, ld);
-      if (!e->partSq) E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+      e->planSq = gemv_t_plan(n, n, ld);
+      if (!e->partSq) E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
       break;
     }
     case ADMM_PROB_BASISPURSUIT: {
@@ -485,13 +490,29 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->rhs_kind = RHS_DIFF;
       E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
       E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
-      e->planSq = gemv_n_plan(n, n, e->ldP);
-      E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems()));
+      e->planSq = gemv_t_plan(n, n, e->ldP);
+      E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
       e->xsolve = ADMM_XSOLVE_INVERSE;  // x = P*(z-u) + q is a GEMV by construction
       break;
     }
+    case ADMM_PROB_TOTALVARIATION: {
+      // totalvariation.m:122-157: s is the (column) signal, D = spdiags([1 -1],0:1,n,n) is implicit
+      const int64_t nn = n > 0 ? n : m;
+      if (!desc->s || nn <= 0) return bail(fail(ADMM_E_INVALID, "Argument s is not a vector! (totalvariation.m:197)"));
+      if (desc->lambda < 0) return bail(fail(ADMM_E_INVALID, "Given lambda parameter is not a nonnegative number!"));
+      e->m = e->n = nn;
+      e->a_identity = false;
+      e->nA = nn;
+      e->len = nn;
+      e->prox = PROX_SOFT;
+      e->rhs_kind = RHS_NONE;
+      E_TRY(upload(e->mem, &e->s, desc->s, nn, mk, e->stream));
+      E_TRY(e->mem.alloc(&e->tv_y, round_up(nn, 2)));
+      E_TRY(e->mem.alloc(&e->tv_zB, round_up(nn, 2)));
+      E_TRY(e->mem.alloc(&e->tv_uB, round_up(nn, 2)));
+      break;
+    }
     case ADMM_PROB_LASSO_CONSENSUS:
-    case ADMM_PROB_TOTALVARIATION:
       return bail(fail(ADMM_E_UNSUPPORTED, "problem kind not engine-native yet"));
     default:
       return bail(fail(ADMM_E_INVALID, "Invalid input for problem - not a solver (getProxOps.m:916)"));
@@ -507,11 +528,13 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   E_TRY(e->mem.alloc(&e->uhat, L2));
   E_TRY(e->mem.alloc(&e->zprev, L2));
   E_TRY(e->mem.alloc(&e->uprev, L2));
-  if (!e->a_identity) {
+  if (!e->a_identity && e->problem != ADMM_PROB_TOTALVARIATION) {
     E_TRY(e->mem.alloc(&e->dz, L2));
     e->ldg = N2;
     E_TRY(e->mem.alloc(&e->g, 3 * N2));
   }
+  e->tv_zA = e->z;
+  e->tv_uA = e->u;
   E_TRY(e->mem.alloc(&e->part, static_cast<size_t>(S_COUNT) * kMaxPartBlocks));
   E_TRY(e->mem.alloc(&e->objpart, kMaxPartBlocks));
   {
@@ -547,10 +570,10 @@ static void x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int
     case ADMM_PROB_LASSO:
       if (!e->fat) {
         if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
-          launch_gemv_n(e->planSq, e->Minv, e->rhs, e->partSq, e->ctrl, e->stream);
+          launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
           *axsrc = e->partSq;
           *naxpart = e->planSq.nchunk;
-          *axld = e->planSq.ldy;
+          *axld = e->planSq.ldg;
         } else {
           launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
         }
@@ -568,18 +591,18 @@ static void x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int
     case ADMM_PROB_QP_BOUNDED:
       if (e->xsolve == ADMM_XSOLVE_INVERSE) {
         // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
-        GemvNPlan p = gemv_n_plan(e->nF, e->nF, e->ldF);
-        launch_gemv_n(p, e->Minv, e->rhs, e->partSq, e->ctrl, e->stream);
+        const GemvTPlan& p = e->planSq;
+        launch_gemv_t(p, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
         *axsrc = e->partSq;
         *naxpart = p.nchunk;
-        *axld = p.ldy;
+        *axld = p.ldg;
       } else {
         launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
       }
       break;
     case ADMM_PROB_BASISPURSUIT:
-      launch_gemv_n(e->planSq, e->Pmat, e->rhs, e->partSq, e->ctrl, e->stream);
-      launch_combine(e->partSq, e->planSq.nchunk, e->planSq.ldy, 1.0, nullptr, 0.0, e->q, e->x, e->n, e->ctrl,
+      launch_gemv_t(e->planSq, e->Pmat, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+      launch_combine(e->partSq, e->planSq.nchunk, e->planSq.ldg, 1.0, nullptr, 0.0, e->q, e->x, e->n, e->ctrl,
                      e->stream);
       break;
     default:  // LAD / Huber / SVM: rhs already holds D'*(c + z - u) (row 0 of g)
@@ -793,6 +816,116 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   xa.rho = o.rho;
   xa.rhs_kind = e->rhs_kind;
 
+  if (e->problem == ADMM_PROB_TOTALVARIATION) {
+    if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for total variation");
+    if (o.relax != 1.0)
+      return fail(ADMM_E_UNSUPPORTED,
+                  "relaxation with total variation applies D twice in the reference (getProxOps.m:199); not implemented");
+    std::vector<double> prefix;
+    double bstar = 0.0;
+    int halo = 0, elems = 0, tile = 0;
+    ADMM_TRY(tv_plan(o.rho, e->n, &prefix, &bstar, &halo, &elems, &tile));
+    if (prefix.size() > e->tv_bprefix_cap) {
+      ADMM_TRY(e->mem.alloc(&e->tv_bprefix, prefix.size()));
+      e->tv_bprefix_cap = prefix.size();
+    }
+    ADMM_HIP_TRY(hipMemcpyAsync(e->tv_bprefix, prefix.data(), sizeof(double) * prefix.size(), hipMemcpyHostToDevice,
+                                e->stream));
+    // the initial iterates were written to e->z / e->u; make buffer A the current one
+    if (e->z != e->tv_zA) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+    }
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    TvArgs ta{};
+    ta.n = e->n;
+    ta.rho = o.rho;
+    ta.thresh = e->lambda / o.rho;
+    ta.s = e->s;
+    ta.x = e->x;
+    ta.y = e->tv_y;
+    ta.bprefix = e->tv_bprefix;
+    ta.nprefix = static_cast<int64_t>(prefix.size());
+    ta.bstar = bstar;
+    ta.halo = halo;
+    ta.elems = elems;
+    ta.tile = tile;
+    ta.objevals = o.objevals;
+    ta.xhist = e->xhist;
+    ta.zhist = e->zhist;
+    ta.uhist = e->uhist;
+    ta.part = e->part;
+    fa.g = nullptr;
+    fa.x = nullptr;
+    fa.xhist = nullptr;
+    fa.dual_from_slots = 1;
+    if (o.objevals) {  // totalvariation.m:134-135
+      fa.obj_scale_x = 0.5;
+      fa.obj_scale_z = e->lambda;
+    }
+    const int check_tv = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t done = 0;
+    bool stop_seen = false;
+    while (done < N && !stop_seen) {
+      const int32_t batch = (N - done < check_tv) ? N - done : check_tv;
+      for (int32_t b = 0; b < batch; ++b) {
+        const bool a_cur = ((done + b) & 1) == 0;  // iteration k reads A when k is even
+        ta.z = a_cur ? e->tv_zA : e->tv_zB;
+        ta.u = a_cur ? e->tv_uA : e->tv_uB;
+        ta.zo = a_cur ? e->tv_zB : e->tv_zA;
+        ta.uo = a_cur ? e->tv_uB : e->tv_uA;
+        {
+          TimerScope ts(e, ADMM_K_XSOLVE);
+          launch_tv_sweep(ta, false, e->ctrl, e->stream);
+          launch_tv_sweep(ta, true, e->ctrl, e->stream);
+        }
+        int nblk = 1;
+        {
+          TimerScope ts(e, ADMM_K_PROX);
+          launch_tv_prox(ta, e->ctrl, &nblk, e->stream);
+        }
+        fa.nblk = nblk;
+        {
+          TimerScope ts(e, ADMM_K_FINALIZE);
+          launch_finalize(fa, e->stream);
+        }
+      }
+      done += batch;
+      if (!o.domaxiters || done >= N) {
+        ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->ctrl_host->stop) stop_seen = true;
+      }
+    }
+    ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+    }
+    const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (e->profiling) collect_timers(e);
+    const int32_t steps = e->ctrl_host->steps;
+    // iterations executed on the device decide which ping-pong buffer holds the final z, u
+    e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
+    e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+    e->last = admm_run_summary{};
+    e->last.steps = steps;
+    e->last.stopped_early = (steps < N) ? 1 : 0;
+    e->last.convtest_failed_at = e->ctrl_host->convfail;
+    e->last.runtime_s = rt;
+    e->last.objopt = NAN;
+    if (o.objevals && steps > 0) {
+      double v = NAN;
+      ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+      e->last.objopt = v;
+    }
+    e->has_run = true;
+    if (summary) *summary = e->last;
+    return ADMM_OK;
+  }
+
   const int nrhs_dual = o.nodualerror ? 1 : 3;
   int check_every = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
 
@@ -852,9 +985,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         fa.nobjpart = nob;
       } else if (obj_qp_gemv) {  // 1/2 x'Px + q'x + r  (quadraticprogram.m:242)
         int nob = 0;
-        GemvNPlan p = gemv_n_plan(e->n, e->n, e->ldP);
-        launch_gemv_n(p, e->Pmat, e->x, e->partSq, e->ctrl, e->stream);
-        launch_qp_objective(e->partSq, p.nchunk, p.ldy, e->x, e->q, e->n, e->objpart, &nob, e->ctrl, e->stream);
+        const GemvTPlan& p = e->planSq;  // P is symmetric
+        launch_gemv_t(p, e->Pmat, e->x, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+        launch_qp_objective(e->partSq, p.nchunk, p.ldg, e->x, e->q, e->n, e->objpart, &nob, e->ctrl, e->stream);
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
       }

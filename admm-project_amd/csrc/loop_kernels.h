@@ -39,7 +39,9 @@ enum Slot : int32_t {
   S_OBJX = 7,
   S_DUH2 = 8,  // ||u - uhat||^2                       admm.m:572
   S_DZV2 = 9,  // ||z - v||^2                          admm.m:573
-  S_COUNT = 10
+  S_G2 = 10,   // ||D'(z - zprev)||^2 via stencil (TV)   admm.m:624
+  S_G3 = 11,   // ||D'u||^2 via stencil (TV)             admm.m:654
+  S_COUNT = 12
 };
 
 struct ProxArgs {
@@ -112,6 +114,7 @@ struct FinArgs {
   double rho, rhoH;
   double abstol, reltol, Hnormtol, convtol, restart, dvaltol;
   int32_t alg, a_identity, nodualerror, objevals, use_h, convtest, stopcond, domaxiters, maxiters;
+  int32_t dual_from_slots;  // dual norms come from S_G2/S_G3 (stencil operators) instead of g
   double* pnorm;
   double* dnorm;
   double* perr;

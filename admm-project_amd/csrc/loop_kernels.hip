@@ -271,14 +271,26 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
   Ctrl* ctrl = a.ctrl;
   if (ctrl->stop) return;
   __shared__ double scratch[4];
-  __shared__ double S[S_COUNT + 4];
+  __shared__ double S[16];
   const int it = ctrl->iter;
-  for (int s = 0; s < S_COUNT; ++s) {
-    const double v = sum_slot(a.part, s, a.nblk, scratch);
-    if (threadIdx.x == 0) S[s] = v;
+  {
+    // all slots at once: 16 lanes per slot stride over the block partials, then a 16-lane
+    // shuffle tree (fixed order -> reproducible); one round of global loads instead of S_COUNT.
+    static_assert(S_COUNT <= 16, "slot layout");
+    const int slot = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    double v = 0.0;
+    if (slot < S_COUNT)
+      for (int b = sub; b < a.nblk; b += 16) v += a.part[slot * kMaxPartBlocks + b];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (sub == 0) S[slot] = v;
+    __syncthreads();
   }
   double ng2 = 0.0, ng3 = 0.0, nx2 = 0.0, objp = 0.0;
-  if (a.g && !a.nodualerror) {
+  if (a.dual_from_slots) {
+    ng2 = S[S_G2];
+    ng3 = S[S_G3];
+  } else if (a.g && !a.nodualerror) {
     double s2 = 0.0, s3 = 0.0;
     for (int64_t j = threadIdx.x; j < a.nA; j += blockDim.x) {
       const double g2 = a.g[a.ldg + j], g3 = a.g[2 * a.ldg + j];

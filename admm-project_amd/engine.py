@@ -19,7 +19,7 @@ class Engine:
 
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
-                 device=0, slices=None, comm=None):
+                 device=0, slices=None, comm=None, nvec=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -47,6 +47,8 @@ class Engine:
             if D is None:
                 d.m = Pm.shape[0]
             d.P = L.as_dp(Pm)
+        if nvec is not None:  # problems without a data matrix (total variation): vector length
+            d.m = d.n = int(nvec)
         if s is not None:
             d.s = vec(s)
         if ell is not None:

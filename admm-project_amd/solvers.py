@@ -15,7 +15,8 @@ import numpy as np
 from .api import admm, getproxops
 from .errorcheck import is_nonnegative_real, is_positive_real
 
-__all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit"]
+__all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit",
+           "totalvariation"]
 
 _ENGINE_OBJ = "<engine-native objective>"
 
@@ -220,3 +221,40 @@ def basispursuit(D, s, options=None):
     results = admm(minx, minz, options)
     results["solverruntime"] = time.perf_counter() - t0
     return results
+
+
+def totalvariation(s, lam, options=None):
+    """results = totalvariation(s, lambda, options)   (solvers/totalvariation.m:62-167)
+
+    minimise 1/2*||x - s||_2^2 + lambda*sum|x_{i+1} - x_i| (1-D signal).  The difference operator
+    D = spdiags([1 -1], 0:1, n, n) (totalvariation.m:127) is never formed on the device: its
+    stencils are fused into the kernels and (I + rho*D'D) is solved by parallel recurrences.
+    """
+    import scipy.sparse as sp
+
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    if not np.isscalar(lam) or np.real(lam) < 0:  # totalvariation.m:190-194
+        raise ValueError("Given lambda parameter is not a nonnegative number!")
+    lam = float(np.real(lam))
+    s = _colvec(s, "s")
+    n = s.size
+    args = _engine_args(options, dict(s=s))
+    args["lambda"] = lam
+    xmin, zmin, _ = getproxops("TotalVariation", args)
+    D = sp.diags([np.ones(n), -np.ones(n - 1)], [0, 1], shape=(n, n), format="csr") if n <= (1 << 22) else \
+        _ShapeOnly((n, n))
+    options.update(A=D, At=None, B=-1, mB=n, nB=n, c=0, m=n)  # totalvariation.m:151-157
+    options["obj"] = _ENGINE_OBJ  # totalvariation.m:134-135
+    results = admm(xmin, zmin, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+class _ShapeOnly:
+    """Stand-in for options.A when materialising the sparse operator would only cost memory."""
+
+    def __init__(self, shape):
+        self.shape = shape
