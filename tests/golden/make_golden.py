@@ -86,6 +86,10 @@ def main():
     o = dict(objevals=1)
     save("basispursuit_32x96", dict(D=p["D"], s=p["s"]), o, S.basispursuit(p["D"], p["s"], o))
 
+    p = ap.synth.tv_problem(0, 512)
+    o = dict(objevals=1, maxiters=10000)
+    save("tv_512", dict(s=p["s"], lam=p["lam"], truex=p["truex"]), o, S.totalvariation(p["s"], p["lam"], o))
+
 
 if __name__ == "__main__":
     main()

@@ -45,6 +45,8 @@ def test_oracle_reproduces_fixture(path):
         r = S.linearsvm(inp["D"], inp["ell"], float(inp["C"]), o)
     elif name.startswith("qp"):
         r = S.quadraticprogram_bounded(inp["P"], inp["q"], float(inp["r"]), inp["lb"], inp["ub"], o)
+    elif name.startswith("tv"):
+        r = S.totalvariation(inp["s"], float(inp["lam"]), o)
     else:
         r = S.basispursuit(inp["D"], inp["s"], o)
     assert r["steps"] == int(z["steps"])

@@ -191,6 +191,44 @@ def test_basispursuit(gpu):
     _compare(gpu.basispursuit(p["D"], p["s"], o), S.basispursuit(p["D"], p["s"], o))
 
 
+@pytest.mark.parametrize("n,lam,rho,opts", [
+    (128, 1.0, 1.0, dict(maxiters=10000)),          # totalvariationtest.m defaults
+    (1000, 2.0, 1.0, dict()),
+    (5000, 0.5, 3.0, dict(stopcond="both")),        # several tiles + halo overlap
+    (9973, 1.0, 0.25, dict(convtest=1)),
+    (4096, 1.0, 40.0, dict(maxiters=300)),          # slower-decaying recurrence (halo ~ 270)
+    (2, 1.0, 1.0, dict(maxiters=5)), (257, 0.0, 1.0, dict(maxiters=20)),
+])
+def test_total_variation(gpu, n, lam, rho, opts):
+    p = gpu.synth.tv_problem(n % 97, n)
+    o = dict(objevals=1, rho=rho, **opts)
+    got = gpu.totalvariation(p["s"], lam, o)
+    ref = S.totalvariation(p["s"], lam, o)
+    _compare(got, ref)
+    if n == 128:  # totalvariationtest.m:151
+        obj = lambda x: 0.5 * np.sum((x - p["s"]) ** 2) + lam * np.sum(np.abs(np.diff(x)))
+        assert obj(got["xopt"]) < obj(p["truex"])
+
+
+def test_total_variation_second_run_and_errors(gpu):
+    p = gpu.synth.tv_problem(3, 3000)
+    args = dict(s=p["s"])
+    args["lambda"] = 1.0
+    minx, minz, _ = gpu.getproxops("TotalVariation", args)
+    import scipy.sparse as sp
+    D = sp.diags([np.ones(3000), -np.ones(2999)], [0, 1], format="csr")
+    base = dict(A=D, B=-1, c=0, m=3000, nB=3000)
+    a = gpu.admm(minx, minz, dict(base, maxiters=7, domaxiters=1))   # odd step count: ping-pong parity
+    b = gpu.admm(minx, minz, dict(base, maxiters=7, domaxiters=1))
+    np.testing.assert_array_equal(a["zopt"], b["zopt"])
+    np.testing.assert_array_equal(a["zopt"], a["zvals"][:, -1])
+    np.testing.assert_array_equal(a["uopt"], a["uvals"][:, -1])
+    with pytest.raises(gpu.AdmmError):
+        gpu.admm(minx, minz, dict(base, relax=1.5))
+    with pytest.raises(gpu.AdmmError):
+        gpu.admm(minx, minz, dict(base, fast=1))
+
+
 def test_precomputed_factor_is_used(gpu):
     """args.L handed in by the caller (lasso.m:183) must give the same iterates as the on-device factor."""
     import scipy.linalg as sla
@@ -281,6 +319,8 @@ def test_golden_fixture(gpu, path):
         got = gpu.quadraticprogram(inp["P"], inp["q"], float(inp["r"]), inp["lb"], inp["ub"], o)
     elif name.startswith("basispursuit"):
         got = gpu.basispursuit(inp["D"], inp["s"], o)
+    elif name.startswith("tv"):
+        got = gpu.totalvariation(inp["s"], float(inp["lam"]), o)
     else:
         pytest.fail(f"no runner for fixture {name}")
     ref = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
