@@ -31,6 +31,7 @@ FAST_OFF, FAST_STRONG, FAST_WEAK = 0, 1, 2
 
 K_XSOLVE, K_GEMV_N, K_GEMV_T, K_PROX, K_FINALIZE, K_COUNT = 0, 1, 2, 3, 4, 5
 COMM_ID_BYTES = 128
+COMM_RCCL, COMM_SHM = 0, 1
 
 _dp = C.POINTER(C.c_double)
 
@@ -97,7 +98,8 @@ _SIGNATURES = {
     "admm_op_trsv_pair": (C.c_int, [_dp, C.c_int64, C.c_int64, _dp, _dp]),
     "admm_op_soft_threshold": (C.c_int, [_dp, C.c_int64, C.c_double, _dp]),
     "admm_comm_unique_id": (C.c_int, [C.c_char_p]),
-    "admm_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "admm_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "admm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "admm_comm_allreduce_sum": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
     "admm_comm_destroy": (None, [C.c_void_p]),
 }

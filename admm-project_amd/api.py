@@ -76,6 +76,9 @@ def getproxops(problem, args):
     xs = {"auto": L.XSOLVE_AUTO, "trsv": L.XSOLVE_TRSV, "inverse": L.XSOLVE_INVERSE,
           "cg": L.XSOLVE_CG}[str(args.get("xsolve", "auto")).lower()]
     dev = int(args.get("device", 0))
+    comm = args.get("comm")  # parallel.Comm: D/s/ell are then this rank's rows (see parallel.py)
+    if comm is not None:
+        dev = comm.device
     extra = {}
 
     if kind == "lasso":
@@ -91,21 +94,21 @@ def getproxops(problem, args):
         Lf = args.get("L")
         if Lf is not None and hasattr(Lf, "toarray"):
             Lf = Lf.toarray()  # lasso.m:175 stores the factor sparse
-        eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev)
+        eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev, comm=comm)
         prob = _Problem("lasso", eng, dict(A=1, c=0.0, nA=n, nB=n))
     elif kind in ("lad", "huberfit"):
         D, s = _get(args, "D"), _get(args, "s")
         m, n = D.shape
         code = L.PROB_LAD if kind == "lad" else L.PROB_HUBERFIT
         eng = Engine(code, D=D, s=s, Lfactor=args.get("R"), userelax=int(bool(args.get("userelax", 0))),
-                     xsolve=xs, device=dev)
+                     xsolve=xs, device=dev, comm=comm)
         prob = _Problem(kind, eng, dict(A="D", c="s", nA=n, nB=m))
     elif kind == "linearsvm":
         D, ell, Cval = _get(args, "D"), _get(args, "ell"), _get(args, "C")
         loss = args.get("lossfunction", "hinge")
         m, n = D.shape
         eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
-                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev)
+                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev, comm=comm)
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
     elif kind == "quadraticprogram":
         if _get(args, "constraint") != "bounded":

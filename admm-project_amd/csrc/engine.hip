@@ -65,7 +65,9 @@ struct admm_engine {
   int problem = 0;
   int64_t m = 0, n = 0;  // D is m x n (local rows)
   int64_t nA = 0;        // length of x
-  int64_t len = 0;       // nB = length of z, u, c
+  int64_t len = 0;       // nB = length of z, u, c (local rows when sharded)
+  int64_t len_global = 0;  // rows over all ranks (0 = not sharded / A = I)
+  double* red = nullptr;   // 32 doubles: packed scalar all-reduce payloads
   bool a_identity = true;
   int prox = PROX_SOFT;
   int rhs_kind = RHS_NONE;
@@ -376,7 +378,24 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (xs == ADMM_XSOLVE_AUTO) xs = ADMM_XSOLVE_TRSV;
   if (xs == ADMM_XSOLVE_CG) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=CG is not implemented yet"));
   e->xsolve = xs;
-  if (e->comm) return bail(fail(ADMM_E_UNSUPPORTED, "row-sharded engines are not implemented yet"));
+  const bool sharded = e->comm && comm_nranks(e->comm) > 1;
+  if (sharded && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
+      desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
+    return bail(fail(ADMM_E_UNSUPPORTED, "row sharding applies to problems with a data matrix D (lasso/LAD/Huber/SVM)"));
+  // global number of rows of D (the local m when not sharded)
+  int64_t m_global = m;
+  if (sharded) {
+    double* cnt = nullptr;
+    E_TRY(e->mem.alloc(&cnt, 2));
+    const double mine = static_cast<double>(m);
+    E_HIP(hipMemcpyAsync(cnt, &mine, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    E_TRY(comm_allreduce_device(e->comm, cnt, 1, e->stream));
+    double tot = 0.0;
+    E_HIP(hipMemcpyAsync(&tot, cnt, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    E_HIP(hipStreamSynchronize(e->stream));
+    m_global = static_cast<int64_t>(tot + 0.5);
+  }
+  e->len_global = 0;
 
   switch (desc->problem) {
     case ADMM_PROB_LASSO: {
@@ -387,7 +406,9 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->len = n;
       e->prox = PROX_SOFT;
       e->rhs_kind = RHS_RHO_DTS;
-      e->fat = m < n;
+      e->fat = m_global < n;
+      if (sharded && e->fat)
+        return bail(fail(ADMM_E_UNSUPPORTED, "row-sharded lasso needs a tall matrix (global m >= n)"));
       E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
       E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
       e->planDN = gemv_n_plan(m, n, e->ldD);
@@ -398,6 +419,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(e->mem.alloc(&e->rhs_add, round_up(n, 2)));
       launch_gemv_t(e->planDT, e->D, e->s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
       launch_sum_partials_t(e->planDT, e->partDT, 1, e->rhs_add, round_up(n, 2), nullptr, e->stream);
+      if (sharded) E_TRY(comm_allreduce_device(e->comm, e->rhs_add, n, e->stream));  // sum_g D_g'*s_g
       const int64_t nF = e->fat ? m : n;
       const int64_t ld = round_up(nF, 16);
       double* W = nullptr;
@@ -406,6 +428,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
         if (!e->fat) {  // lasso.m:168  chol(D'*D + rho*I)
           launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+          // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
+          if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
           launch_add_diag(W, n, ld, desc->rho, e->stream);
         } else {  // lasso.m:172  chol(1/rho*(D*D') + I)
           launch_gemm(0, 1, m, m, n, 1.0 / desc->rho, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
@@ -426,10 +450,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (!desc->D || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "problem needs D (m x n)"));
       if (!svm && !desc->s) return bail(fail(ADMM_E_INVALID, "LAD/Huber need the signal vector s"));
       if (svm && !desc->ell) return bail(fail(ADMM_E_INVALID, "linear SVM needs the label vector ell"));
-      if (m < n) return bail(fail(ADMM_E_INVALID, "D must have full column rank (m >= n) for chol(D'*D) (lad.m:134)"));
+      if (m_global < n)
+        return bail(fail(ADMM_E_INVALID, "D must have full column rank (m >= n) for chol(D'*D) (lad.m:134)"));
       e->a_identity = false;
       e->nA = n;
       e->len = m;
+      e->len_global = m_global;
       e->rhs_kind = RHS_T1;
       if (desc->problem == ADMM_PROB_LAD) e->prox = PROX_SOFT;
       else if (desc->problem == ADMM_PROB_HUBERFIT) e->prox = PROX_HUBER;
@@ -451,6 +477,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (!desc->L) {  // lad.m:134  chol(D'*D,'lower') (un-shifted; also D^+ = (D'D)^-1 D' for the SVM)
         E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
         launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+        // W = sum_g D_g'*D_g  (unwrappedadmm.m:96-123)
+        if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
       }
       E_TRY(factorize(e, W, n, ld, desc->L, mk));
       break;
@@ -531,8 +559,9 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (!e->a_identity && e->problem != ADMM_PROB_TOTALVARIATION) {
     E_TRY(e->mem.alloc(&e->dz, L2));
     e->ldg = N2;
-    E_TRY(e->mem.alloc(&e->g, 3 * N2));
+    E_TRY(e->mem.alloc(&e->g, 3 * N2 + 16));  // + 16 reduction slots: one all-reduce payload
   }
+  E_TRY(e->mem.alloc(&e->red, 32));  // packed scalar payloads of the sharded runs
   e->tv_zA = e->z;
   e->tv_uA = e->u;
   E_TRY(e->mem.alloc(&e->part, static_cast<size_t>(S_COUNT) * kMaxPartBlocks));
@@ -550,6 +579,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     E_HIP(hipStreamSynchronize(e->stream));
     double ss = 0.0;
     for (double vv : hc) ss += vv * vv;
+    if (sharded) {  // ||c||^2 = sum over the row shards
+      E_HIP(hipMemcpyAsync(e->red, &ss, sizeof(double), hipMemcpyHostToDevice, e->stream));
+      E_TRY(comm_allreduce_device(e->comm, e->red, 1, e->stream));
+      E_HIP(hipMemcpyAsync(&ss, e->red, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+      E_HIP(hipStreamSynchronize(e->stream));
+    }
     e->cnorm = std::sqrt(ss);
   }
   E_HIP(hipStreamSynchronize(e->stream));
@@ -927,6 +962,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   }
 
   const int nrhs_dual = o.nodualerror ? 1 : 3;
+  const bool sharded = e->comm && comm_nranks(e->comm) > 1;
+  fa.len_global = e->len_global;
   int check_every = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
 
   // ---- loop (admm.m:315 tic .. 756 toc)
@@ -937,6 +974,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     TimerScope ts(e, ADMM_K_GEMV_T);
     launch_gemv_t(e->planDT, e->D, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
     launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+    if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
   }
   int32_t enq = 0;
   bool stopped = false;
@@ -964,7 +1002,15 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_prox(pa, e->ctrl, &nblk, e->stream);
       }
       fa.nblk = nblk;
+      fa.slots_reduced = nullptr;
+      fa.objp_reduced = nullptr;
+      const bool shard_rows = sharded && !e->a_identity;  // z, u and the residual sums are row-local
       if (alg == 2) {
+        if (shard_rows) {  // the restart decision needs the global ||u-uhat||^2, ||z-v||^2 (admm.m:572-573)
+          launch_pack_slots(e->part, nblk, e->red, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red, 16, e->stream));
+          fa.slots_reduced = e->red;
+        }
         launch_fast_decide(fa, e->stream);
         launch_extrapolate(xa, e->ctrl, e->stream);
       }
@@ -972,6 +1018,20 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         TimerScope ts(e, ADMM_K_GEMV_T);
         launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs_dual, e->partDT, e->ctrl, e->stream);
         launch_sum_partials_t(e->planDT, e->partDT, nrhs_dual, e->g, e->ldg, e->ctrl, e->stream);
+        if (shard_rows) {
+          // ONE all-reduce per iteration: d = sum_g D_g'(...) (unwrappedadmm.m:135-137) for up to
+          // three right-hand sides plus the 16 residual/objective partial sums (X3 + X6)
+          double* slots = e->g + 3 * e->ldg;
+          if (alg == 2) ADMM_HIP_TRY(hipMemcpyAsync(slots, e->red, 16 * sizeof(double), hipMemcpyDeviceToDevice,
+                                                     e->stream));
+          else launch_pack_slots(e->part, nblk, slots, e->ctrl, e->stream);
+          if (alg == 2) {  // slots were already reduced: only the vectors travel
+            ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(3 * e->ldg), e->stream));
+          } else {
+            ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(3 * e->ldg + 16), e->stream));
+          }
+          fa.slots_reduced = slots;
+        }
       }
       fa.objpart = nullptr;
       fa.nobjpart = 0;
@@ -983,6 +1043,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
                            e->stream);
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
+        if (sharded) {  // sum over the row shards of ||D_g*x - s_g||^2
+          launch_pack_sum(e->objpart, nob, e->red + 16, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 1, e->stream));
+          fa.objp_reduced = e->red + 16;
+        }
       } else if (obj_qp_gemv) {  // 1/2 x'Px + q'x + r  (quadraticprogram.m:242)
         int nob = 0;
         const GemvTPlan& p = e->planSq;  // P is symmetric

@@ -115,6 +115,10 @@ struct FinArgs {
   double abstol, reltol, Hnormtol, convtol, restart, dvaltol;
   int32_t alg, a_identity, nodualerror, objevals, use_h, convtest, stopcond, domaxiters, maxiters;
   int32_t dual_from_slots;  // dual norms come from S_G2/S_G3 (stencil operators) instead of g
+  // row-sharded runs: sums already reduced over blocks AND ranks (all-reduced), else null
+  const double* slots_reduced;  // [16]
+  const double* objp_reduced;   // [1]
+  int64_t len_global;           // numel(Ax) over all ranks (admm.m:644-645); 0 = use len
   double* pnorm;
   double* dnorm;
   double* perr;
@@ -131,6 +135,10 @@ void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t
 void launch_fast_decide(const FinArgs& a, hipStream_t stream);   // alg 2: d, restart decision, alpha
 void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_finalize(const FinArgs& a, hipStream_t stream);
+// out[slot] = sum over blocks of part[slot][.] (slot < 16): the payload of the per-iteration all-reduce
+void launch_pack_slots(const double* part, int32_t nblk, double* out16, const Ctrl* ctrl, hipStream_t stream);
+// out[0] = sum of v[0..n)
+void launch_pack_sum(const double* v, int32_t n, double* out1, const Ctrl* ctrl, hipStream_t stream);
 // rhs for the very first x-update from (zx, ux): same formulas as the fused epilogue
 void launch_initial_rhs(int64_t len, int rhs_kind, double rho, const double* zx, const double* ux, const double* c,
                         const double* rhs_add, double* rhs, hipStream_t stream);

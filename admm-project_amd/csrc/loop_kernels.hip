@@ -175,8 +175,8 @@ __global__ __launch_bounds__(kBlock) void fast_decide_kernel(FinArgs a) {
   Ctrl* ctrl = a.ctrl;
   if (ctrl->stop) return;
   __shared__ double scratch[4];
-  const double s_duh = sum_slot(a.part, S_DUH2, a.nblk, scratch);
-  const double s_dzv = sum_slot(a.part, S_DZV2, a.nblk, scratch);
+  const double s_duh = a.slots_reduced ? a.slots_reduced[S_DUH2] : sum_slot(a.part, S_DUH2, a.nblk, scratch);
+  const double s_dzv = a.slots_reduced ? a.slots_reduced[S_DZV2] : sum_slot(a.part, S_DZV2, a.nblk, scratch);
   if (threadIdx.x == 0) {
     const double aprev = ctrl->acurr;  // admm.m:504
     const double dprev = ctrl->d;      // admm.m:509
@@ -273,7 +273,10 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
   __shared__ double scratch[4];
   __shared__ double S[16];
   const int it = ctrl->iter;
-  {
+  if (a.slots_reduced) {  // row-sharded: already summed over blocks and ranks
+    if (threadIdx.x < 16) S[threadIdx.x] = a.slots_reduced[threadIdx.x];
+    __syncthreads();
+  } else {
     // all slots at once: 16 lanes per slot stride over the block partials, then a 16-lane
     // shuffle tree (fixed order -> reproducible); one round of global loads instead of S_COUNT.
     static_assert(S_COUNT <= 16, "slot layout");
@@ -309,12 +312,15 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
     }
     nx2 = block_sum(s, scratch);
   }
-  if (a.objpart) {
+  if (a.objp_reduced) {
+    objp = a.objp_reduced[0];
+  } else if (a.objpart) {
     double s = 0.0;
     for (int b = threadIdx.x; b < a.nobjpart; b += blockDim.x) s += a.objpart[b];
     objp = block_sum(s, scratch);
   }
   if (threadIdx.x != 0) return;
+  const double Mlen = static_cast<double>(a.len_global > 0 ? a.len_global : a.len);
 
   const int i1 = it + 1;  // 1-based iteration number (admm.m loop variable)
   const double NaN = __longlong_as_double(0x7ff8000000000000LL);
@@ -355,9 +361,9 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
       // alg 0: ||rho*At(B(z - zprev))||; alg 1: rho*||At(B(z - v))|| with z - v = -coef*(z - zprev)
       dn = (a.alg == 0) ? a.rho * base : a.rho * (fabs(coef) * base);
       const double un = a.a_identity ? sqrt(S[S_U2]) : sqrt(ng3);
-      de = sqrt(static_cast<double>(a.len)) * a.abstol + a.reltol * (a.rho * un);
+      de = sqrt(Mlen) * a.abstol + a.reltol * (a.rho * un);
     }
-    const double pe = sqrt(static_cast<double>(a.len)) * a.abstol +
+    const double pe = sqrt(Mlen) * a.abstol +
                       a.reltol * fmax(fmax(sqrt(S[S_AX2]), sqrt(S[S_Z2])), a.cnorm);
     a.pnorm[it] = pn;
     a.dnorm[it] = dn;
@@ -391,6 +397,38 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
 
 void launch_finalize(const FinArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, a);
+}
+
+// ---------------------------------------------------------------- all-reduce payload packing
+__global__ __launch_bounds__(kBlock) void pack_slots_kernel(const double* __restrict__ part, int32_t nblk,
+                                                            double* __restrict__ out16,
+                                                            const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  const int slot = threadIdx.x >> 4, sub = threadIdx.x & 15;
+  double v = 0.0;
+  if (slot < S_COUNT)
+    for (int b = sub; b < nblk; b += 16) v += part[slot * kMaxPartBlocks + b];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (sub == 0) out16[slot] = v;
+}
+
+void launch_pack_slots(const double* part, int32_t nblk, double* out16, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_slots_kernel, dim3(1), dim3(kBlock), 0, stream, part, nblk, out16, ctrl);
+}
+
+__global__ __launch_bounds__(kBlock) void pack_sum_kernel(const double* __restrict__ v, int32_t n,
+                                                          double* __restrict__ out1, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double scratch[4];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < n; b += blockDim.x) s += v[b];
+  const double t = block_sum(s, scratch);
+  if (threadIdx.x == 0) out1[0] = t;
+}
+
+void launch_pack_sum(const double* v, int32_t n, double* out1, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_sum_kernel, dim3(1), dim3(kBlock), 0, stream, v, n, out1, ctrl);
 }
 
 // ---------------------------------------------------------------- small helpers

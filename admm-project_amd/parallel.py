@@ -1,0 +1,87 @@
+"""Row-sharded (multi-GPU) runs: one process per GPU, rows of D split with the reference's
+``slicemaker(0, workers, len)`` rule (errorcheck.m:249-259), sums of D_g' products and of the
+residual partials exchanged by ONE all-reduce per iteration inside the engine (RCCL over xGMI).
+
+This replaces the reference's ``parfor`` transpose reduction (unwrappedadmm.m:96-141) and is
+used by passing ``options['comm'] = Comm`` and the LOCAL rows to the ordinary solvers:
+
+    comm = parallel.init_from_torch(dist, device=local_rank)          # after init_process_group
+    lo, hi = parallel.my_rows(m, comm)
+    results = admm_project_amd.lad(D[lo:hi], s[lo:hi], dict(comm=comm))
+
+x (and everything derived from it) is replicated and identical on all ranks; z, u and their
+histories are this rank's row slice.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .errorcheck import rank_rows
+
+__all__ = ["Comm", "unique_id", "init_from_torch", "my_rows", "gather_rows"]
+
+
+def unique_id():
+    """128-byte communicator id (RCCL's ncclUniqueId when a GPU is present, random bytes otherwise)."""
+    buf = C.create_string_buffer(L.COMM_ID_BYTES)
+    L.check(L.load().admm_comm_unique_id(buf))
+    return bytes(buf.raw)
+
+
+class Comm:
+    """Owner of one ``admm_comm`` handle."""
+
+    def __init__(self, uid, rank, nranks, device=0, transport="rccl"):
+        if len(uid) != L.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM}[transport]
+        h = C.c_void_p()
+        L.check(L.load().admm_comm_init(uid, int(rank), int(nranks), int(device), tr, C.byref(h)))
+        self.handle = h
+        self.rank, self.nranks, self.device, self.transport = int(rank), int(nranks), int(device), transport
+
+    def allreduce_sum(self, host_array):
+        """Sum a host fp64 array over the ranks (convenience / tests; the loop reduces on the device)."""
+        a = np.ascontiguousarray(host_array, dtype=np.float64)
+        L.check(L.load().admm_comm_allreduce_sum(self.handle, L.as_dp(a), a.size))
+        return a
+
+    def close(self):
+        if getattr(self, "handle", None):
+            L.load().admm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def init_from_torch(dist, device=0, transport="rccl"):
+    """Create the engine communicator from an initialised ``torch.distributed`` group: rank 0
+    makes the unique id, ``broadcast_object_list`` hands it to the others (works with gloo and nccl)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Comm(box[0], rank, world, device=device, transport=transport)
+
+
+def my_rows(length, comm_or_rank, nranks=None):
+    """[lo, hi) rows of this rank: slicemaker(0, nranks, length) (errorcheck.m:249-259)."""
+    if nranks is None:
+        return rank_rows(length, comm_or_rank.rank, comm_or_rank.nranks)
+    return rank_rows(length, int(comm_or_rank), int(nranks))
+
+
+def gather_rows(dist, local, length):
+    """All-gather row-sharded result slices (first axis) back into the full array, in rank order."""
+    world = dist.get_world_size()
+    parts = [None] * world
+    dist.all_gather_object(parts, np.asarray(local))
+    out = np.concatenate(parts, axis=0)
+    assert out.shape[0] == length
+    return out

@@ -25,7 +25,7 @@ def _randn_cols(rng_seed, rows, cols, threads=None):
             out[:, j0:j1] = rng.standard_normal((j1 - j0, rows)).T
         return out
     threads = threads or min(32, os.cpu_count() or 1)
-    blk = max(1, -(-cols // (threads * 4)))
+    blk = 64  # fixed column-block size: the data must not depend on the thread count
     blocks = [(j0, min(cols, j0 + blk)) for j0 in range(0, cols, blk)]
     seeds = np.random.SeedSequence(rng_seed).spawn(len(blocks))
 
@@ -41,11 +41,48 @@ def _randn_cols(rng_seed, rows, cols, threads=None):
     return out
 
 
-def lasso_problem(seed=0, rows=2 ** 8, cols=2 ** 6, threads=None):
+def _unit_cols_rows(rng_seed, rows, cols, lo, hi, threads=None):
+    """Rows [lo, hi) of the column-normalised randn(rows, cols) that ``_randn_cols`` (large path)
+    + normalisation produce, without ever holding the full matrix (row-sharded ranks)."""
+    out = np.empty((hi - lo, cols), dtype=np.float64, order="F")
+    threads = threads or min(32, os.cpu_count() or 1)
+    blk = 64  # fixed column-block size: the data must not depend on the thread count
+    blocks = [(j0, min(cols, j0 + blk)) for j0 in range(0, cols, blk)]
+    seeds = np.random.SeedSequence(rng_seed).spawn(len(blocks))
+
+    def fill(args):
+        (j0, j1), ss = args
+        rng = np.random.default_rng(ss)
+        col = np.empty(rows)
+        for j in range(j0, j1):
+            rng.standard_normal(rows, out=col)
+            out[:, j] = col[lo:hi] / np.sqrt(col @ col)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(fill, zip(blocks, seeds)))
+    return out
+
+
+def lasso_problem(seed=0, rows=2 ** 8, cols=2 ** 6, threads=None, row_range=None):
     """testers/lassotest.m:109-122: D=randn with unit-norm columns, 60 %-dense planted
-    testx, s = D*testx + sqrt(0.001)*randn, lambda = 0.1*||D's||_inf."""
+    testx, s = D*testx + sqrt(0.001)*randn, lambda = 0.1*||D's||_inf.
+
+    ``row_range=(lo, hi)``: return only those rows of D and s (one rank's shard of the same
+    problem); ``lam`` is then computed from the LOCAL D's and must be re-derived by the caller
+    from the all-reduced D's."""
     rng = np.random.default_rng(seed)
     testx = np.where(rng.random(cols) < 0.6, rng.standard_normal(cols), 0.0)
+    if row_range is not None:
+        lo, hi = row_range
+        if rows * cols < (1 << 22):
+            full = lasso_problem(seed, rows, cols, threads)
+            D = np.asfortranarray(full["D"][lo:hi])
+            return dict(D=D, s=full["s"][lo:hi].copy(), lam=full["lam"], testx=full["testx"])
+        D = _unit_cols_rows(seed + 7919, rows, cols, lo, hi, threads)
+        noise = np.sqrt(0.001) * rng.standard_normal(rows)
+        s = D @ testx + noise[lo:hi]
+        lam = 0.1 * float(np.max(np.abs(D.T @ s)))
+        return dict(D=D, s=s, lam=lam, testx=testx)
     D = _randn_cols(seed + 7919, rows, cols, threads)
     # column normalisation, blockwise to bound temporaries at large sizes
     for j0 in range(0, cols, 512):

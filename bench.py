@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X ADMM engine (driver contract: see README/DESIGN.md).
+"""bench.py -- headline benchmark of the MI355X ADMM engine (driver contract: see DESIGN.md).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): lasso.m on synthetic dense D 100000 x 10000 fp64, rho = 1,
-lassotest.m:109-122 recipe, fixed work via the reference's own switch domaxiters=1
+lassotest.m:109-122 recipe (seed 1), fixed work via the reference's own switch domaxiters=1
 (admm.m:59, 711).  A "step" is one ADMM iteration (admm.m:496-743) with D, the cached factor
-and all iterates resident in HBM.  Rank 0 prints ONE JSON line.
+and all iterates resident in HBM.  With N > 1 the SAME problem is row-sharded over the ranks
+(slicemaker(0, N, m), errorcheck.m:249-259) -> strong scaling.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -19,12 +21,13 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -32,14 +35,15 @@ def parse():
     ap.add_argument("--rows", type=int, default=100000)
     ap.add_argument("--cols", type=int, default=10000)
     ap.add_argument("--xsolve", default="inverse", choices=["trsv", "inverse"])
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the objevals=1 and A-streaming side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def dist_setup(n_gpus):
-    """One process per GPU (torch.distributed, backend nccl == RCCL).  Returns (rank, world, dist|None)."""
+def dist_setup():
+    """One process per GPU (torch.distributed, backend nccl == RCCL).  Returns (rank, world, local, dist|None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,7 +57,17 @@ def dist_setup(n_gpus):
     return rank, world, local, dist
 
 
-def sync_all(dist, ap_mod):
+def max_over_ranks(dist, value, device="cuda"):
+    if dist is None:
+        return float(value)
+    import torch
+
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sync_all(dist):
     if dist is not None:
         import torch
 
@@ -63,19 +77,26 @@ def sync_all(dist, ap_mod):
 
 def timed_run(eng, dist, steps, **kw):
     """barrier + sync, EXACTLY `steps` iterations, sync + barrier; MAX over ranks."""
-    sync_all(dist, None)
+    sync_all(dist)
     t0 = time.perf_counter()
-    s = eng.run(maxiters=steps, domaxiters=1, record_history=0, **kw)
-    sync_all(dist, None)  # eng.run returns only after its stream has drained
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    s = eng.run(maxiters=steps, domaxiters=1, record_history=0, **kw)  # returns after its stream drained
+    sync_all(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
     assert s.steps == steps, (s.steps, steps)
     return dt, s
+
+
+def make_problem(ap_mod, dist, m, n, lo, hi):
+    """lassotest.m:109-122 at full size; each rank keeps only its rows [lo, hi) of D and s."""
+    if dist is None:
+        return ap_mod.synth.lasso_problem(seed=1, rows=m, cols=n)
+    import torch
+
+    p = ap_mod.synth.lasso_problem(seed=1, rows=m, cols=n, row_range=(lo, hi))
+    g = torch.from_numpy(p["D"].T @ p["s"]).cuda()  # lambda = 0.1*||D's||_inf needs the global D's
+    dist.all_reduce(g)
+    p["lam"] = 0.1 * float(g.abs().max().item())
+    return p
 
 
 def cpu_baseline(p, factor, seconds, rho):
@@ -109,28 +130,40 @@ def cpu_baseline(p, factor, seconds, rho):
 
 def main():
     a = parse()
-    rank, world, local, dist = dist_setup(a.gpus)
+    rank, world, local, dist = dist_setup()
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
     import admm_project_amd as ap
+    from admm_project_amd import parallel
 
     L = ap._lib
     L.require_device()
-    if world > 1:
-        raise SystemExit("bench.py: row-sharded multi-GPU engines are not wired into the bench yet")
-
     m, n = a.rows, a.cols
     rho = 1.0
+    comm = None
+    transport = None
+    lo, hi = 0, m
+    if dist is not None:
+        transport = a.transport
+        try:
+            comm = parallel.init_from_torch(dist, device=local, transport=transport)
+        except ap.AdmmError as exc:  # RCCL refused the topology: host-staged transport still measures the GPUs
+            if rank == 0:
+                print(f"bench.py: RCCL communicator failed ({exc}); falling back to the shm transport", file=sys.stderr)
+            transport = "shm"
+            comm = parallel.init_from_torch(dist, device=local, transport=transport)
+        lo, hi = parallel.my_rows(m, comm)
+
     t0 = time.perf_counter()
-    p = ap.synth.lasso_problem(seed=1, rows=m, cols=n)
+    p = make_problem(ap, dist, m, n, lo, hi)
     t_gen = time.perf_counter() - t0
 
     xs = {"trsv": L.XSOLVE_TRSV, "inverse": L.XSOLVE_INVERSE}[a.xsolve]
-    eng = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local)
-    setup_s = eng.setup_seconds
+    eng = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local, comm=comm)
+    setup_s = max_over_ranks(dist, eng.setup_seconds)
 
     # ---- headline: objevals = 0 ----------------------------------------------------------
     timed_run(eng, dist, max(1, a.warmup), rho=rho)
@@ -141,7 +174,7 @@ def main():
     value = a.steps / dt
     if a.xsolve == "inverse":
         alg_bytes = 8.0 * n * n  # one pass over the symmetric n x n inverse (full storage)
-        kname = "gemv_n_kernel (x = inv(D'D+rho I) * y)"
+        kname = "gemv_t_kernel<1> (x = inv(D'D+rho I) * y as column dots of the symmetric inverse)"
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "trsv_fwd/bwd_step kernels (x = L'\\(L\\y))"
@@ -153,7 +186,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"lasso.m cached-factor loop, D {m}x{n} fp64, rho=1, lassotest.m recipe seed=1, "
                                f"domaxiters=1, objevals=0, xsolve={a.xsolve}",
-                   "rows": m, "cols": n, "rho": rho, "parallelism": f"rows{world}"},
+                   "rows": m, "cols": n, "rho": rho, "parallelism": f"rows{world}", "collective": transport},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": xs_avg_ms, "launches": xs_cnt},
@@ -169,22 +202,24 @@ def main():
         dt1, _ = timed_run(eng, dist, k1, rho=rho, objevals=1)
         eng.set_profiling(False)
         gn_ms, gn_cnt = eng.kernel_time(L.K_GEMV_N)
-        gbs = 8.0 * m * n / (gn_ms / max(1, gn_cnt) * 1e-3) / 1e9 if gn_cnt else 0.0
+        rows_local = hi - lo
+        gbs = 8.0 * rows_local * n / (gn_ms / max(1, gn_cnt) * 1e-3) / 1e9 if gn_cnt else 0.0
         out["objevals1"] = {"iters_per_s": k1 / dt1, "ms_per_step": dt1 / k1 * 1e3,
-                            "gemv_n_GBs": gbs, "gemv_n_frac": gbs / HBM_PEAK_GBS,
+                            "gemv_n_GBs_per_gpu": gbs, "gemv_n_frac": gbs / HBM_PEAK_GBS,
                             "gemv_n_avg_ms": gn_ms / max(1, gn_cnt),
-                            "note": "lassotest.m:131 sets objevals=1: one extra D*x pass (8mn B) per iteration; "
-                                    "timing includes the residual-norm kernel"}
+                            "note": "lassotest.m:131 sets objevals=1: one extra D*x pass (8mn B) per iteration, "
+                                    "row-sharded when N > 1; timing includes the residual-norm kernel"}
 
     factor = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:
         factor = eng.fetch(L.F_FACTOR, n * n, (n, n))
     eng.close()
 
     if not a.no_extras:
         # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
-        # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes.
-        lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local)
+        # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
+        # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
+        lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
         k2 = max(5, a.steps // 8)
         timed_run(lad, dist, 2)
         lad.set_profiling(True)
@@ -193,19 +228,24 @@ def main():
         gn_ms, gn_cnt = lad.kernel_time(L.K_GEMV_N)
         gt_ms, gt_cnt = lad.kernel_time(L.K_GEMV_T)
         pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
-        gbs = 16.0 * m * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
-        out["a_streaming"] = {"workload": "lad.m on the same D,s: D*x + D'*[s+z-u, dz, u] per iteration (16mn B)",
+        rows_local = hi - lo
+        gbs = 16.0 * rows_local * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        out["a_streaming"] = {"workload": "lad.m on the same D,s: D*x + D'*[s+z-u, dz, u] per iteration (16mn B), "
+                                          "transpose reduction over the row shards",
                               "iters_per_s": k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
-                              "AtAx_unit_ms": pair_ms, "AtAx_GBs": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                              "AtAx_unit_ms": pair_ms, "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
                               "gemv_n_avg_ms": gn_ms / max(1, gn_cnt), "gemv_t_avg_ms": gt_ms / max(1, gt_cnt),
-                              "setup_seconds": lad.setup_seconds}
+                              "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
         lad.close()
 
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1 and rank == 0:
         out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -207,8 +207,14 @@ int admm_op_soft_threshold(const double* v, int64_t n, double t, double* out);
  * (torch.distributed / MPI / a file).  errorcheck.m:216-267 defines the row partition.
  */
 #define ADMM_COMM_ID_BYTES 128
+/* transports: RCCL over xGMI (collectives enqueued on the engine's stream), or a host-staged
+ * all-reduce through POSIX shared memory (any number of ranks may then share one GPU; used for
+ * single-GPU testing of the sharded engines and as a fallback) */
+enum { ADMM_COMM_RCCL = 0, ADMM_COMM_SHM = 1 };
 int admm_comm_unique_id(char id[ADMM_COMM_ID_BYTES]);
-int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int device, admm_comm** out);
+int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int device, int transport,
+                   admm_comm** out);
+int admm_comm_info(admm_comm* comm, int* rank, int* nranks, int* transport);
 int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count); /* host convenience/test */
 void admm_comm_destroy(admm_comm* comm);
 

@@ -142,6 +142,17 @@ def test_synth_shapes_and_layout(ap):
     assert t["s"].shape == (64,)
 
 
+def test_row_sharded_generator_matches_full(ap):
+    full = ap.synth.lasso_problem(3, 4200, 1001, threads=3)  # large (threaded) path
+    parts = [ap.synth.lasso_problem(3, 4200, 1001, threads=2, row_range=ap.errorcheck.rank_rows(4200, r, 3))
+             for r in range(3)]
+    D = np.concatenate([q["D"] for q in parts], axis=0)
+    np.testing.assert_allclose(D, full["D"], rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(np.concatenate([q["s"] for q in parts]), full["s"], rtol=1e-12, atol=1e-14)
+    small = ap.synth.lasso_problem(1, 64, 16, row_range=(10, 30))
+    np.testing.assert_array_equal(small["D"], ap.synth.lasso_problem(1, 64, 16)["D"][10:30])
+
+
 def test_mnist_label_reader(ap, tmp_path):
     import struct
 

@@ -37,7 +37,11 @@ def _close(name, got, ref, tol=TOL, limit=None):
 
 
 def _compare(got, ref, keys=HIST, tol=TOL, limit=None):
-    assert got["steps"] == ref["steps"], (got["steps"], ref["steps"])
+    if "steps" not in ref:  # q4: the convergence test aborted the reference run (admm.m:692-701)
+        assert "steps" not in got and "xopt" not in got
+        assert got["convtest_failed_at"] == ref["convtest_failed_at"]
+    else:
+        assert got["steps"] == ref["steps"], (got["steps"], ref["steps"])
     for k in keys:
         if k in ref:
             assert k in got, f"result field {k} missing"
