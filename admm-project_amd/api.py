@@ -50,6 +50,19 @@ class ProxOp:
         return f"<ProxOp {self.problem.kind}:{self.role}>"
 
 
+class EngineHook:
+    """Marker for ``extra.altu`` / ``extra.specialnorms`` of consensus lasso (getProxOps.m:441-442):
+    the solver stores them in ``options`` (lasso.m:222-223) and ``admm`` recognises that the
+    engine implements them (altuLASSO 1312-1326, lassonorms 1335-1343) on the device."""
+
+    def __init__(self, problem, name):
+        self.problem = problem
+        self.name = name
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError("engine-native hook; it runs inside admm() on the device")
+
+
 def _get(args, name):
     if name not in args:
         raise KeyError(f"args.{name} is required for this problem (getProxOps.m)")
@@ -82,8 +95,16 @@ def getproxops(problem, args):
     extra = {}
 
     if kind == "lasso":
-        if args.get("parallel", 0):
-            raise NotImplementedError("consensus lasso (args.parallel=1) is not engine-native yet")
+        if args.get("parallel", 0):  # getProxOps.m:383-442: consensus over row slices
+            D, s, lam = _get(args, "D"), _get(args, "s"), _get(args, "lambda")
+            slices = [int(k) for k in np.atleast_1d(_get(args, "slices"))]
+            rho = float(args.get("rho", 1.0))
+            n = D.shape[1]
+            eng = Engine(L.PROB_LASSO_CONSENSUS, D=D, s=s, lam=lam, rho=rho, xsolve=xs, device=dev, comm=comm,
+                         slices=slices)
+            prob = _Problem("lasso-consensus", eng, dict(A=1, c=0.0, nA=n, nB=n))
+            extra = {"altu": EngineHook(prob, "altu"), "specialnorms": EngineHook(prob, "specialnorms")}
+            return ProxOp(prob, "x"), ProxOp(prob, "z"), extra
         D = _get(args, "D")
         lam = _get(args, "lambda")
         rho = float(args.get("rho", 1.0))
@@ -190,9 +211,15 @@ def admm(xminf, zming, options):
     prob = xminf.problem
     eng = prob.engine
     _check_constraint(options, prob)
-    for unsupported in ("altu", "specialnorms", "preprocess"):
-        if unsupported in options and options[unsupported] is not None:
-            raise NotImplementedError(f"options.{unsupported} (host callback) is not supported by the device loop")
+    for hook in ("altu", "specialnorms", "preprocess"):
+        h = options.get(hook)
+        if h is None:
+            continue
+        if not (isinstance(h, EngineHook) and h.problem is prob and h.name == hook):
+            raise NotImplementedError(f"options.{hook} (host callback) is not supported by the device loop")
+    if prob.kind == "lasso-consensus" and not ("altu" in options and "specialnorms" in options):
+        raise ValueError("consensus lasso needs options.altu and options.specialnorms from getproxops' extra "
+                         "(lasso.m:222-223)")
     if _setopt(options, "adaptive", 0):
         raise NotImplementedError("options.adaptive (experimental in the reference, admm.m:724-741) is not supported")
     par = _setopt(options, "parallel", "none")
@@ -290,6 +317,9 @@ def admm(xminf, zming, options):
         return results
 
     results["steps"] = steps
+    if prob.kind == "lasso-consensus":
+        # q9: the z admm holds is identically zero; the closure's consensus z is exposed as an extra field
+        results["zconsensus"] = eng.fetch(L.F_ZCONSENSUS, nA)
     results["xopt"] = eng.fetch(L.F_XOPT, nA)
     results["zopt"] = eng.fetch(L.F_ZOPT, nB)
     results["uopt"] = eng.fetch(L.F_UOPT, nB)

@@ -1,0 +1,120 @@
+// consensus.hip -- vector kernels of consensus lasso (getProxOps.m:1217-1343).  Each slice k keeps
+// its own x_k, u_k and cached factor; the consensus variable z couples them through the means
+// of x_k and u_k (one all-reduce of 2n doubles when the slices live on several GPUs, X1 in SURVEY).
+#include "consensus.h"
+#include "loop_kernels.h"
+
+namespace admm {
+
+// y_k = rho*(z - u_k) + Dts_k      getProxOps.m:1240
+__global__ __launch_bounds__(kBlock) void cons_rhs_kernel(int64_t n, double rho, const double* __restrict__ z,
+                                                          const double* __restrict__ u,
+                                                          const double* __restrict__ Dts, double* __restrict__ y,
+                                                          const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    y[i] = rho * (z[i] - u[i]) + Dts[i];
+}
+
+void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, const double* Dts, double* y,
+                     const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(n, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cons_rhs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, n, rho, z, u, Dts,
+                     y, ctrl);
+}
+
+// sums[0][i] = sum_k x_k[i], sums[1][i] = sum_k u_k[i]   (getProxOps.m:1281-1284, slice order)
+__global__ __launch_bounds__(kBlock) void cons_sum_kernel(int64_t n, int64_t ldn, int32_t K,
+                                                          const double* __restrict__ X,
+                                                          const double* __restrict__ U, double* __restrict__ sums,
+                                                          const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double sx = 0.0, su = 0.0;
+    for (int32_t k = 0; k < K; ++k) {
+      su = su + U[k * ldn + i];
+      sx = sx + X[k * ldn + i];
+    }
+    sums[i] = sx;
+    sums[ldn + i] = su;
+  }
+}
+
+void launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
+                     const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(n, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cons_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, n, ldn, K, X, U,
+                     sums, ctrl);
+}
+
+// z-update + per-slice u-update + every partial sum admm / lassonorms need:
+//   getProxOps.m:1286-1298 (means, soft threshold with lambda/(rho*N), u_k += x_k - z),
+//   1312-1326 (altu: mean of the updated u_k = uave + xave - z), 1335-1343 (squared norms).
+__global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  const double Nd = static_cast<double>(a.Ntot);
+  const double t = a.lambda / (a.rho * Nd);  // q11
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double xave = a.sums[i] / Nd;
+    const double uave = a.sums[a.ldn + i] / Nd;
+    const double v = uave + xave;
+    const double q = fabs(v) - t;
+    const double p = q > 0.0 ? q : 0.0;
+    const double z = (v > 0.0) ? p : ((v < 0.0) ? -p : 0.0 * p);
+    double dev = 0.0;
+    for (int32_t k = 0; k < a.K; ++k) {
+      const double xk = a.X[k * a.ldn + i];
+      a.U[k * a.ldn + i] = a.U[k * a.ldn + i] + (xk - z);
+      const double d = xk - xave;
+      dev += d * d;
+    }
+    const double xprev = a.xave[i];
+    const double ub_old = a.ubar[i];
+    const double ub = (uave + xave) - z;  // mean over ALL slices of u_k + (x_k - z)
+    acc[S_R2] += dev;                     // lassonorms v(1), this rank's slices
+    acc[S_AX2] += xave * xave;            // ||Ax||, A = 1, x = mean x_k (getProxOps.m:1259)
+    const double dx = xave - xprev;
+    acc[S_G2] += dx * dx;                 // lassonorms v(2) = N*rho^2*||xave - xaveprev||^2
+    acc[S_U2] += ub * ub;
+    const double du = ub - ub_old;
+    acc[S_DU2] += du * du;
+    a.zc[i] = z;
+    a.xaveprev[i] = xprev;
+    a.xave[i] = xave;
+    a.ubar[i] = ub;
+    if (a.xhist) a.xhist[it * a.n + i] = xave;
+    if (a.zhist) a.zhist[it * a.n + i] = 0.0;  // q9: zminParallelLASSO hands zeros back to admm
+    if (a.uhist) a.uhist[it * a.n + i] = ub;
+  }
+  __shared__ double sred[4][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    a.part[s * kMaxPartBlocks + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+  }
+}
+
+void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.n, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(cons_update_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
+}  // namespace admm

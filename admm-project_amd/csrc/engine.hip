@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "tv.h"
+#include "consensus.h"
 
 namespace admm {
 
@@ -109,6 +110,12 @@ struct admm_engine {
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
   size_t tv_bprefix_cap = 0;
+  // consensus lasso (getProxOps.m:383-442, 1217-1343)
+  std::vector<ConsSlice> cslices;
+  int32_t cons_total = 0;  // slicenum over all ranks
+  double *cX = nullptr, *cU = nullptr, *csums = nullptr, *czc = nullptr, *cxave = nullptr, *cxaveprev = nullptr,
+         *cubar = nullptr, *cy = nullptr, *cobjpart = nullptr;
+  int64_t cldn = 0;
   double* part = nullptr;     // [S_COUNT][kMaxPartBlocks]
   double* objpart = nullptr;  // [kMaxPartBlocks]
   Ctrl* ctrl = nullptr;
@@ -270,6 +277,54 @@ void solve_factor(admm_engine* e, const double* y, double* out) {
     launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldg, e->nF, out, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
+  }
+}
+
+
+// ---- consensus slices: one cached factor per slice ----------------------------------------
+int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld) {
+  f.F = W;
+  f.n = n;
+  f.ld = ld;
+  const int64_t nblk = ceil_div(n, 64);
+  ADMM_TRY(e->mem.alloc(&f.dinv, static_cast<size_t>(nblk) * 64 * 64));
+  double* infod = nullptr;
+  ADMM_TRY(e->mem.alloc(&infod, 1));
+  int32_t* info_dev = reinterpret_cast<int32_t*>(infod);
+  ADMM_TRY(cholesky_lower(W, n, ld, info_dev, f.dinv, e->stream));
+  int32_t info = 0;
+  ADMM_HIP_TRY(hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  if (info != 0)
+    return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " + std::to_string(info) + ")");
+  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+    double* X = nullptr;
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
+    int rc = trtri_lower_from_diag(W, n, ld, f.dinv, X, ld, e->stream);
+    if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(ld) * n);
+    if (rc == ADMM_OK) {
+      launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, ld, true, e->stream);
+      launch_symmetrize_lower(f.Minv, n, ld, e->stream);
+    }
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(X);
+    ADMM_TRY(rc);
+    f.plan = gemv_t_plan(n, n, ld);
+    ADMM_TRY(e->mem.alloc(&f.part, f.plan.part_elems(1)));
+  } else {
+    double* dv = f.dinv;
+    ADMM_TRY(trsv_build(W, n, ld, &dv, &f.trsv, e->stream));
+    ADMM_TRY(e->mem.alloc(&f.work, trsv_workspace_elems(f.trsv)));
+  }
+  return ADMM_OK;
+}
+
+void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, double* out) {
+  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+    launch_gemv_t(f.plan, f.Minv, y, nullptr, nullptr, 1, f.part, e->ctrl, e->stream);
+    launch_sum_partials(f.part, f.plan.nchunk, f.plan.ldg, f.n, out, e->ctrl, e->stream);
+  } else {
+    launch_trsv_pair(f.trsv, y, out, f.work, e->ctrl, e->stream);
   }
 }
 
@@ -540,8 +595,79 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(e->mem.alloc(&e->tv_uB, round_up(nn, 2)));
       break;
     }
-    case ADMM_PROB_LASSO_CONSENSUS:
-      return bail(fail(ADMM_E_UNSUPPORTED, "problem kind not engine-native yet"));
+    case ADMM_PROB_LASSO_CONSENSUS: {
+      // lasso.m:193-224 + getProxOps.m:383-442: one (D_k, D_k's_k, chol(D_k'D_k + rho*I)) per row slice
+      if (!desc->D || !desc->s || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "lasso needs D (m x n) and s"));
+      if (desc->lambda < 0) return bail(fail(ADMM_E_INVALID, "lambda must be a nonnegative real (lasso.m:132)"));
+      if (desc->nslices < 1 || !desc->slices) return bail(fail(ADMM_E_INVALID, "consensus lasso needs args.slices"));
+      int64_t tot = 0;
+      for (int32_t k = 0; k < desc->nslices; ++k) {
+        if (desc->slices[k] <= 0) return bail(fail(ADMM_E_INVALID, "empty slice"));
+        tot += desc->slices[k];
+      }
+      if (tot != m)
+        return bail(fail(ADMM_E_INVALID, "The number of parallel slices does not match length of x! (errorcheck.m:264)"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_SOFT;
+      e->rhs_kind = RHS_NONE;
+      e->cons_total = desc->nslices;
+      if (e->comm && comm_nranks(e->comm) > 1) {
+        double* cnt = nullptr;
+        E_TRY(e->mem.alloc(&cnt, 2));
+        const double mine = static_cast<double>(desc->nslices);
+        E_HIP(hipMemcpyAsync(cnt, &mine, sizeof(double), hipMemcpyHostToDevice, e->stream));
+        E_TRY(comm_allreduce_device(e->comm, cnt, 1, e->stream));
+        double totd = 0.0;
+        E_HIP(hipMemcpyAsync(&totd, cnt, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        E_HIP(hipStreamSynchronize(e->stream));
+        e->cons_total = static_cast<int32_t>(totd + 0.5);
+      }
+      const int64_t ldsrc = desc->ldD ? desc->ldD : m;
+      const int64_t ld = round_up(n, 16);
+      e->cslices.resize(desc->nslices);
+      int64_t r0 = 0;
+      for (int32_t k = 0; k < desc->nslices; ++k) {
+        ConsSlice& sl = e->cslices[k];
+        sl.m = desc->slices[k];
+        if (sl.m < n)  // q12: the reference's fat-slice branch indexes the wrong diagonal; not reproduced
+          return bail(fail(ADMM_E_UNSUPPORTED, "consensus lasso needs tall slices (rows per slice >= columns), see q12"));
+        E_TRY(upload_matrix(e->mem, &sl.D, &sl.ld, desc->D + r0, sl.m, n, ldsrc, mk, e->stream));
+        E_TRY(upload(e->mem, &sl.s, desc->s + r0, sl.m, mk, e->stream));
+        sl.planN = gemv_n_plan(sl.m, n, sl.ld);
+        sl.planT = gemv_t_plan(sl.m, n, sl.ld);
+        if (k == 0 || sl.planN.part_elems() > e->planDN.part_elems()) e->planDN = sl.planN;  // largest = buffer size
+        if (k == 0 || sl.planT.part_elems(1) > e->planDT.part_elems(1)) e->planDT = sl.planT;
+        r0 += sl.m;
+      }
+      E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
+      E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(1)));
+      for (int32_t k = 0; k < desc->nslices; ++k) {
+        ConsSlice& sl = e->cslices[k];
+        E_TRY(e->mem.alloc(&sl.Dts, round_up(n, 2)));
+        launch_gemv_t(sl.planT, sl.D, sl.s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
+        launch_sum_partials_t(sl.planT, e->partDT, 1, sl.Dts, round_up(n, 2), nullptr, e->stream);
+        double* W = nullptr;
+        E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
+        E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
+        launch_gemm(1, 0, n, n, sl.m, 1.0, sl.D, sl.ld, sl.D, sl.ld, 0.0, W, ld, true, e->stream);
+        launch_add_diag(W, n, ld, desc->rho, e->stream);
+        E_TRY(build_slice_factor(e, sl.fac, W, n, ld));
+      }
+      e->cldn = round_up(n, 2);
+      const size_t K = static_cast<size_t>(desc->nslices);
+      E_TRY(e->mem.alloc(&e->cX, K * e->cldn));
+      E_TRY(e->mem.alloc(&e->cU, K * e->cldn));
+      E_TRY(e->mem.alloc(&e->csums, 2 * e->cldn));
+      E_TRY(e->mem.alloc(&e->czc, e->cldn));
+      E_TRY(e->mem.alloc(&e->cxave, e->cldn));
+      E_TRY(e->mem.alloc(&e->cxaveprev, e->cldn));
+      E_TRY(e->mem.alloc(&e->cubar, e->cldn));
+      E_TRY(e->mem.alloc(&e->cy, e->cldn));
+      E_TRY(e->mem.alloc(&e->cobjpart, K * kMaxPartBlocks));
+      break;
+    }
     default:
       return bail(fail(ADMM_E_INVALID, "Invalid input for problem - not a solver (getProxOps.m:916)"));
   }
@@ -660,6 +786,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   if (o.rho != e->rho_factor && e->F && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
       e->problem != ADMM_PROB_LINEARSVM)
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)
+    return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached slice factors were built for");
   if (o.relax != 1.0 && (e->problem == ADMM_PROB_LINEARSVM))
     return fail(ADMM_E_INVALID,
                 "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");
@@ -850,6 +978,135 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   xa.uhathist = e->uhathist;
   xa.rho = o.rho;
   xa.rhs_kind = e->rhs_kind;
+
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS) {
+    if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for consensus lasso");
+    if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for consensus lasso");
+    const bool shard = e->comm && comm_nranks(e->comm) > 1;
+    const int32_t K = static_cast<int32_t>(e->cslices.size());
+    const int64_t n = e->n, ldn = e->cldn;
+    // closure state at getproxops time: x_k = u_k = 0, z = 0, xave = 0 (getProxOps.m:390-411); admm's own
+    // u starts at options.u0 (admm.m:254) and only enters the first H-norm difference
+    ADMM_HIP_TRY(hipMemsetAsync(e->cX, 0, sizeof(double) * K * ldn, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->cU, 0, sizeof(double) * K * ldn, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->czc, 0, sizeof(double) * ldn, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->cxave, 0, sizeof(double) * ldn, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->cxaveprev, 0, sizeof(double) * ldn, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cubar, e->u, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->cobjpart, 0, sizeof(double) * K * kMaxPartBlocks, e->stream));
+    ConsArgs ca{};
+    ca.n = n;
+    ca.ldn = ldn;
+    ca.K = K;
+    ca.Ntot = e->cons_total;
+    ca.rho = o.rho;
+    ca.lambda = e->lambda;
+    ca.sums = e->csums;
+    ca.X = e->cX;
+    ca.U = e->cU;
+    ca.zc = e->czc;
+    ca.xave = e->cxave;
+    ca.xaveprev = e->cxaveprev;
+    ca.ubar = e->cubar;
+    ca.xhist = e->xhist;
+    ca.zhist = e->zhist;
+    ca.uhist = e->uhist;
+    ca.part = e->part;
+    fa.specialnorms = 1;
+    fa.nslices_total = e->cons_total;
+    fa.g = nullptr;
+    fa.x = nullptr;
+    fa.xhist = nullptr;
+    fa.obj_scale_part = o.objevals ? 0.5 : 0.0;  // lasso.m:227 with the z admm holds (zeros): 0.5*||D*x - s||^2
+    fa.obj_scale_z = 0.0;
+    const int check_c = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t done = 0;
+    bool stop_seen = false;
+    while (done < N && !stop_seen) {
+      const int32_t batch = (N - done < check_c) ? N - done : check_c;
+      for (int32_t b = 0; b < batch; ++b) {
+        {
+          TimerScope ts(e, ADMM_K_XSOLVE);
+          for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
+            ConsSlice& sl = e->cslices[k];
+            launch_cons_rhs(n, o.rho, e->czc, e->cU + k * ldn, sl.Dts, e->cy, e->ctrl, e->stream);
+            apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
+          }
+        }
+        launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->ctrl, e->stream);
+        if (shard) ADMM_TRY(comm_allreduce_device(e->comm, e->csums, static_cast<size_t>(2 * ldn), e->stream));  // X1
+        int nblk = 1;
+        {
+          TimerScope ts(e, ADMM_K_PROX);
+          launch_cons_update(ca, e->ctrl, &nblk, e->stream);
+        }
+        fa.nblk = nblk;
+        fa.objpart = nullptr;
+        fa.nobjpart = 0;
+        fa.slots_reduced = nullptr;
+        fa.objp_reduced = nullptr;
+        if (o.objevals) {
+          TimerScope ts(e, ADMM_K_GEMV_N);
+          for (int32_t k = 0; k < K; ++k) {
+            ConsSlice& sl = e->cslices[k];
+            int nob = 0;
+            launch_gemv_n(sl.planN, sl.D, e->cxave, e->partDN, e->ctrl, e->stream);
+            launch_residual_sq(e->partDN, sl.planN.nchunk, sl.planN.ldy, sl.s, sl.m, e->cobjpart + k * kMaxPartBlocks,
+                               &nob, e->ctrl, e->stream);
+          }
+          fa.objpart = e->cobjpart;
+          fa.nobjpart = K * kMaxPartBlocks;
+        }
+        if (shard) {  // X2: only sum_k ||x_k - xave||^2 and the objective are rank-local sums
+          launch_pack_slots(e->part, nblk, e->red, e->ctrl, e->stream);
+          ADMM_HIP_TRY(hipMemcpyAsync(e->red + 16, e->red + S_R2, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+          if (o.objevals) launch_pack_sum(e->cobjpart, K * kMaxPartBlocks, e->red + 17, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 2, e->stream));
+          ADMM_HIP_TRY(hipMemcpyAsync(e->red + S_R2, e->red + 16, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+          fa.slots_reduced = e->red;
+          if (o.objevals) fa.objp_reduced = e->red + 17;
+        }
+        {
+          TimerScope ts(e, ADMM_K_FINALIZE);
+          launch_finalize(fa, e->stream);
+        }
+      }
+      done += batch;
+      if (!o.domaxiters || done >= N) {
+        ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->ctrl_host->stop) stop_seen = true;
+      }
+    }
+    // what admm holds at exit: x = mean x_k, z = 0 (q9), u = mean u_k
+    ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->cxave, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemsetAsync(e->z, 0, sizeof(double) * n, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->u, e->cubar, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+    }
+    const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (e->profiling) collect_timers(e);
+    const int32_t steps = e->ctrl_host->steps;
+    e->last = admm_run_summary{};
+    e->last.steps = steps;
+    e->last.stopped_early = (steps < N) ? 1 : 0;
+    e->last.convtest_failed_at = e->ctrl_host->convfail;
+    e->last.runtime_s = rt;
+    e->last.objopt = NAN;
+    if (o.objevals && steps > 0) {
+      double v = NAN;
+      ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+      e->last.objopt = v;
+    }
+    e->has_run = true;
+    if (summary) *summary = e->last;
+    return ADMM_OK;
+  }
 
   if (e->problem == ADMM_PROB_TOTALVARIATION) {
     if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for total variation");
@@ -1119,6 +1376,11 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
     case ADMM_F_AVALS: src = e->avals; count = steps; need_fast = true; break;
     case ADMM_F_DVALS: src = e->dvals; count = steps; need_fast = true; break;
     case ADMM_F_RESTARTED: src = e->restarted; count = steps; need_fast = true; break;
+    case ADMM_F_ZCONSENSUS:
+      if (e->problem != ADMM_PROB_LASSO_CONSENSUS) return fail(ADMM_E_INVALID, "field exists only for consensus lasso");
+      src = e->czc;
+      count = e->nA;
+      break;
     case ADMM_F_FACTOR: {
       if (!e->F) return fail(ADMM_E_INVALID, "problem has no cached factor");
       count = static_cast<size_t>(e->nF) * e->nF;

@@ -115,6 +115,8 @@ struct FinArgs {
   double abstol, reltol, Hnormtol, convtol, restart, dvaltol;
   int32_t alg, a_identity, nodualerror, objevals, use_h, convtest, stopcond, domaxiters, maxiters;
   int32_t dual_from_slots;  // dual norms come from S_G2/S_G3 (stencil operators) instead of g
+  int32_t specialnorms;     // consensus lasso: pnorm/dnorm are lassonorms' squared sums (q10)
+  int32_t nslices_total;    // slicenum over all ranks
   // row-sharded runs: sums already reduced over blocks AND ranks (all-reduced), else null
   const double* slots_reduced;  // [16]
   const double* objp_reduced;   // [1]

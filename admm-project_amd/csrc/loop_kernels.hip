@@ -351,9 +351,14 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
       ctrl->coef = coef;
       a.avals[it] = acn;
     }
-    const double pn = sqrt(S[S_R2]);
+    // options.specialnorms (admm.m:612-616) = lassonorms (getProxOps.m:1335-1343): both values are
+    // SQUARED sums (q10): sum_k ||x_k - xave||^2 and N*rho^2*||xave - xaveprev||^2
+    const double pn = a.specialnorms ? S[S_R2] : sqrt(S[S_R2]);
     double dn, de;
-    if (a.nodualerror) {
+    if (a.specialnorms) {
+      dn = static_cast<double>(a.nslices_total) * (a.rho * a.rho) * S[S_G2];
+      de = a.nodualerror ? NaN : sqrt(Mlen) * a.abstol + a.reltol * (a.rho * sqrt(S[S_U2]));
+    } else if (a.nodualerror) {
       dn = NaN;
       de = NaN;
     } else {

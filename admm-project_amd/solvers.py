@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from .api import admm, getproxops
-from .errorcheck import is_nonnegative_real, is_positive_real
+from .errorcheck import is_nonnegative_real, is_positive_real, slicemaker
 
 __all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit",
            "totalvariation"]
@@ -58,14 +58,26 @@ def lasso(D, s, lam, options=None):
     D = _matrix(D, "D")
     s = _colvec(s, "s")
     rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
-    if options.get("parallel", "none") in ("both", "zming", "xminf"):  # lasso.m:144-156
-        raise NotImplementedError("consensus lasso (options.parallel) is not engine-native yet")
     m, n = D.shape
     if s.size != m:
         raise ValueError("The number of rows in argument D do not match size of s!")
-    args = _engine_args(options, dict(D=D, s=s, m=m, n=n, parallel=0, rho=rho))
-    args["lambda"] = lam
-    minx, minz, _ = getproxops("LASSO", args)
+    if options.get("parallel", "none") in ("both", "zming", "xminf"):  # lasso.m:144-156, 193-224
+        # consensus lasso: row slices each with their own x_k, u_k and cached factor.  `workers`
+        # stands for gcp().NumWorkers (lasso.m:203-207); with options['comm'] D, s are this rank's rows
+        # and the slices given here are this rank's local slices.
+        options["parallel"] = "none"
+        options["stopcond"] = "both"
+        slices = np.atleast_1d(options.get("slices", 0))[0]  # lasso.m:197 takes only slices(1)
+        workers = int(options.get("workers", 1 if "comm" in options else 8))
+        args = _engine_args(options, dict(D=D, s=s, rho=rho, parallel=1, slices=slicemaker(slices, workers, m)))
+        args["lambda"] = lam
+        minx, minz, extra = getproxops("LASSO", args)
+        options["altu"] = extra["altu"]  # lasso.m:222-223
+        options["specialnorms"] = extra["specialnorms"]
+    else:
+        args = _engine_args(options, dict(D=D, s=s, m=m, n=n, parallel=0, rho=rho))
+        args["lambda"] = lam
+        minx, minz, _ = getproxops("LASSO", args)
     options["obj"] = _ENGINE_OBJ  # lasso.m:227  0.5*sum((D*x - s).^2) + lambda*norm(z,1)
     options.update(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, parallel="none")  # lasso.m:232-239
     results = admm(minx, minz, options)

@@ -233,6 +233,35 @@ def test_total_variation_second_run_and_errors(gpu):
         gpu.admm(minx, minz, dict(base, fast=1))
 
 
+@pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
+@pytest.mark.parametrize("rows,cols,workers,opts", [
+    (256, 64, 4, dict()),                      # 4 x (64 x 64) slices, as in the survey's feasibility run
+    (1000, 60, 8, dict(rho=2.0)),              # 8 slices of 125 rows (config-4 shape, scaled down)
+    (515, 48, 3, dict(maxiters=15, domaxiters=1)),  # uneven slices 172/172/171
+    (300, 70, 2, dict(u0=np.linspace(-1, 1, 70))),
+])
+def test_consensus_lasso(gpu, rows, cols, workers, opts, xsolve):
+    """Config 4 semantics (getProxOps.m:1217-1343) incl. quirks q9-q11: z handed to admm is 0,
+    squared special norms, threshold lambda/(rho*N); compared with the N-slice oracle."""
+    p = gpu.synth.lasso_problem(1, rows, cols)
+    o = dict(objevals=1, parallel="both", **opts)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, workers=workers, xsolve=xsolve))
+    ref = S.lasso(p["D"], p["s"], p["lam"], o, workers=workers)
+    _compare(got, ref)
+    assert np.all(got["zvals"] == 0.0) and np.all(got["zopt"] == 0.0)  # q9
+    zc = ref["_consensus"]["_state"]["z"]
+    assert np.max(np.abs(got["zconsensus"] - zc)) < 1e-9 * max(1.0, np.max(np.abs(zc)))
+    if not opts:
+        obj = lambda x: 0.5 * np.sum((p["D"] @ x - p["s"]) ** 2) + p["lam"] * np.sum(np.abs(x))
+        assert obj(got["zconsensus"]) < obj(p["testx"])
+
+
+def test_consensus_lasso_rejects_fat_slices(gpu):
+    p = gpu.synth.lasso_problem(1, 120, 64)
+    with pytest.raises(gpu.AdmmError):  # q12: 4 slices of 30 rows < 64 columns
+        gpu.lasso(p["D"], p["s"], p["lam"], dict(parallel="both", workers=4))
+
+
 def test_precomputed_factor_is_used(gpu):
     """args.L handed in by the caller (lasso.m:183) must give the same iterates as the on-device factor."""
     import scipy.linalg as sla

@@ -45,6 +45,13 @@ def _rank_main(rank, world, uid, case, q):
             r = ap.linearsvm(p["D"][lo:hi], p["ell"][lo:hi], p["C"], o)
             out["svm"] = {k: r[k] for k in ("steps", "xvals", "pnorm", "perr", "Hnormsq", "objevals", "zopt")}
             out["rows"] = (lo, hi)
+        elif case == "consensus":
+            p = ap.synth.lasso_problem(1, 256, 64)
+            lo, hi = parallel.my_rows(256, comm)  # 128 rows per rank, 2 local slices of 64 -> 4 slices in total
+            r = ap.lasso(p["D"][lo:hi], p["s"][lo:hi], p["lam"],
+                         dict(objevals=1, parallel="both", comm=comm, workers=2, xsolve="inverse"))
+            out["consensus"] = {k: r[k] for k in ("steps", "xvals", "zvals", "uvals", "pnorm", "dnorm", "perr",
+                                                  "derr", "objevals", "Hnormsq", "zconsensus")}
         elif case == "lasso":
             p = ap.synth.lasso_problem(2, 301, 64)
             lo, hi = parallel.my_rows(301, comm)
@@ -133,6 +140,19 @@ def test_sharded_lasso_matches_unsharded_oracle(gpu):
         assert g["steps"] == ref["steps"]
         for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "objevals"):
             assert _rel(g[k], ref[k]) < 1e-9, k
+
+
+def test_sharded_consensus_lasso_matches_four_slice_oracle(gpu):
+    """Config 4 (e2): slices spread over two ranks, one all-reduce of [sum x_k; sum u_k] per iteration."""
+    res = _run_two_ranks("consensus")
+    p = gpu.synth.lasso_problem(1, 256, 64)
+    ref = S.lasso(p["D"], p["s"], p["lam"], dict(objevals=1, parallel="both"), workers=4)
+    for rank in (0, 1):
+        g = res[rank]["consensus"]
+        assert g["steps"] == ref["steps"]
+        for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq"):
+            assert np.max(np.abs(np.asarray(g[k]) - ref[k])) <= 1e-8 * max(1e-30, np.max(np.abs(ref[k]))), k
+        assert _rel(g["zconsensus"], ref["_consensus"]["_state"]["z"]) < 1e-9
 
 
 def test_single_rank_rccl_communicator(gpu):
