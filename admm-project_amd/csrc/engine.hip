@@ -434,7 +434,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (xs == ADMM_XSOLVE_CG) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=CG is not implemented yet"));
   e->xsolve = xs;
   const bool sharded = e->comm && comm_nranks(e->comm) > 1;
-  if (sharded && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
+  if (sharded && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LASSO_CONSENSUS &&
+      desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
     return bail(fail(ADMM_E_UNSUPPORTED, "row sharding applies to problems with a data matrix D (lasso/LAD/Huber/SVM)"));
   // global number of rows of D (the local m when not sharded)

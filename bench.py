@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+_DEV = "cuda"  # device of the torch tensors used for rendezvous collectives ("cpu" in --one-gpu rehearsals)
 
 
 def parse(argv=None):
@@ -39,11 +40,15 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the objevals=1 and A-streaming side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="rehearsal on a single-GPU box: every rank uses HIP device 0, torch.distributed runs "
+                         "over gloo and the engine over the shm transport (RCCL refuses two ranks on one device)")
     return ap.parse_args(argv)
 
 
-def dist_setup():
+def dist_setup(one_gpu=False):
     """One process per GPU (torch.distributed, backend nccl == RCCL).  Returns (rank, world, local, dist|None)."""
+    global _DEV
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -52,17 +57,21 @@ def dist_setup():
     import torch
     import torch.distributed as dist
 
+    if one_gpu:
+        _DEV = "cpu"
+        dist.init_process_group(backend="gloo")
+        return rank, world, 0, dist
     torch.cuda.set_device(local)
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     return rank, world, local, dist
 
 
-def max_over_ranks(dist, value, device="cuda"):
+def max_over_ranks(dist, value, device=None):
     if dist is None:
         return float(value)
     import torch
 
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or _DEV)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -72,7 +81,8 @@ def sync_all(dist):
         import torch
 
         dist.barrier()
-        torch.cuda.synchronize()
+        if _DEV == "cuda":
+            torch.cuda.synchronize()
 
 
 def timed_run(eng, dist, steps, **kw):
@@ -93,7 +103,7 @@ def make_problem(ap_mod, dist, m, n, lo, hi):
     import torch
 
     p = ap_mod.synth.lasso_problem(seed=1, rows=m, cols=n, row_range=(lo, hi))
-    g = torch.from_numpy(p["D"].T @ p["s"]).cuda()  # lambda = 0.1*||D's||_inf needs the global D's
+    g = torch.from_numpy(p["D"].T @ p["s"]).to(_DEV)  # lambda = 0.1*||D's||_inf needs the global D's
     dist.all_reduce(g)
     p["lam"] = 0.1 * float(g.abs().max().item())
     return p
@@ -130,7 +140,9 @@ def cpu_baseline(p, factor, seconds, rho):
 
 def main():
     a = parse()
-    rank, world, local, dist = dist_setup()
+    rank, world, local, dist = dist_setup(a.one_gpu)
+    if a.one_gpu:
+        a.transport = "shm"
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
