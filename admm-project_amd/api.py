@@ -93,6 +93,7 @@ def getproxops(problem, args):
     if comm is not None:
         dev = comm.device
     extra = {}
+    cg = {k: args[k] for k in ("cg_tol", "cg_maxit") if k in args}  # xsolve='cg' (matrix-free) knobs
 
     if kind == "lasso":
         if args.get("parallel", 0):  # getProxOps.m:383-442: consensus over row slices
@@ -115,21 +116,21 @@ def getproxops(problem, args):
         Lf = args.get("L")
         if Lf is not None and hasattr(Lf, "toarray"):
             Lf = Lf.toarray()  # lasso.m:175 stores the factor sparse
-        eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev, comm=comm)
+        eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev, comm=comm, **cg)
         prob = _Problem("lasso", eng, dict(A=1, c=0.0, nA=n, nB=n))
     elif kind in ("lad", "huberfit"):
         D, s = _get(args, "D"), _get(args, "s")
         m, n = D.shape
         code = L.PROB_LAD if kind == "lad" else L.PROB_HUBERFIT
         eng = Engine(code, D=D, s=s, Lfactor=args.get("R"), userelax=int(bool(args.get("userelax", 0))),
-                     xsolve=xs, device=dev, comm=comm)
+                     xsolve=xs, device=dev, comm=comm, **cg)
         prob = _Problem(kind, eng, dict(A="D", c="s", nA=n, nB=m))
     elif kind == "linearsvm":
         D, ell, Cval = _get(args, "D"), _get(args, "ell"), _get(args, "C")
         loss = args.get("lossfunction", "hinge")
         m, n = D.shape
         eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
-                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev, comm=comm)
+                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev, comm=comm, **cg)
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
     elif kind == "quadraticprogram":
         if _get(args, "constraint") != "bounded":
@@ -317,6 +318,10 @@ def admm(xminf, zming, options):
         return results
 
     results["steps"] = steps
+    try:  # matrix-free x-update: total inner CG iterations (engine extension, not a reference field)
+        results["cg_iters_total"] = int(eng.fetch(L.F_CG_ITERS, 1)[0])
+    except L.AdmmError:
+        pass
     if prob.kind == "lasso-consensus":
         # q9: the z admm holds is identically zero; the closure's consensus z is exposed as an extra field
         results["zconsensus"] = eng.fetch(L.F_ZCONSENSUS, nA)

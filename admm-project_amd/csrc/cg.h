@@ -1,0 +1,37 @@
+// cg.h -- device-resident conjugate gradients for the matrix-free x-update (cg.hip).
+#pragma once
+#include "common.h"
+
+namespace admm {
+
+struct CgState {     // device scalars of one solve
+  double rs;         // r.r
+  double ynorm;      // ||y||
+  int32_t iters;     // inner iterations of the current solve
+  int32_t done;      // converged (or hit maxit): the remaining launches of the chunk are no-ops
+  int64_t total;     // inner iterations since the run started
+};
+
+struct CgArgs {
+  int64_t n;
+  double shift;      // rho for lasso (D'D + rho I), 0 for LAD/Huber/SVM (D'D)
+  double tol;        // relative residual ||y - Mx|| <= tol*||y||
+  int32_t maxit;
+  const double* y;
+  double* x;
+  double* r;
+  double* p;
+  double* q;
+  double* part;      // [2][kMaxPartBlocks]
+  CgState* st;
+  const Ctrl* ctrl;
+};
+
+// q = sum of the gemv_t chunk partials + shift*p (and the block partials of p.q when with_dot)
+void launch_cg_q(const CgArgs& a, const double* qin, int32_t nchunk, int64_t ldq, bool with_dot, hipStream_t stream);
+// r = y - q, p = r, rs, ||y||, done-if-already-converged
+void launch_cg_init(const CgArgs& a, hipStream_t stream);
+// alpha, x/r update, beta, p update, scalar state advance (after launch_cg_q(..., with_dot = true))
+void launch_cg_step_tail(const CgArgs& a, hipStream_t stream);
+
+}  // namespace admm

@@ -11,6 +11,7 @@
 #include "loop_kernels.h"
 #include "tv.h"
 #include "consensus.h"
+#include "cg.h"
 
 namespace admm {
 
@@ -110,6 +111,14 @@ struct admm_engine {
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
   size_t tv_bprefix_cap = 0;
+  // matrix-free x-update (xsolve = cg)
+  double cg_tol = 1e-12;
+  int32_t cg_maxit = 200;
+  bool cg_shift_is_rho = false;
+  double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_tmp = nullptr, *cg_part = nullptr;
+  CgState* cg_st = nullptr;
+  CgState* cg_st_host = nullptr;  // pinned
+  int64_t cg_total_last = 0;
   // consensus lasso (getProxOps.m:383-442, 1217-1343)
   std::vector<ConsSlice> cslices;
   int32_t cons_total = 0;  // slicenum over all ranks
@@ -431,8 +440,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
 
   int xs = desc->xsolve;
   if (xs == ADMM_XSOLVE_AUTO) xs = ADMM_XSOLVE_TRSV;
-  if (xs == ADMM_XSOLVE_CG) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=CG is not implemented yet"));
+  if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
+      desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
+    return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg applies to problems whose x-update solves with D'D (+ rho I)"));
   e->xsolve = xs;
+  e->cg_tol = desc->cg_tol > 0 ? desc->cg_tol : 1e-12;
+  e->cg_maxit = desc->cg_maxit > 0 ? desc->cg_maxit : 200;
   const bool sharded = e->comm && comm_nranks(e->comm) > 1;
   if (sharded && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LASSO_CONSENSUS &&
       desc->problem != ADMM_PROB_LAD &&
@@ -476,6 +489,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       launch_gemv_t(e->planDT, e->D, e->s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
       launch_sum_partials_t(e->planDT, e->partDT, 1, e->rhs_add, round_up(n, 2), nullptr, e->stream);
       if (sharded) E_TRY(comm_allreduce_device(e->comm, e->rhs_add, n, e->stream));  // sum_g D_g'*s_g
+      if (e->xsolve == ADMM_XSOLVE_CG) {  // matrix-free: nothing n x n is ever formed
+        if (e->fat) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg needs a tall matrix (m >= n)"));
+        e->cg_shift_is_rho = true;
+        E_TRY(e->mem.alloc(&e->tmpA, round_up(m, 2)));
+        break;
+      }
       const int64_t nF = e->fat ? m : n;
       const int64_t ld = round_up(nF, 16);
       double* W = nullptr;
@@ -527,6 +546,11 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->planDT = gemv_t_plan(m, n, e->ldD);
       E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
       E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(3)));
+      if (e->xsolve == ADMM_XSOLVE_CG) {  // matrix-free normal equations D'D x = D'(c + z - u)
+        e->cg_shift_is_rho = false;
+        E_TRY(e->mem.alloc(&e->tmpA, round_up(m, 2)));
+        break;
+      }
       const int64_t ld = round_up(n, 16);
       double* W = nullptr;
       E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
@@ -689,6 +713,18 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     E_TRY(e->mem.alloc(&e->g, 3 * N2 + 16));  // + 16 reduction slots: one all-reduce payload
   }
   E_TRY(e->mem.alloc(&e->red, 32));  // packed scalar payloads of the sharded runs
+  if (e->xsolve == ADMM_XSOLVE_CG) {
+    E_TRY(e->mem.alloc(&e->cg_r, N2));
+    E_TRY(e->mem.alloc(&e->cg_p, N2));
+    E_TRY(e->mem.alloc(&e->cg_q, N2));
+    E_TRY(e->mem.alloc(&e->cg_tmp, N2));
+    E_TRY(e->mem.alloc(&e->cg_part, 2 * kMaxPartBlocks));
+    double* st = nullptr;
+    E_TRY(e->mem.alloc(&st, (sizeof(CgState) + 7) / 8));
+    e->cg_st = reinterpret_cast<CgState*>(st);
+    E_HIP(hipMemsetAsync(e->cg_st, 0, sizeof(CgState), e->stream));
+    E_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->cg_st_host), sizeof(CgState), hipHostMallocDefault));
+  }
   e->tv_zA = e->z;
   e->tv_uA = e->u;
   E_TRY(e->mem.alloc(&e->part, static_cast<size_t>(S_COUNT) * kMaxPartBlocks));
@@ -722,12 +758,78 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
 #undef E_HIP
 }
 
+// q-source for CG: D'*(D*v) as gemv_t chunk partials (or, row-sharded, the all-reduced sum in cg_tmp)
+static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t* nchunk, int64_t* ldq) {
+  {
+    TimerScope ts(e, ADMM_K_GEMV_N);
+    launch_gemv_n(e->planDN, e->D, v, e->partDN, e->ctrl, e->stream);
+  }
+  launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, e->ctrl, e->stream);
+  {
+    TimerScope ts(e, ADMM_K_GEMV_T);
+    launch_gemv_t(e->planDT, e->D, e->tmpA, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+  }
+  *qin = e->partDT;
+  *nchunk = e->planDT.nchunk;
+  *ldq = e->planDT.ldg;
+  if (e->comm && comm_nranks(e->comm) > 1) {  // sum_g D_g'(D_g v): n doubles per inner iteration
+    launch_sum_partials_t(e->planDT, e->partDT, 1, e->cg_tmp, round_up(e->n, 2), e->ctrl, e->stream);
+    ADMM_TRY(comm_allreduce_device(e->comm, e->cg_tmp, static_cast<size_t>(e->n), e->stream));
+    *qin = e->cg_tmp;
+    *nchunk = 1;
+    *ldq = 0;
+  }
+  return ADMM_OK;
+}
+
+// x <- argmin-free solve of (D'D + shift I) x = y by warm-started CG (cg.hip); polls the device flag
+static int cg_solve(admm_engine* e, const double* y) {
+  CgArgs a{};
+  a.n = e->n;
+  a.shift = e->cg_shift_is_rho ? e->last_opts.rho : 0.0;
+  a.tol = e->cg_tol;
+  a.maxit = e->cg_maxit;
+  a.y = y;
+  a.x = e->x;
+  a.r = e->cg_r;
+  a.p = e->cg_p;
+  a.q = e->cg_q;
+  a.part = e->cg_part;
+  a.st = e->cg_st;
+  a.ctrl = e->ctrl;
+  // clear iters/done of the previous solve (total keeps counting)
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
+  const double* qin;
+  int32_t nchunk;
+  int64_t ldq;
+  ADMM_TRY(cg_apply(e, e->x, &qin, &nchunk, &ldq));
+  CgArgs a0 = a;
+  a0.p = e->x;  // q = D'D x + shift*x
+  launch_cg_q(a0, qin, nchunk, ldq, false, e->stream);
+  launch_cg_init(a, e->stream);
+  const int chunk = 4;
+  for (int done_it = 0; done_it < e->cg_maxit;) {
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
+    const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
+    for (int c = 0; c < k; ++c) {
+      ADMM_TRY(cg_apply(e, e->cg_p, &qin, &nchunk, &ldq));
+      launch_cg_q(a, qin, nchunk, ldq, true, e->stream);
+      launch_cg_step_tail(a, e->stream);
+    }
+    done_it += k;
+  }
+  return ADMM_OK;
+}
+
 // one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
-static void x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   *axsrc = e->x;
   *naxpart = 1;
   *axld = 0;
+  if (e->xsolve == ADMM_XSOLVE_CG) return cg_solve(e, e->a_identity ? e->rhs : e->g);
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
@@ -771,6 +873,7 @@ static void x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int
       solve_factor(e, e->g, e->x);
       break;
   }
+  return ADMM_OK;
 }
 
 int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* summary) {
@@ -842,6 +945,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl, e->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, e->stream));
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   for (auto& t : e->timers) t.used = 0;
+  if (e->cg_st) ADMM_HIP_TRY(hipMemsetAsync(e->cg_st, 0, sizeof(CgState), e->stream));
 
   // ---- objective wiring (solver-supplied handles: lasso.m:227, lad.m:148, huberfit.m:180,
   //      linearsvm.m:231-236, quadraticprogram.m:242, basispursuit.m:140)
@@ -1242,7 +1346,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       const double* axsrc;
       int32_t naxpart;
       int64_t axld;
-      x_update(e, &axsrc, &naxpart, &axld);
+      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld));
       if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
         TimerScope ts(e, ADMM_K_GEMV_N);
         launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
@@ -1337,6 +1441,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
 
   e->last = admm_run_summary{};
   e->last.steps = e->ctrl_host->steps;
+  if (e->cg_st) {
+    ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
+    e->cg_total_last = e->cg_st_host->total;
+  }
   e->last.stopped_early = (e->ctrl_host->steps < N) ? 1 : 0;
   e->last.convtest_failed_at = e->ctrl_host->convfail;
   e->last.runtime_s = runtime;
@@ -1377,6 +1485,13 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
     case ADMM_F_AVALS: src = e->avals; count = steps; need_fast = true; break;
     case ADMM_F_DVALS: src = e->dvals; count = steps; need_fast = true; break;
     case ADMM_F_RESTARTED: src = e->restarted; count = steps; need_fast = true; break;
+    case ADMM_F_CG_ITERS: {
+      if (e->xsolve != ADMM_XSOLVE_CG) return fail(ADMM_E_INVALID, "field exists only for xsolve = cg");
+      if (cap < 1) return fail(ADMM_E_CAPACITY, "destination too small");
+      dst[0] = static_cast<double>(e->cg_total_last);
+      if (written) *written = 1;
+      return ADMM_OK;
+    }
     case ADMM_F_ZCONSENSUS:
       if (e->problem != ADMM_PROB_LASSO_CONSENSUS) return fail(ADMM_E_INVALID, "field exists only for consensus lasso");
       src = e->czc;
@@ -1435,6 +1550,7 @@ void admm_engine_destroy(admm_engine* e) {
     for (hipEvent_t ev : t.ev) (void)hipEventDestroy(ev);
   e->mem.release();
   if (e->ctrl_host) (void)hipHostFree(e->ctrl_host);
+  if (e->cg_st_host) (void)hipHostFree(e->cg_st_host);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }

@@ -19,7 +19,7 @@ class Engine:
 
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
-                 device=0, slices=None, comm=None, nvec=None):
+                 device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -72,6 +72,10 @@ class Engine:
         d.xsolve = int(xsolve)
         d.mem = L.MEM_HOST
         d.device = int(device)
+        if cg_tol is not None:
+            d.cg_tol = float(cg_tol)
+        if cg_maxit is not None:
+            d.cg_maxit = int(cg_maxit)
         if slices is not None:
             sl = np.ascontiguousarray(np.asarray(slices, dtype=np.int64))
             keep.append(sl)

@@ -250,6 +250,27 @@ def main():
                               "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
         lad.close()
 
+        # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
+        # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
+        mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
+                       comm=comm, cg_tol=1e-10)
+        k3 = max(3, a.steps // 40)
+        timed_run(mf, dist, 1, rho=rho)
+        mf.set_profiling(True)
+        dt3, _ = timed_run(mf, dist, k3, rho=rho)
+        mf.set_profiling(False)
+        inner = float(mf.fetch(L.F_CG_ITERS, 1)[0])
+        gn_ms, gn_cnt = mf.kernel_time(L.K_GEMV_N)
+        gt_ms, gt_cnt = mf.kernel_time(L.K_GEMV_T)
+        pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
+        gbs = 16.0 * (hi - lo) * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        out["matrix_free"] = {"workload": "lasso, x-update by warm-started CG on (D'D + rho I), tol 1e-10",
+                              "iters_per_s": k3 / dt3, "ms_per_step": dt3 / k3 * 1e3,
+                              "inner_iters_per_step": inner / k3, "AtAx_unit_ms": pair_ms,
+                              "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                              "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
+        mf.close()
+
     if not a.no_cpu_baseline and world == 1 and rank == 0:
         out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
     if rank == 0:

@@ -256,6 +256,27 @@ def test_consensus_lasso(gpu, rows, cols, workers, opts, xsolve):
         assert obj(got["zconsensus"]) < obj(p["testx"])
 
 
+@pytest.mark.parametrize("solver,opts", [
+    ("lasso", dict()), ("lasso", dict(rho=3.0, relax=1.5)), ("lasso", dict(fast=1, fasttype="strong", maxiters=40)),
+    ("lad", dict()), ("huberfit", dict(convtest=1)),
+])
+def test_matrix_free_cg_matches_factor_path(gpu, solver, opts):
+    """xsolve='cg' (no reference counterpart: the reference always factors).  Its own oracle is the
+    factor-path oracle: with inner tolerance 1e-13 the per-iteration iterates agree to 1e-7."""
+    if solver == "lasso":
+        p = gpu.synth.lasso_problem(2, 600, 120)
+        o = dict(objevals=1, **opts)
+        got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, xsolve="cg", cg_tol=1e-13))
+        ref = S.lasso(p["D"], p["s"], p["lam"], o)
+    else:
+        p = (gpu.synth.lad_problem if solver == "lad" else gpu.synth.huber_problem)(0, 512, 64)
+        o = dict(objevals=1, **opts)
+        got = getattr(gpu, solver)(p["D"], p["s"], dict(o, xsolve="cg", cg_tol=1e-13))
+        ref = getattr(S, solver)(p["D"], p["s"], o)
+    _compare(got, ref, tol=1e-7)
+    assert 0 < got["cg_iters_total"] <= 60 * got["steps"]
+
+
 def test_consensus_lasso_rejects_fat_slices(gpu):
     p = gpu.synth.lasso_problem(1, 120, 64)
     with pytest.raises(gpu.AdmmError):  # q12: 4 slices of 30 rows < 64 columns
