@@ -138,6 +138,41 @@ def cpu_baseline(p, factor, seconds, rho):
                        f"loop only, as results.runtime")
 
 
+def other_configs(ap, L, device, steps):
+    """BASELINE.json configs 3 and 5 on one GPU (side lines; the headline stays config 2)."""
+    res = {}
+    # config 5: total variation, 1-D signal of length 4096^2 (the reference's TV is 1-D: totalvariation.m:127)
+    n = 4096 * 4096
+    p = ap.synth.tv_problem(seed=1, n=n)
+    tv = ap.Engine(L.PROB_TOTALVARIATION, s=p["s"], lam=1.0, nvec=n, device=device)
+    k = max(20, steps // 2)
+    tv.run(maxiters=5, domaxiters=1, record_history=0)
+    t0 = time.perf_counter()
+    s = tv.run(maxiters=k, domaxiters=1, record_history=0)
+    dt = time.perf_counter() - t0
+    passes = 11  # forward sweep 3r+1w, backward sweep 1r+1w, prox 3r+2w  (DESIGN.md section 4)
+    res["totalvariation_16777216"] = {"iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3,
+                                      "algorithmic_GB_per_iter": passes * 8.0 * n / 1e9,
+                                      "achieved_GBs": passes * 8.0 * n * s.steps / dt / 1e9,
+                                      "frac": passes * 8.0 * n * s.steps / dt / 1e9 / HBM_PEAK_GBS}
+    tv.close()
+    # config 3: linear SVM, hinge, MNIST-shaped synthetic pixels (image files are absent from the reference)
+    for m in (6000, 60000):
+        q = ap.synth.mnist_like_problem(seed=1, m=m, n=400, digit=0)
+        svm = ap.Engine(L.PROB_LINEARSVM, D=q["D"], ell=q["ell"], Cval=q["C"], xsolve=L.XSOLVE_INVERSE, device=device)
+        kw = dict(maxiters=1000, domaxiters=1, record_history=0, nodualerror=1, stopcond="both",
+                  x0=q["x0"], z0=q["z0"], u0=q["u0"])  # unwrappedadmm.m:87-92
+        svm.run(**dict(kw, maxiters=20))
+        t0 = time.perf_counter()
+        s = svm.run(**kw)
+        dt = time.perf_counter() - t0
+        res[f"linearsvm_{m}x400"] = {"iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3,
+                                     "algorithmic_MB_per_iter": 16.0 * m * 400 / 1e6,
+                                     "note": "L2/MALL-resident: latency-bound, HBM fraction not meaningful"}
+        svm.close()
+    return res
+
+
 def main():
     a = parse()
     rank, world, local, dist = dist_setup(a.one_gpu)
@@ -270,6 +305,9 @@ def main():
                               "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
                               "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
         mf.close()
+
+    if not a.no_extras and world == 1:
+        out["other_configs"] = other_configs(ap, L, local, a.steps)
 
     if not a.no_cpu_baseline and world == 1 and rank == 0:
         out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
