@@ -4,6 +4,7 @@
 // quadraticprogram.m:210-232, basispursuit.m:116-127); run() = admm.m:252-767.
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -142,7 +143,7 @@ struct admm_engine {
   bool has_run = false;
   double setup_seconds = 0.0;
 
-  bool profiling = false;
+  uint32_t profiling = 0;  // bit k set: time kernel class k with HIP events
   KTimer timers[ADMM_K_COUNT];
 };
 
@@ -193,7 +194,7 @@ struct TimerScope {
   int which;
   bool on;
   size_t slot = 0;
-  TimerScope(admm_engine* eng, int w) : e(eng), which(w), on(eng->profiling) {
+  TimerScope(admm_engine* eng, int w) : e(eng), which(w), on((eng->profiling >> w) & 1u) {
     if (!on) return;
     KTimer& t = e->timers[which];
     if (t.used + 2 > t.ev.size()) {
@@ -1338,11 +1339,17 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
     if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
   }
-  int32_t enq = 0;
-  bool stopped = false;
-  while (enq < N && !stopped) {
-    const int32_t batch = (N - enq < check_every) ? N - enq : check_every;
-    for (int32_t b = 0; b < batch; ++b) {
+  // One iteration = a fixed sequence of launches with iteration-independent arguments (the
+  // iteration index lives in ctrl->iter), so a batch of iterations is captured ONCE into a
+  // hipGraph and replayed: launch-bound problems (SVM 6000x400, small lasso, the TRSV x-solve
+  // with its 2*n/64 launches) stop paying ~3.5 us of host launch time per kernel.  Iterations
+  // past a stop condition or past maxiters are no-ops on the device, so whole batches are replayed.
+  // Not used when collectives or event timing sit inside the iteration, or for the CG x-solve
+  // (which polls the device between inner iterations).
+  const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG &&
+                         std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
+  auto enqueue_iteration = [&]() -> int {
+    {
       const double* axsrc;
       int32_t naxpart;
       int64_t axld;
@@ -1423,13 +1430,48 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_finalize(fa, e->stream);
       }
     }
-    enq += batch;
-    if (!o.domaxiters || enq >= N) {
-      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
-      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-      if (e->ctrl_host->stop) stopped = true;
+    return ADMM_OK;
+  };
+
+  int32_t enq = 0;
+  bool stopped = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int32_t gbatch = 0;
+  if (use_graph) {
+    gbatch = (N < check_every) ? N : check_every;
+    hipError_t ge = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+    int rc_cap = ADMM_OK;
+    if (ge == hipSuccess) {
+      for (int32_t b = 0; b < gbatch && rc_cap == ADMM_OK; ++b) rc_cap = enqueue_iteration();
+      ge = hipStreamEndCapture(e->stream, &graph);
+    }
+    if (ge == hipSuccess && rc_cap == ADMM_OK) ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+    if (ge != hipSuccess || rc_cap != ADMM_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return fail(ADMM_E_DEVICE, std::string("hipGraph capture of the iteration failed: ") + hipGetErrorString(ge));
     }
   }
+  int loop_rc = ADMM_OK;
+  while (enq < N && !stopped && loop_rc == ADMM_OK) {
+    int32_t batch = (N - enq < check_every) ? N - enq : check_every;
+    if (gexec) {
+      batch = gbatch;  // a full batch; iterations beyond maxiters are device-side no-ops
+      if (hipGraphLaunch(gexec, e->stream) != hipSuccess) loop_rc = fail(ADMM_E_DEVICE, "hipGraphLaunch failed");
+    } else {
+      for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
+    }
+    enq += batch;
+    if (loop_rc == ADMM_OK && (!o.domaxiters || enq >= N)) {
+      if (hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+          hipStreamSynchronize(e->stream) != hipSuccess)
+        loop_rc = fail(ADMM_E_DEVICE, "polling the device control block failed");
+      else if (e->ctrl_host->stop) stopped = true;
+    }
+  }
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
+  ADMM_TRY(loop_rc);
   ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   {
@@ -1530,7 +1572,7 @@ int admm_engine_setup_seconds(admm_engine* e, double* seconds) {
 
 int admm_engine_set_profiling(admm_engine* e, int enabled) {
   if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
-  e->profiling = enabled != 0;
+  e->profiling = enabled < 0 ? 0xffffffffu : static_cast<uint32_t>(enabled);  // bitmask of (1 << ADMM_K_*)
   return ADMM_OK;
 }
 

@@ -111,7 +111,16 @@ class Engine:
         return v.value
 
     def set_profiling(self, on):
-        L.check(self._lib.admm_engine_set_profiling(self._h, 1 if on else 0))
+        """True/False, or an iterable of kernel classes (L.K_XSOLVE, ...) to time with HIP events."""
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            mask = 0
+            for k in on:
+                mask |= 1 << int(k)
+        L.check(self._lib.admm_engine_set_profiling(self._h, mask))
 
     def kernel_time(self, which):
         ms, cnt = C.c_double(0), C.c_int64(0)

@@ -214,7 +214,7 @@ def main():
 
     # ---- headline: objevals = 0 ----------------------------------------------------------
     timed_run(eng, dist, max(1, a.warmup), rho=rho)
-    eng.set_profiling(True)
+    eng.set_profiling([L.K_XSOLVE])  # only the dominant kernel class: 2 event records per iteration
     dt, _ = timed_run(eng, dist, a.steps, rho=rho)
     eng.set_profiling(False)
     xs_ms, xs_cnt = eng.kernel_time(L.K_XSOLVE)
@@ -245,7 +245,7 @@ def main():
     if not a.no_extras:
         k1 = max(5, a.steps // 4)
         timed_run(eng, dist, 2, rho=rho, objevals=1)
-        eng.set_profiling(True)
+        eng.set_profiling([L.K_GEMV_N])
         dt1, _ = timed_run(eng, dist, k1, rho=rho, objevals=1)
         eng.set_profiling(False)
         gn_ms, gn_cnt = eng.kernel_time(L.K_GEMV_N)
@@ -269,7 +269,7 @@ def main():
         lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
         k2 = max(5, a.steps // 8)
         timed_run(lad, dist, 2)
-        lad.set_profiling(True)
+        lad.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
         dt2, _ = timed_run(lad, dist, k2)
         lad.set_profiling(False)
         gn_ms, gn_cnt = lad.kernel_time(L.K_GEMV_N)
@@ -291,7 +291,7 @@ def main():
                        comm=comm, cg_tol=1e-10)
         k3 = max(3, a.steps // 40)
         timed_run(mf, dist, 1, rho=rho)
-        mf.set_profiling(True)
+        mf.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
         dt3, _ = timed_run(mf, dist, k3, rho=rho)
         mf.set_profiling(False)
         inner = float(mf.fetch(L.F_CG_ITERS, 1)[0])

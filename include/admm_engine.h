@@ -179,8 +179,9 @@ int admm_engine_setup_seconds(admm_engine* eng, double* seconds);
  * which = ADMM_K_*; returns total milliseconds and launch count */
 enum { ADMM_K_XSOLVE = 0, ADMM_K_GEMV_N = 1, ADMM_K_GEMV_T = 2, ADMM_K_PROX = 3, ADMM_K_FINALIZE = 4, ADMM_K_COUNT = 5 };
 int admm_engine_kernel_time(admm_engine* eng, int which, double* total_ms, int64_t* launches);
-/* turn per-kernel event timing on/off for subsequent runs (off by default) */
-int admm_engine_set_profiling(admm_engine* eng, int enabled);
+/* per-kernel event timing for subsequent runs: mask = OR of (1 << ADMM_K_*), 0 = off (default),
+ * negative = every class.  Each timed class costs two hipEventRecord per launch group. */
+int admm_engine_set_profiling(admm_engine* eng, int mask);
 void admm_engine_destroy(admm_engine* eng);
 
 /* ---- stand-alone operators (kernel-level entry points; HOST pointers) ---------
