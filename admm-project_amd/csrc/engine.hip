@@ -230,24 +230,6 @@ void collect_timers(admm_engine* e) {
   }
 }
 
-// Graph replays re-record the SAME event pairs (captured as event-record nodes) every launch:
-// after each replay (stream drained) add up the pairs of the first `real` of `batch` iterations.
-void accumulate_graph_timers(admm_engine* e, int32_t real, int32_t batch, const size_t* base) {
-  for (int w = 0; w < ADMM_K_COUNT; ++w) {
-    KTimer& t = e->timers[w];
-    const size_t pairs = (t.used - base[w]) / 2;  // pairs recorded inside the captured batch
-    if (pairs == 0 || batch <= 0) continue;
-    const size_t take = pairs * static_cast<size_t>(real) / static_cast<size_t>(batch);
-    for (size_t k = 0; k < take; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, t.ev[base[w] + 2 * k], t.ev[base[w] + 2 * k + 1]) == hipSuccess) {
-        t.total_ms += ms;
-        t.launches += 1;
-      }
-    }
-  }
-}
-
 // ---- factor setup ------------------------------------------------------------------
 // W (nF x nF, ld) holds an SPD matrix in its lower triangle -> F (in place), dinv, optionally Minv.
 int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind) {
@@ -1366,10 +1348,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // hipGraph and replayed: launch-bound problems (SVM 6000x400, small lasso, the TRSV x-solve
   // with its 2*n/64 launches) stop paying ~3.5 us of host launch time per kernel.  Iterations
   // past a stop condition or past maxiters are no-ops on the device, so whole batches are replayed.
-  // Not used when collectives sit inside the iteration or for the CG x-solve (which polls the
-  // device between inner iterations).  Event timing survives capture: the hipEventRecord calls
-  // become event-record nodes and are read back after every replay.
-  const bool use_graph = !sharded && e->xsolve != ADMM_XSOLVE_CG && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
+  // Not used when collectives sit inside the iteration, for the CG x-solve (which polls the device
+  // between inner iterations), or with event timing on (hipEventElapsedTime rejects events that were
+  // recorded by graph nodes on ROCm 7.2: "invalid resource handle").
+  const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG &&
+                         std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
   auto enqueue_iteration = [&]() -> int {
     {
       const double* axsrc;
@@ -1460,8 +1443,6 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   int32_t gbatch = 0;
-  size_t tbase[ADMM_K_COUNT];
-  for (int w = 0; w < ADMM_K_COUNT; ++w) tbase[w] = e->timers[w].used;
   if (use_graph) {
     gbatch = (N < check_every) ? N : check_every;
     hipError_t ge = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
@@ -1482,10 +1463,6 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     if (gexec) {
       batch = gbatch;  // a full batch; iterations beyond maxiters are device-side no-ops
       if (hipGraphLaunch(gexec, e->stream) != hipSuccess) loop_rc = fail(ADMM_E_DEVICE, "hipGraphLaunch failed");
-      if (loop_rc == ADMM_OK && e->profiling) {
-        if (hipStreamSynchronize(e->stream) != hipSuccess) loop_rc = fail(ADMM_E_DEVICE, "hipStreamSynchronize failed");
-        else accumulate_graph_timers(e, (N - enq < gbatch) ? N - enq : gbatch, gbatch, tbase);
-      }
     } else {
       for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
     }
@@ -1507,7 +1484,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
   }
   const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
-  if (e->profiling && !use_graph) collect_timers(e);
+  if (e->profiling) collect_timers(e);
   for (auto& t : e->timers) t.used = 0;
 
   e->last = admm_run_summary{};

@@ -19,7 +19,16 @@
 
 namespace admm {
 
-__device__ __forceinline__ double tv_pivot(const TvArgs& a, int64_t i) { return (i < a.nprefix) ? a.bprefix[i] : a.bstar; }
+// recurrence multiplier: forward a_i = rho/b_{i-1} (a_0 = 0); backward a_i = rho/b_i, 0 for the last row
+template <bool BWD>
+__device__ __forceinline__ double tv_coef(const TvArgs& a, int64_t i, int64_t n, double rho, double cstar) {
+  if (!BWD) {
+    if (i <= 0) return 0.0;
+    return (i - 1 < a.nprefix) ? rho / a.bprefix[i - 1] : cstar;
+  }
+  if (i >= n - 1) return 0.0;
+  return (i < a.nprefix) ? rho / a.bprefix[i] : cstar;
+}
 
 // One sweep.  Logical position q in [0, count) maps to global index i = p0 + q (forward) or
 // p1 - 1 - q (backward); the scan always runs in increasing q with zero incoming carry.
@@ -42,19 +51,26 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
   }
   const int count = static_cast<int>(p1 - p0);
   const double rho = a.rho;
+  const double cstar = rho / a.bstar;   // stationary multiplier (no per-element division past the prefix)
+  const double ibstar = 1.0 / a.bstar;
 
-  // ---- stage the per-element constant term r_q (coalesced global reads -> padded LDS)
-  for (int q = tid; q < count; q += kBlock) {
+  // ---- stage the per-element constant term r_q (coalesced global reads -> padded LDS).  Fully
+  // unrolled so that all E independent loads of a thread are in flight together.
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = tid + k * kBlock;
+    const bool live = q < count;
     const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-    double r;
+    double r = 0.0;
     if (!BWD) {  // r_i = s_i + rho*(D'(z-u))_i     getProxOps.m:1047
-      const double t = a.z[i] - a.u[i];
-      const double dt = (i > 0) ? t - (a.z[i - 1] - a.u[i - 1]) : t;
-      r = a.s[i] + rho * dt;
-    } else {
-      r = a.y[i] / tv_pivot(a, i);
+      const double t = live ? a.z[i] - a.u[i] : 0.0;
+      double tm = __shfl_up(t, 1, 64);  // element i-1 sits in the previous lane
+      if (lane == 0 && live && i > 0) tm = a.z[i - 1] - a.u[i - 1];
+      if (live) r = a.s[i] + rho * ((i > 0) ? t - tm : t);
+    } else if (live) {
+      r = a.y[i] * ((i < a.nprefix) ? 1.0 / a.bprefix[i] : ibstar);
     }
-    lds[q + (q >> 4)] = r;
+    if (live) lds[q + (q >> 4)] = r;
   }
   __syncthreads();
 
@@ -66,10 +82,7 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
     const int q = q0 + k;
     if (q < count) {
       const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-      // forward: a_i = rho/b_{i-1} (a_0 = 0); backward: a_i = rho/b_i, 0 for the last row
-      double c;
-      if (!BWD) c = (i > 0) ? rho / tv_pivot(a, i - 1) : 0.0;
-      else c = (i < n - 1) ? rho / tv_pivot(a, i) : 0.0;
+      const double c = tv_coef<BWD>(a, i, n, rho, cstar);
       B = c * B + lds[q + (q >> 4)];
       A = c * A;
     }
@@ -106,9 +119,7 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
     const int q = q0 + k;
     if (q < count) {
       const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-      double c;
-      if (!BWD) c = (i > 0) ? rho / tv_pivot(a, i - 1) : 0.0;
-      else c = (i < n - 1) ? rho / tv_pivot(a, i) : 0.0;
+      const double c = tv_coef<BWD>(a, i, n, rho, cstar);
       yin = c * yin + lds[q + (q >> 4)];
       lds[q + (q >> 4)] = yin;
     }
@@ -116,9 +127,11 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
   __syncthreads();
   // ---- coalesced store of the owned range
   const int64_t it = ctrl->iter;
-  for (int q = tid; q < count; q += kBlock) {
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = tid + k * kBlock;
     const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-    if (i >= o0 && i < o1) {
+    if (q < count && i >= o0 && i < o1) {
       const double v = lds[q + (q >> 4)];
       if (!BWD) {
         a.y[i] = v;
