@@ -2,6 +2,7 @@
 // ADMM loop.  create() = the reference solver's one-time setup + getproxops (lasso.m:160-192,
 // lad.m:129-137, huberfit.m:161-169, linearsvm.m:183-217 + unwrappedadmm.m:76-92,
 // quadraticprogram.m:210-232, basispursuit.m:116-127); run() = admm.m:252-767.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -1351,8 +1352,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // Not used when collectives sit inside the iteration, for the CG x-solve (which polls the device
   // between inner iterations), or with event timing on (hipEventElapsedTime rejects events that were
   // recorded by graph nodes on ROCm 7.2: "invalid resource handle").
+  // Only worth it in the launch-bound regime (matrices up to 256 MB): capture + instantiate cost
+  // about a millisecond, which a GPU-bound loop (8 GB per pass) never earns back.
+  const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
   const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG &&
-                         std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
+                         heavy <= (int64_t{32} << 20) && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
   auto enqueue_iteration = [&]() -> int {
     {
       const double* axsrc;

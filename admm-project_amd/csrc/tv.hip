@@ -19,6 +19,8 @@
 
 namespace admm {
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
 // recurrence multiplier: forward a_i = rho/b_{i-1} (a_0 = 0); backward a_i = rho/b_i, 0 for the last row
 template <bool BWD>
 __device__ __forceinline__ double tv_coef(const TvArgs& a, int64_t i, int64_t n, double rho, double cstar) {
@@ -54,23 +56,54 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
   const double cstar = rho / a.bstar;   // stationary multiplier (no per-element division past the prefix)
   const double ibstar = 1.0 / a.bstar;
 
-  // ---- stage the per-element constant term r_q (coalesced global reads -> padded LDS).  Fully
-  // unrolled so that all E independent loads of a thread are in flight together.
+  // ---- stage the per-element constant term r (global -> padded LDS).  Walks i ascending in
+  // aligned pairs (16-byte loads; p0 is even by construction) whatever the sweep direction, and is
+  // fully unrolled so that all of a thread's independent loads are in flight together.
+  auto qpos = [&](int64_t i) -> int { return BWD ? static_cast<int>(p1 - 1 - i) : static_cast<int>(i - p0); };
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int q = tid + k * kBlock;
-    const bool live = q < count;
-    const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-    double r = 0.0;
+  for (int k = 0; k < E / 2; ++k) {
+    const int j = tid + k * kBlock;  // pair index
+    const int64_t i0 = p0 + 2 * static_cast<int64_t>(j);
+    const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+    double r0 = 0.0, r1 = 0.0;
     if (!BWD) {  // r_i = s_i + rho*(D'(z-u))_i     getProxOps.m:1047
-      const double t = live ? a.z[i] - a.u[i] : 0.0;
-      double tm = __shfl_up(t, 1, 64);  // element i-1 sits in the previous lane
-      if (lane == 0 && live && i > 0) tm = a.z[i - 1] - a.u[i - 1];
-      if (live) r = a.s[i] + rho * ((i > 0) ? t - tm : t);
-    } else if (live) {
-      r = a.y[i] * ((i < a.nprefix) ? 1.0 / a.bprefix[i] : ibstar);
+      double t0 = 0.0, t1 = 0.0, s0 = 0.0, s1 = 0.0;
+      if (live1) {
+        const double2_t zz = *reinterpret_cast<const double2_t*>(a.z + i0);
+        const double2_t uu = *reinterpret_cast<const double2_t*>(a.u + i0);
+        const double2_t ss = *reinterpret_cast<const double2_t*>(a.s + i0);
+        t0 = zz.x - uu.x;
+        t1 = zz.y - uu.y;
+        s0 = ss.x;
+        s1 = ss.y;
+      } else if (live0) {
+        t0 = a.z[i0] - a.u[i0];
+        s0 = a.s[i0];
+      }
+      double tm = __shfl_up(t1, 1, 64);  // element i0-1 is the previous lane's second element
+      if (lane == 0 && live0 && i0 > 0) tm = a.z[i0 - 1] - a.u[i0 - 1];
+      r0 = s0 + rho * ((i0 > 0) ? t0 - tm : t0);
+      r1 = s1 + rho * (t1 - t0);
+    } else {
+      double y0 = 0.0, y1 = 0.0;
+      if (live1) {
+        const double2_t yy = *reinterpret_cast<const double2_t*>(a.y + i0);
+        y0 = yy.x;
+        y1 = yy.y;
+      } else if (live0) {
+        y0 = a.y[i0];
+      }
+      r0 = y0 * ((i0 < a.nprefix) ? 1.0 / a.bprefix[i0] : ibstar);
+      r1 = y1 * ((i0 + 1 < a.nprefix && live1) ? 1.0 / a.bprefix[i0 + 1] : ibstar);
     }
-    if (live) lds[q + (q >> 4)] = r;
+    if (live0) {
+      const int q = qpos(i0);
+      lds[q + (q >> 4)] = r0;
+    }
+    if (live1) {
+      const int q = qpos(i0 + 1);
+      lds[q + (q >> 4)] = r1;
+    }
   }
   __syncthreads();
 
@@ -125,19 +158,39 @@ __global__ __launch_bounds__(kBlock) void tv_sweep_kernel(TvArgs a, const Ctrl* 
     }
   }
   __syncthreads();
-  // ---- coalesced store of the owned range
+  // ---- coalesced store of the owned range (ascending pairs, 16-byte stores)
   const int64_t it = ctrl->iter;
+  double* __restrict__ out = BWD ? a.x : a.y;
+  double* __restrict__ hist = (BWD && a.xhist) ? a.xhist + it * n : nullptr;
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int q = tid + k * kBlock;
-    const int64_t i = BWD ? (p1 - 1 - q) : (p0 + q);
-    if (q < count && i >= o0 && i < o1) {
-      const double v = lds[q + (q >> 4)];
-      if (!BWD) {
-        a.y[i] = v;
-      } else {
-        a.x[i] = v;
-        if (a.xhist) a.xhist[it * n + i] = v;
+  for (int k = 0; k < E / 2; ++k) {
+    const int j = tid + k * kBlock;
+    const int64_t i0 = p0 + 2 * static_cast<int64_t>(j);
+    const bool own0 = 2 * j < count && i0 >= o0 && i0 < o1;
+    const bool own1 = 2 * j + 1 < count && i0 + 1 >= o0 && i0 + 1 < o1;
+    double v0 = 0.0, v1 = 0.0;
+    if (own0) {
+      const int q = qpos(i0);
+      v0 = lds[q + (q >> 4)];
+    }
+    if (own1) {
+      const int q = qpos(i0 + 1);
+      v1 = lds[q + (q >> 4)];
+    }
+    if (own0 && own1) {
+      *reinterpret_cast<double2_t*>(out + i0) = double2_t{v0, v1};
+      if (hist) {  // history columns start at it*n, which is odd-aligned for odd n: scalar stores
+        hist[i0] = v0;
+        hist[i0 + 1] = v1;
+      }
+    } else {
+      if (own0) {
+        out[i0] = v0;
+        if (hist) hist[i0] = v0;
+      }
+      if (own1) {
+        out[i0 + 1] = v1;
+        if (hist) hist[i0 + 1] = v1;
       }
     }
   }
@@ -243,7 +296,8 @@ int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, i
   if (!(worst < 1.0)) return fail(ADMM_E_NUMERIC, "total variation: matrix is not diagonally dominant");
   const double h = std::log(1e-18) / std::log(worst);
   int H = static_cast<int>(std::ceil(h));
-  if (H < 1) H = 1;
+  if (H < 2) H = 2;
+  if (H & 1) H += 1;  // even: the sweeps walk the processing range in aligned pairs
   if (H <= 1024) {
     *elems = 20;
     *tile = 256 * 20 - 1024;
