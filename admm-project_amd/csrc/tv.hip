@@ -298,12 +298,18 @@ int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, i
   int H = static_cast<int>(std::ceil(h));
   if (H < 2) H = 2;
   if (H & 1) H += 1;  // even: the sweeps walk the processing range in aligned pairs
-  if (H <= 1024) {
+  // workgroup capacity = 256*elems positions = owned tile + halo.  Small tiles keep the LDS
+  // footprint low (17 KiB at elems = 8 -> 8 workgroups per CU), which is what hides the
+  // load -> scan -> store phase structure of a workgroup behind its neighbours.
+  if (H <= 256) {
+    *elems = 8;
+    *tile = 256 * 8 - H;
+  } else if (H <= 1024) {
     *elems = 20;
-    *tile = 256 * 20 - 1024;
+    *tile = 256 * 20 - H;
   } else if (H <= 4096) {
     *elems = 48;
-    *tile = 256 * 48 - 4096;
+    *tile = 256 * 48 - H;
   } else {
     return fail(ADMM_E_UNSUPPORTED, "total variation: rho too large for the windowed tridiagonal solve");
   }
@@ -315,7 +321,10 @@ void launch_tv_sweep(const TvArgs& a, bool backward, const Ctrl* ctrl, hipStream
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n, a.tile));
   const int cap = a.elems * kBlock;
   const size_t lds = static_cast<size_t>(cap + (cap >> 4) + 1) * sizeof(double);
-  if (a.elems == 20) {
+  if (a.elems == 8) {
+    if (backward) hipLaunchKernelGGL((tv_sweep_kernel<8, true>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+    else hipLaunchKernelGGL((tv_sweep_kernel<8, false>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
+  } else if (a.elems == 20) {
     if (backward) hipLaunchKernelGGL((tv_sweep_kernel<20, true>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
     else hipLaunchKernelGGL((tv_sweep_kernel<20, false>), dim3(blocks), dim3(kBlock), lds, stream, a, ctrl);
   } else {

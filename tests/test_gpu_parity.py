@@ -200,7 +200,8 @@ def test_basispursuit(gpu):
     (1000, 2.0, 1.0, dict()),
     (5000, 0.5, 3.0, dict(stopcond="both")),        # several tiles + halo overlap
     (9973, 1.0, 0.25, dict(convtest=1)),
-    (4096, 1.0, 40.0, dict(maxiters=300)),          # slower-decaying recurrence (halo ~ 270)
+    (4096, 1.0, 40.0, dict(maxiters=300)),          # slower-decaying recurrence (halo ~ 270, 20-element tiles)
+    (30011, 1.0, 800.0, dict(maxiters=6, domaxiters=1)),  # halo ~ 1200: 48-element tiles, odd n
     (2, 1.0, 1.0, dict(maxiters=5)), (257, 0.0, 1.0, dict(maxiters=20)),
 ])
 def test_total_variation(gpu, n, lam, rho, opts):
