@@ -290,12 +290,21 @@ int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, i
     return fail(ADMM_E_UNSUPPORTED, "total variation: tridiagonal pivots did not become stationary (rho too large)");
   *bstar = cur;
   *prefix = b;
-  const double amax = rho / cur;  // limiting multiplier; earlier ones are smaller or equal in effect
-  double worst = amax;
-  for (double bv : b) worst = (rho / bv > worst) ? rho / bv : worst;
-  if (!(worst < 1.0)) return fail(ADMM_E_NUMERIC, "total variation: matrix is not diagonally dominant");
-  const double h = std::log(1e-18) / std::log(worst);
-  int H = static_cast<int>(std::ceil(h));
+  // Halo length: a window that does not reach row 0 must damp an arbitrary incoming carry below
+  // 1e-18.  The multipliers rho/b_i decrease monotonically towards rho/b*, so the weakest damping
+  // is the window that starts right after row 0: multiply the actual multipliers from there.
+  // (Both sweeps use the same multipliers, the backward one indexed from the other end where they
+  // are stationary, so this bound covers it.)
+  const double astar = rho / cur;
+  if (!(astar < 1.0) || !(rho / b[0] < 1.0))
+    return fail(ADMM_E_NUMERIC, "total variation: matrix is not diagonally dominant");
+  double prod = 1.0;
+  int H = 0;
+  while (prod > 1e-18 && H < (1 << 20)) {
+    const size_t idx = static_cast<size_t>(H);
+    prod *= (idx < b.size()) ? rho / b[idx] : astar;
+    ++H;
+  }
   if (H < 2) H = 2;
   if (H & 1) H += 1;  // even: the sweeps walk the processing range in aligned pairs
   // workgroup capacity = 256*elems positions = owned tile + halo.  Small tiles keep the LDS
