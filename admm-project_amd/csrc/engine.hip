@@ -102,6 +102,9 @@ struct admm_engine {
   GemvNPlan planDN{};   // D*x
   GemvTPlan planDT{};   // D'*v
   GemvTPlan planSq{};   // square symmetric nA x nA GEMV (Minv or P) run as column dots: M*v == M'*v
+  SymvPlan planSy{};    // Minv applied from its lower triangle only (half the bytes)
+  double *syN = nullptr, *syT = nullptr;
+  bool sy_half = false;
   double *partDN = nullptr, *partDT = nullptr, *partSq = nullptr;
 
   // iterates
@@ -272,6 +275,12 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
       if (p == X) p = nullptr;
     e->planSq = gemv_t_plan(nF, nF, ld);
     ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
+    e->sy_half = std::getenv("ADMM_HIP_FULL_SYMV") == nullptr;
+    if (e->sy_half) {
+      e->planSy = symv_plan(nF, ld);
+      ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
+      ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));
+    }
   } else {
     double* dv = e->dinv;
     ADMM_TRY(trsv_build(W, nF, ld, &dv, &e->trsv, e->stream));
@@ -283,7 +292,9 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 // out = F^-T F^-1 y  (out has nF elements).  For the INVERSE path the result is left as
 // chunk partials in partSq unless `materialize`.
 void solve_factor(admm_engine* e, const double* y, double* out) {
-  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+  if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
+    launch_symv_lower(e->planSy, e->Minv, y, e->syN, e->syT, out, e->ctrl, e->stream);
+  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
     launch_gemv_t(e->planSq, e->Minv, y, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
     launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldg, e->nF, out, e->ctrl, e->stream);
   } else {
@@ -835,7 +846,9 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
-        if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
+        if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
+          launch_symv_lower(e->planSy, e->Minv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+        } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
           launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
           *axsrc = e->partSq;
           *naxpart = e->planSq.nchunk;
@@ -855,7 +868,9 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       }
       break;
     case ADMM_PROB_QP_BOUNDED:
-      if (e->xsolve == ADMM_XSOLVE_INVERSE) {
+      if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
+        launch_symv_lower(e->planSy, e->Minv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+      } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
         // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
         const GemvTPlan& p = e->planSq;
         launch_gemv_t(p, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);

@@ -36,6 +36,19 @@ void launch_gemv_t(const GemvTPlan& p, const double* D, const double* v0, const 
 void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,
                            const Ctrl* ctrl, hipStream_t stream);
 
+// y = M*x for symmetric M from its lower triangle only (half the bytes of a full GEMV).
+struct SymvPlan {
+  int64_t n, ld;
+  int64_t ldp;    // row stride of the partial arrays
+  int32_t nrow;   // 512-row chunks  -> tpart is [nrow][ldp]
+  int32_t ncol;   // 128-column groups -> npart is [ncol][ldp]
+  size_t npart_elems() const { return static_cast<size_t>(ncol) * ldp; }
+  size_t tpart_elems() const { return static_cast<size_t>(nrow) * ldp; }
+};
+SymvPlan symv_plan(int64_t n, int64_t ld);
+void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
+                       const Ctrl* ctrl, hipStream_t stream);
+
 // ---------------------------------------------------------------- dense setup (dense.hip)
 // C = alpha*op(A)*op(B) + beta*C, column-major fp64 on the MFMA f64 path.  transA/transB: 0 = N, 1 = T.
 // lower_only: compute only tiles that touch the lower triangle (SYRK-style symmetric results).

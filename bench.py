@@ -222,8 +222,12 @@ def main():
     # the same K steps without HIP events in the stream: batches of iterations replay as a hipGraph
     dt_graph, _ = timed_run(eng, dist, a.steps, rho=rho)
     if a.xsolve == "inverse":
-        alg_bytes = 8.0 * n * n  # one pass over the symmetric n x n inverse (full storage)
-        kname = "gemv_t_kernel<1> (x = inv(D'D+rho I) * y as column dots of the symmetric inverse)"
+        if os.environ.get("ADMM_HIP_FULL_SYMV"):
+            alg_bytes = 8.0 * n * n  # one pass over the full symmetric n x n inverse
+            kname = "gemv_t_kernel<1> (x = inv(D'D+rho I) * y as column dots of the symmetric inverse)"
+        else:
+            alg_bytes = 8.0 * n * (n + 1) / 2  # lower triangle of the symmetric inverse, read once
+            kname = "symv_lower_kernel (+ symv_reduce): x = inv(D'D+rho I) * y from the lower triangle only"
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "trsv_fwd/bwd_step kernels (x = L'\\(L\\y))"

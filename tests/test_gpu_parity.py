@@ -52,7 +52,8 @@ def _compare(got, ref, keys=HIST, tol=TOL, limit=None):
 
 # ---------------------------------------------------------------------------- oracle parity
 @pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
-@pytest.mark.parametrize("rows,cols,seed", [(256, 64, 0), (300, 150, 1), (97, 65, 2), (1000, 200, 3)])
+@pytest.mark.parametrize("rows,cols,seed", [(256, 64, 0), (300, 150, 1), (97, 65, 2), (1000, 200, 3),
+                                            (2500, 1100, 4)])  # n = 1100: 3 x 9 tiles of the symmetric-half GEMV
 def test_lasso_tall(gpu, rows, cols, seed, xsolve):
     p = gpu.synth.lasso_problem(seed, rows, cols)
     o = dict(objevals=1)
