@@ -285,125 +285,4 @@ void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, do
                      p.nchunk, nrhs, p.ldg, p.n, g, ldg_out, ctrl);
 }
 
-// ------------------------------------------------------------------------------------
-// symv_lower: y = M*x for a SYMMETRIC M reading only its lower triangle (half the bytes).
-// Used for the explicit-inverse x-update (x = inv(D'D + rho I)*y, getProxOps.m:1200 semantics).
-//
-// Workgroup = tile of 512 rows x 128 columns that touches the lower triangle.  Every element
-// M[r,j] of the tile is loaded once (16-byte loads, thread owns a row pair, loops over the
-// columns) and used twice:
-//   N-part  yN[r] += M[r,j]*x[j]        (j <= r)   register accumulation per row
-//   T-part  yT[j] += M[r,j]*x[r]        (r >  j)   per-column accumulators, reduced over the
-//                                                  workgroup once per 32-column panel
-// Partials: npart[cg][r] per column group, tpart[rc][j] per row chunk; a small second kernel adds
-// them in a fixed order (bitwise reproducible, no atomics).
-// ------------------------------------------------------------------------------------
-constexpr int kSyRows = 512;   // rows per tile (256 threads x 2)
-constexpr int kSyCols = 128;   // columns per tile
-constexpr int kSyPanel = 32;   // T-part accumulators kept in registers at a time
-
-__global__ __launch_bounds__(kBlock) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
-                                                            const double* __restrict__ x, double* __restrict__ npart,
-                                                            double* __restrict__ tpart, int64_t ldp,
-                                                            const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
-  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kSyRows;
-  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyCols;
-  if (r0 + kSyRows - 1 < c0) return;  // tile strictly above the diagonal
-  __shared__ double sred[4][kSyPanel];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int64_t r = r0 + 2 * tid;  // this thread's row pair (r, r+1)
-  const bool live0 = r < n, live1 = r + 1 < n;
-  const double xr0 = live0 ? x[r] : 0.0, xr1 = live1 ? x[r + 1] : 0.0;
-  const bool diag = r0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
-  double n0 = 0.0, n1 = 0.0;
-  const int64_t cend = (c0 + kSyCols < n) ? c0 + kSyCols : n;
-  for (int64_t cp = c0; cp < cend; cp += kSyPanel) {
-    double tacc[kSyPanel];
-#pragma unroll
-    for (int k = 0; k < kSyPanel; ++k) tacc[k] = 0.0;
-    {
-      // all indices static (registers, not scratch); columns past the matrix edge load zeros
-      double2_t d[kSyPanel];
-#pragma unroll
-      for (int k = 0; k < kSyPanel; ++k) {
-        d[k] = double2_t{0.0, 0.0};
-        if (cp + k < cend) {
-          if (live1) d[k] = *reinterpret_cast<const double2_t*>(M + r + (cp + k) * ld);
-          else if (live0) d[k].x = M[r + (cp + k) * ld];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < kSyPanel; ++k) {
-        const int64_t j = cp + k;
-        const double xj = (j < cend) ? x[j] : 0.0;
-        double a0 = d[k].x, a1 = d[k].y;
-        if (diag) {  // keep only the lower triangle: N-part j <= row, T-part row > j
-          const bool in0 = j <= r, in1 = j <= r + 1;
-          const double t0 = (r > j) ? a0 : 0.0, t1 = (r + 1 > j) ? a1 : 0.0;
-          tacc[k] = __builtin_fma(t0, xr0, __builtin_fma(t1, xr1, tacc[k]));
-          a0 = in0 ? a0 : 0.0;
-          a1 = in1 ? a1 : 0.0;
-        } else {
-          tacc[k] = __builtin_fma(a0, xr0, __builtin_fma(a1, xr1, tacc[k]));
-        }
-        n0 = __builtin_fma(a0, xj, n0);
-        n1 = __builtin_fma(a1, xj, n1);
-      }
-    }
-    // reduce the panel's column sums over the workgroup
-#pragma unroll
-    for (int k = 0; k < kSyPanel; ++k) {
-      const double s = wave_sum(tacc[k]);
-      if (lane == 0) sred[wid][k] = s;
-    }
-    __syncthreads();
-    if (tid < kSyPanel && cp + tid < cend)
-      tpart[static_cast<int64_t>(blockIdx.x) * ldp + cp + tid] =
-          ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
-    __syncthreads();
-  }
-  if (live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + r] = n0;
-  if (live1) npart[static_cast<int64_t>(blockIdx.y) * ldp + r + 1] = n1;
-}
-
-// y[i] = sum over column groups g <= i/128 of npart[g][i] + sum over row chunks c >= i/512 of tpart[c][i]
-__global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __restrict__ npart,
-                                                             const double* __restrict__ tpart, int64_t ldp,
-                                                             int64_t n, int32_t nrow, double* __restrict__ y,
-                                                             const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double s = 0.0;
-    const int32_t gmax = static_cast<int32_t>(i / kSyCols);
-    // column groups whose tile row (i/512) reaches the diagonal: g*128 <= r0 + 511
-    for (int32_t g = 0; g <= gmax; ++g) s += npart[static_cast<int64_t>(g) * ldp + i];
-    // row chunks c with c*512 + 511 >= (i/128)*128, i.e. tiles that exist for column i
-    const int32_t cmin = static_cast<int32_t>(((i / kSyCols) * kSyCols) / kSyRows);
-    for (int32_t c = cmin; c < nrow; ++c) s += tpart[static_cast<int64_t>(c) * ldp + i];
-    y[i] = s;
-  }
-}
-
-SymvPlan symv_plan(int64_t n, int64_t ld) {
-  SymvPlan p{};
-  p.n = n;
-  p.ld = ld;
-  p.ldp = round_up(n, 2);
-  p.nrow = static_cast<int32_t>(ceil_div(n, kSyRows));
-  p.ncol = static_cast<int32_t>(ceil_div(n, kSyCols));
-  return p;
-}
-
-void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
-                       const Ctrl* ctrl, hipStream_t stream) {
-  dim3 grid(static_cast<unsigned>(p.nrow), static_cast<unsigned>(p.ncol));
-  hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kBlock), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
-  int64_t blocks = ceil_div(p.n, kBlock);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
-                     p.ldp, p.n, p.nrow, y, ctrl);
-}
-
 }  // namespace admm
