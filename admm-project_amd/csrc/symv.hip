@@ -18,33 +18,38 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSyWaveRows = 128;  // rows per wave (64 lanes x 2)
 constexpr int kSyBlkRows = 512;   // rows per workgroup (4 waves)
-constexpr int kSyCols = 256;      // columns per workgroup
-constexpr int kSyPanel = 8;       // columns per panel = loads in flight per lane = T-part accumulators
+constexpr int kSyCols = 128;      // columns per workgroup
+constexpr int kSyPanel = 16;      // columns per panel = loads in flight per lane = T-part accumulators
 
-// reduce-scatter of 8 per-lane values over the 64 lanes of a wave: on return every lane holds the
-// wave-wide sum of element *col (its lane bits 5..3 select the column); 7 + 3 shuffles.
-__device__ __forceinline__ double reduce_scatter8(const double (&t)[kSyPanel], int lane, int* col) {
-  double a4[4], a2[2];
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+// reduce-scatter of 16 per-lane values over the 64 lanes of a wave: on return every lane holds the
+// wave-wide sum of element *col (its lane bits 5..2 select the column); 15 + 2 shuffles.
+__device__ __forceinline__ double reduce_scatter16(const double (&t)[kSyPanel], int lane, int* col) {
+  double a8[8], a4[4], a2[2];
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double keep = b5 ? t[k + 8] : t[k];
+    const double send = b5 ? t[k] : t[k + 8];
+    a8[k] = keep + __shfl_xor(send, 32, 64);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const double keep = b5 ? t[k + 4] : t[k];
-    const double send = b5 ? t[k] : t[k + 4];
-    a4[k] = keep + __shfl_xor(send, 32, 64);
+    const double keep = b4 ? a8[k + 4] : a8[k];
+    const double send = b4 ? a8[k] : a8[k + 4];
+    a4[k] = keep + __shfl_xor(send, 16, 64);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double keep = b4 ? a4[k + 2] : a4[k];
-    const double send = b4 ? a4[k] : a4[k + 2];
-    a2[k] = keep + __shfl_xor(send, 16, 64);
+    const double keep = b3 ? a4[k + 2] : a4[k];
+    const double send = b3 ? a4[k] : a4[k + 2];
+    a2[k] = keep + __shfl_xor(send, 8, 64);
   }
-  const double keep = b3 ? a2[1] : a2[0];
-  const double send = b3 ? a2[0] : a2[1];
-  double r = keep + __shfl_xor(send, 8, 64);
-  r += __shfl_xor(r, 4, 64);
+  const double keep = b2 ? a2[1] : a2[0];
+  const double send = b2 ? a2[0] : a2[1];
+  double r = keep + __shfl_xor(send, 4, 64);
   r += __shfl_xor(r, 2, 64);
   r += __shfl_xor(r, 1, 64);
-  *col = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+  *col = (b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0);
   return r;
 }
 
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(kBlock) void symv_lower_kernel(const double* __rest
       n1 = __builtin_fma(a1, xj, n1);
     }
     int col;
-    const double s = reduce_scatter8(tacc, lane, &col);
-    if ((lane & 7) == 0 && cp + col < cend) tpart[wave_chunk * ldp + cp + col] = s;
+    const double s = reduce_scatter16(tacc, lane, &col);
+    if ((lane & 3) == 0 && cp + col < cend) tpart[wave_chunk * ldp + cp + col] = s;
   }
   if (live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + r) = double2_t{n0, n1};
   else if (live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + r] = n0;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __res
     for (int32_t g = sub; g <= gmax && g <= glast; g += 4) s += npart[static_cast<int64_t>(g) * ldp + i];
     // T partials: wave chunks w >= 2*(i/256) whose rows reach column i's group, and whose panel
     // containing i was not skipped: w*128 + 127 >= (i/32)*32
-    const int32_t wmin_group = 2 * static_cast<int32_t>(i / kSyCols);
+    const int32_t wmin_group = static_cast<int32_t>((i / kSyCols) * kSyCols / kSyWaveRows);
     const int32_t wmin_panel = static_cast<int32_t>(((i / kSyPanel) * kSyPanel) / kSyWaveRows);
     const int32_t wmin = wmin_group > wmin_panel ? wmin_group : wmin_panel;
     for (int32_t w = wmin + sub; w < nwave; w += 4) s += tpart[static_cast<int64_t>(w) * ldp + i];
