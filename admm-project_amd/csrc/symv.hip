@@ -17,7 +17,7 @@ namespace admm {
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSyWaveRows = 128;  // rows per wave (64 lanes x 2)
-constexpr int kSyBlkRows = 512;   // rows per workgroup (4 waves)
+constexpr int kSyBlkRows = 128;   // rows per workgroup: ONE wave, so the triangular tile set load-balances finely
 constexpr int kSyCols = 128;      // columns per workgroup
 constexpr int kSyPanel = 16;      // columns per panel = loads in flight per lane = T-part accumulators
 
@@ -53,7 +53,7 @@ __device__ __forceinline__ double reduce_scatter16(const double (&t)[kSyPanel], 
   return r;
 }
 
-__global__ __launch_bounds__(kBlock) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
+__global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
                                                             const double* __restrict__ x, double* __restrict__ npart,
                                                             double* __restrict__ tpart, int64_t ldp,
                                                             const Ctrl* __restrict__ ctrl) {
@@ -148,7 +148,7 @@ SymvPlan symv_plan(int64_t n, int64_t ld) {
 void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
                        const Ctrl* ctrl, hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(ceil_div(p.n, kSyBlkRows)), static_cast<unsigned>(p.ncol));
-  hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kBlock), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
+  hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kWave), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
   int64_t blocks = ceil_div(4 * p.n, kBlock);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
