@@ -4,11 +4,12 @@
 // Every element M[r,j] (r >= j) is loaded once and used twice:
 //   N-part  yN[r] += M[r,j]*x[j]        register accumulation per row (like gemv_n)
 //   T-part  yT[j] += M[r,j]*x[r], r > j per-column sums over the rows (like gemv_t)
-// A WAVE is the unit of work (128 rows x 256 columns, 16-byte loads, lane owns a row pair) and
-// never synchronises with the other waves of its workgroup: the T-part column sums of an
-// 8-column panel are combined inside the wave by a 10-shuffle reduce-scatter; with 4+ waves per
-// SIMD the loads of other waves cover the reduction.
-// Partials (npart per 256-column group, tpart per 128-row wave chunk) are added by a second small
+// A WAVE is the unit of work (one-wave workgroups: 128 rows x 128 columns, 16-byte loads, lane
+// owns a row pair), so the triangular tile set load-balances finely and nothing synchronises.
+// The T-part column sums of an 8-column panel are combined inside the wave by a 10-shuffle
+// reduce-scatter; the loads of the NEXT panel are issued before that reduction (two register
+// buffers, hand-pipelined), so the memory pipe never drains while a wave shuffles.
+// Partials (npart per 128-column group, tpart per 128-row wave chunk) are added by a second small
 // kernel in a fixed order: bitwise reproducible, no float atomics.
 #include "kernels.h"
 
@@ -16,95 +17,122 @@ namespace admm {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-constexpr int kSyWaveRows = 128;  // rows per wave (64 lanes x 2)
-constexpr int kSyBlkRows = 128;   // rows per workgroup: ONE wave, so the triangular tile set load-balances finely
+constexpr int kSyWaveRows = 128;  // rows per wave = per workgroup (64 lanes x 2)
 constexpr int kSyCols = 128;      // columns per workgroup
-constexpr int kSyPanel = 16;      // columns per panel = loads in flight per lane = T-part accumulators
+constexpr int kSyPanel = 8;       // columns per panel = loads per buffer = T-part accumulators
 
-// reduce-scatter of 16 per-lane values over the 64 lanes of a wave: on return every lane holds the
-// wave-wide sum of element *col (its lane bits 5..2 select the column); 15 + 2 shuffles.
-__device__ __forceinline__ double reduce_scatter16(const double (&t)[kSyPanel], int lane, int* col) {
-  double a8[8], a4[4], a2[2];
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const double keep = b5 ? t[k + 8] : t[k];
-    const double send = b5 ? t[k] : t[k + 8];
-    a8[k] = keep + __shfl_xor(send, 32, 64);
-  }
+// reduce-scatter of 8 per-lane values over the 64 lanes of a wave: on return every lane holds the
+// wave-wide sum of element *col (its lane bits 5..3 select the column); 7 + 3 shuffles.
+__device__ __forceinline__ double reduce_scatter8(const double (&t)[kSyPanel], int lane, int* col) {
+  double a4[4], a2[2];
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const double keep = b4 ? a8[k + 4] : a8[k];
-    const double send = b4 ? a8[k] : a8[k + 4];
-    a4[k] = keep + __shfl_xor(send, 16, 64);
+    const double keep = b5 ? t[k + 4] : t[k];
+    const double send = b5 ? t[k] : t[k + 4];
+    a4[k] = keep + __shfl_xor(send, 32, 64);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double keep = b3 ? a4[k + 2] : a4[k];
-    const double send = b3 ? a4[k] : a4[k + 2];
-    a2[k] = keep + __shfl_xor(send, 8, 64);
+    const double keep = b4 ? a4[k + 2] : a4[k];
+    const double send = b4 ? a4[k] : a4[k + 2];
+    a2[k] = keep + __shfl_xor(send, 16, 64);
   }
-  const double keep = b2 ? a2[1] : a2[0];
-  const double send = b2 ? a2[0] : a2[1];
-  double r = keep + __shfl_xor(send, 4, 64);
+  const double keep = b3 ? a2[1] : a2[0];
+  const double send = b3 ? a2[0] : a2[1];
+  double r = keep + __shfl_xor(send, 8, 64);
+  r += __shfl_xor(r, 4, 64);
   r += __shfl_xor(r, 2, 64);
   r += __shfl_xor(r, 1, 64);
-  *col = (b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0);
+  *col = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
   return r;
 }
 
-__global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
-                                                            const double* __restrict__ x, double* __restrict__ npart,
-                                                            double* __restrict__ tpart, int64_t ldp,
-                                                            const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyBlkRows + wid * kSyWaveRows;  // wave's first row
-  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyCols;
-  if (w0 >= n || w0 + kSyWaveRows - 1 < c0) return;  // nothing of the lower triangle in this wave's tile
-  const int64_t r = w0 + 2 * lane;  // this lane's row pair (r, r+1)
-  const bool live0 = r < n, live1 = r + 1 < n;
-  const double xr0 = live0 ? x[r] : 0.0, xr1 = live1 ? x[r + 1] : 0.0;
-  const bool diag = w0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
-  const int64_t cend = (c0 + kSyCols < n) ? c0 + kSyCols : n;
-  const int64_t wave_chunk = w0 / kSyWaveRows;
-  double n0 = 0.0, n1 = 0.0;
-#pragma unroll 1
-  for (int64_t cp = c0; cp < cend; cp += kSyPanel) {
-    if (w0 + kSyWaveRows - 1 < cp) break;  // the remaining panels lie strictly above the diagonal
-    double tacc[kSyPanel];
-    double2_t d[kSyPanel];
+struct SyLane {  // per-lane constants of a tile
+  const double* M;
+  const double* x;
+  int64_t ld, r, cend;
+  bool live0, live1, diag;
+  double xr0, xr1;
+};
+
+__device__ __forceinline__ void sy_load(const SyLane& s, int64_t cp, double2_t (&d)[kSyPanel]) {
 #pragma unroll
-    for (int k = 0; k < kSyPanel; ++k) {
-      const int64_t j = cp + k;
-      d[k] = double2_t{0.0, 0.0};
-      if (j < cend) {
-        if (live1) d[k] = *reinterpret_cast<const double2_t*>(M + r + j * ld);
-        else if (live0) d[k].x = M[r + j * ld];
-      }
+  for (int k = 0; k < kSyPanel; ++k) {
+    const int64_t j = cp + k;
+    d[k] = double2_t{0.0, 0.0};
+    if (j < s.cend) {
+      if (s.live1) d[k] = *reinterpret_cast<const double2_t*>(s.M + s.r + j * s.ld);
+      else if (s.live0) d[k].x = s.M[s.r + j * s.ld];
     }
-#pragma unroll
-    for (int k = 0; k < kSyPanel; ++k) {
-      const int64_t j = cp + k;
-      const double xj = (j < cend) ? x[j] : 0.0;  // wave-uniform -> scalar load
-      double a0 = d[k].x, a1 = d[k].y;
-      double t0 = a0, t1 = a1;
-      if (diag) {  // lower triangle only: N-part j <= row, T-part row > j
-        t0 = (r > j) ? a0 : 0.0;
-        t1 = (r + 1 > j) ? a1 : 0.0;
-        a0 = (j <= r) ? a0 : 0.0;
-        a1 = (j <= r + 1) ? a1 : 0.0;
-      }
-      tacc[k] = __builtin_fma(t0, xr0, t1 * xr1);
-      n0 = __builtin_fma(a0, xj, n0);
-      n1 = __builtin_fma(a1, xj, n1);
-    }
-    int col;
-    const double s = reduce_scatter16(tacc, lane, &col);
-    if ((lane & 3) == 0 && cp + col < cend) tpart[wave_chunk * ldp + cp + col] = s;
   }
-  if (live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + r) = double2_t{n0, n1};
-  else if (live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + r] = n0;
+}
+
+__device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const double2_t (&d)[kSyPanel], double& n0,
+                                           double& n1, double* __restrict__ tout, int lane) {
+  double tacc[kSyPanel];
+#pragma unroll
+  for (int k = 0; k < kSyPanel; ++k) {
+    const int64_t j = cp + k;
+    const double xj = (j < s.cend) ? s.x[j] : 0.0;  // wave-uniform -> scalar load
+    double a0 = d[k].x, a1 = d[k].y;
+    double t0 = a0, t1 = a1;
+    if (s.diag) {  // lower triangle only: N-part j <= row, T-part row > j
+      t0 = (s.r > j) ? a0 : 0.0;
+      t1 = (s.r + 1 > j) ? a1 : 0.0;
+      a0 = (j <= s.r) ? a0 : 0.0;
+      a1 = (j <= s.r + 1) ? a1 : 0.0;
+    }
+    tacc[k] = __builtin_fma(t0, s.xr0, t1 * s.xr1);
+    n0 = __builtin_fma(a0, xj, n0);
+    n1 = __builtin_fma(a1, xj, n1);
+  }
+  int col;
+  const double sum = reduce_scatter8(tacc, lane, &col);
+  if ((lane & 7) == 0 && cp + col < s.cend) tout[cp + col] = sum;
+}
+
+__global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
+                                                           const double* __restrict__ x, double* __restrict__ npart,
+                                                           double* __restrict__ tpart, int64_t ldp,
+                                                           const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyWaveRows;  // wave's first row
+  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyCols;
+  if (w0 >= n || w0 + kSyWaveRows - 1 < c0) return;  // nothing of the lower triangle in this tile
+  SyLane s;
+  s.M = M;
+  s.x = x;
+  s.ld = ld;
+  s.r = w0 + 2 * lane;  // this lane's row pair (r, r+1)
+  s.live0 = s.r < n;
+  s.live1 = s.r + 1 < n;
+  s.xr0 = s.live0 ? x[s.r] : 0.0;
+  s.xr1 = s.live1 ? x[s.r + 1] : 0.0;
+  s.diag = w0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
+  s.cend = (c0 + kSyCols < n) ? c0 + kSyCols : n;
+  // panels at or beyond this column lie strictly above the diagonal for every row of the wave
+  const int64_t limit = (s.cend < w0 + kSyWaveRows) ? s.cend : w0 + kSyWaveRows;
+  double* __restrict__ tout = tpart + static_cast<int64_t>(blockIdx.x) * ldp;
+  double n0 = 0.0, n1 = 0.0;
+  double2_t bufA[kSyPanel], bufB[kSyPanel];
+  int64_t cp = c0;
+  sy_load(s, cp, bufA);
+#pragma unroll 1
+  for (;;) {
+    const bool haveB = cp + kSyPanel < limit;
+    if (haveB) sy_load(s, cp + kSyPanel, bufB);  // next panel's loads fly during this panel's reduction
+    sy_compute(s, cp, bufA, n0, n1, tout, lane);
+    if (!haveB) break;
+    const bool haveA = cp + 2 * kSyPanel < limit;
+    if (haveA) sy_load(s, cp + 2 * kSyPanel, bufA);
+    sy_compute(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
+    if (!haveA) break;
+    cp += 2 * kSyPanel;
+  }
+  if (s.live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
+  else if (s.live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + s.r] = n0;
 }
 
 // y[i] = sum_g npart[g][i] + sum_w tpart[w][i] over the partials that exist for element i.
@@ -118,16 +146,13 @@ __global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __res
   for (int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 2; i < n;
        i += (static_cast<int64_t>(gridDim.x) * kBlock) >> 2) {
     double s = 0.0;
-    // N partials: column groups g with g*256 <= (first row of i's wave chunk) + 127
+    // N partials: column groups g whose tile exists for i's wave chunk: g*kSyCols <= w0 + 127
     const int64_t w0 = (i / kSyWaveRows) * kSyWaveRows;
     const int32_t gmax = static_cast<int32_t>((w0 + kSyWaveRows - 1) / kSyCols);
     const int32_t glast = static_cast<int32_t>((n - 1) / kSyCols);
     for (int32_t g = sub; g <= gmax && g <= glast; g += 4) s += npart[static_cast<int64_t>(g) * ldp + i];
-    // T partials: wave chunks w >= 2*(i/256) whose rows reach column i's group, and whose panel
-    // containing i was not skipped: w*128 + 127 >= (i/32)*32
-    const int32_t wmin_group = static_cast<int32_t>((i / kSyCols) * kSyCols / kSyWaveRows);
-    const int32_t wmin_panel = static_cast<int32_t>(((i / kSyPanel) * kSyPanel) / kSyWaveRows);
-    const int32_t wmin = wmin_group > wmin_panel ? wmin_group : wmin_panel;
+    // T partials: wave chunks w that processed the panel containing column i: w*128 + 127 >= panel start
+    const int32_t wmin = static_cast<int32_t>(((i / kSyPanel) * kSyPanel) / kSyWaveRows);
     for (int32_t w = wmin + sub; w < nwave; w += 4) s += tpart[static_cast<int64_t>(w) * ldp + i];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
@@ -140,14 +165,14 @@ SymvPlan symv_plan(int64_t n, int64_t ld) {
   p.n = n;
   p.ld = ld;
   p.ldp = round_up(n, 2);
-  p.nrow = static_cast<int32_t>(ceil_div(n, kSyWaveRows));  // tpart rows
-  p.ncol = static_cast<int32_t>(ceil_div(n, kSyCols));      // npart rows
+  p.nrow = static_cast<int32_t>(ceil_div(n, kSyWaveRows));  // tpart rows (wave chunks)
+  p.ncol = static_cast<int32_t>(ceil_div(n, kSyCols));      // npart rows (column groups)
   return p;
 }
 
 void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
                        const Ctrl* ctrl, hipStream_t stream) {
-  dim3 grid(static_cast<unsigned>(ceil_div(p.n, kSyBlkRows)), static_cast<unsigned>(p.ncol));
+  dim3 grid(static_cast<unsigned>(p.nrow), static_cast<unsigned>(p.ncol));
   hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kWave), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
   int64_t blocks = ceil_div(4 * p.n, kBlock);
   if (blocks > 4096) blocks = 4096;
