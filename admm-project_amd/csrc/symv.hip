@@ -52,32 +52,42 @@ struct SyLane {  // per-lane constants of a tile
   const double* M;
   const double* x;
   int64_t ld, r, cend;
-  bool live0, live1, diag;
+  int r32;  // r as a 32-bit element offset from the wave-uniform column base
+  bool live0, live1;
   double xr0, xr1;
 };
 
+// FAST: every row of the wave and every column of the panel is inside the matrix -> no guards at
+// all on the hot path (straight-line loads).  DIAG: the tile intersects the diagonal -> mask.
+template <bool FAST>
 __device__ __forceinline__ void sy_load(const SyLane& s, int64_t cp, double2_t (&d)[kSyPanel]) {
 #pragma unroll
   for (int k = 0; k < kSyPanel; ++k) {
     const int64_t j = cp + k;
-    d[k] = double2_t{0.0, 0.0};
-    if (j < s.cend) {
-      if (s.live1) d[k] = *reinterpret_cast<const double2_t*>(s.M + s.r + j * s.ld);
-      else if (s.live0) d[k].x = s.M[s.r + j * s.ld];
+    const double* cb = s.M + j * s.ld;  // wave-uniform column base
+    if (FAST) {
+      d[k] = *reinterpret_cast<const double2_t*>(cb + s.r32);
+    } else {
+      d[k] = double2_t{0.0, 0.0};
+      if (j < s.cend) {
+        if (s.live1) d[k] = *reinterpret_cast<const double2_t*>(cb + s.r32);
+        else if (s.live0) d[k].x = cb[s.r32];
+      }
     }
   }
 }
 
+template <bool FAST, bool DIAG>
 __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const double2_t (&d)[kSyPanel], double& n0,
                                            double& n1, double* __restrict__ tout, int lane) {
   double tacc[kSyPanel];
 #pragma unroll
   for (int k = 0; k < kSyPanel; ++k) {
     const int64_t j = cp + k;
-    const double xj = (j < s.cend) ? s.x[j] : 0.0;  // wave-uniform -> scalar load
+    const double xj = (FAST || j < s.cend) ? s.x[j] : 0.0;  // wave-uniform -> scalar load
     double a0 = d[k].x, a1 = d[k].y;
     double t0 = a0, t1 = a1;
-    if (s.diag) {  // lower triangle only: N-part j <= row, T-part row > j
+    if (DIAG) {  // lower triangle only: N-part j <= row, T-part row > j
       t0 = (s.r > j) ? a0 : 0.0;
       t1 = (s.r + 1 > j) ? a1 : 0.0;
       a0 = (j <= s.r) ? a0 : 0.0;
@@ -89,7 +99,28 @@ __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const do
   }
   int col;
   const double sum = reduce_scatter8(tacc, lane, &col);
-  if ((lane & 7) == 0 && cp + col < s.cend) tout[cp + col] = sum;
+  if ((lane & 7) == 0 && (FAST || cp + col < s.cend)) tout[cp + col] = sum;
+}
+
+// the panels [c0, limit) of one tile, next panel's loads issued before this panel's reduction
+template <bool FAST, bool DIAG>
+__device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, int64_t limit, double& n0, double& n1,
+                                        double* __restrict__ tout, int lane) {
+  double2_t bufA[kSyPanel], bufB[kSyPanel];
+  int64_t cp = c0;
+  sy_load<FAST>(s, cp, bufA);
+#pragma unroll 1
+  for (;;) {
+    const bool haveB = cp + kSyPanel < limit;
+    if (haveB) sy_load<FAST>(s, cp + kSyPanel, bufB);
+    sy_compute<FAST, DIAG>(s, cp, bufA, n0, n1, tout, lane);
+    if (!haveB) break;
+    const bool haveA = cp + 2 * kSyPanel < limit;
+    if (haveA) sy_load<FAST>(s, cp + 2 * kSyPanel, bufA);
+    sy_compute<FAST, DIAG>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
+    if (!haveA) break;
+    cp += 2 * kSyPanel;
+  }
 }
 
 __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
@@ -106,30 +137,23 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
   s.x = x;
   s.ld = ld;
   s.r = w0 + 2 * lane;  // this lane's row pair (r, r+1)
+  s.r32 = static_cast<int>(s.r);
   s.live0 = s.r < n;
   s.live1 = s.r + 1 < n;
   s.xr0 = s.live0 ? x[s.r] : 0.0;
   s.xr1 = s.live1 ? x[s.r + 1] : 0.0;
-  s.diag = w0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
   s.cend = (c0 + kSyCols < n) ? c0 + kSyCols : n;
+  const bool diag = w0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
   // panels at or beyond this column lie strictly above the diagonal for every row of the wave
   const int64_t limit = (s.cend < w0 + kSyWaveRows) ? s.cend : w0 + kSyWaveRows;
+  const bool fast = (w0 + kSyWaveRows <= n) && ((limit - c0) % kSyPanel == 0);
   double* __restrict__ tout = tpart + static_cast<int64_t>(blockIdx.x) * ldp;
   double n0 = 0.0, n1 = 0.0;
-  double2_t bufA[kSyPanel], bufB[kSyPanel];
-  int64_t cp = c0;
-  sy_load(s, cp, bufA);
-#pragma unroll 1
-  for (;;) {
-    const bool haveB = cp + kSyPanel < limit;
-    if (haveB) sy_load(s, cp + kSyPanel, bufB);  // next panel's loads fly during this panel's reduction
-    sy_compute(s, cp, bufA, n0, n1, tout, lane);
-    if (!haveB) break;
-    const bool haveA = cp + 2 * kSyPanel < limit;
-    if (haveA) sy_load(s, cp + 2 * kSyPanel, bufA);
-    sy_compute(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
-    if (!haveA) break;
-    cp += 2 * kSyPanel;
+  if (fast) {
+    if (diag) sy_tile<true, true>(s, c0, limit, n0, n1, tout, lane);
+    else sy_tile<true, false>(s, c0, limit, n0, n1, tout, lane);
+  } else {
+    sy_tile<false, true>(s, c0, limit, n0, n1, tout, lane);  // masking is harmless off the diagonal
   }
   if (s.live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
   else if (s.live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + s.r] = n0;
