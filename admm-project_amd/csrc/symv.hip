@@ -153,35 +153,45 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
     if (diag) sy_tile<true, true>(s, c0, limit, n0, n1, tout, lane);
     else sy_tile<true, false>(s, c0, limit, n0, n1, tout, lane);
   } else {
-    sy_tile<false, true>(s, c0, limit, n0, n1, tout, lane);  // masking is harmless off the diagonal
+    // ragged edge tiles (last row chunk / last column group): one buffer, no pipelining -- keeps the
+    // register budget of the kernel set by the fast path.  Masking is harmless off the diagonal.
+    double2_t buf[kSyPanel];
+#pragma unroll 1
+    for (int64_t cp = c0; cp < limit; cp += kSyPanel) {
+      sy_load<false>(s, cp, buf);
+      sy_compute<false, true>(s, cp, buf, n0, n1, tout, lane);
+    }
   }
   if (s.live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
   else if (s.live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + s.r] = n0;
 }
 
 // y[i] = sum_g npart[g][i] + sum_w tpart[w][i] over the partials that exist for element i.
-// Four lanes per element split the partial rows, then combine in a fixed order.
+// Workgroup = 64 consecutive elements; lanes run along i (coalesced 512-byte rows), the 4 waves
+// split the partial rows and are combined through LDS in a fixed order.
 __global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __restrict__ npart,
                                                              const double* __restrict__ tpart, int64_t ldp,
                                                              int64_t n, int32_t nwave, double* __restrict__ y,
                                                              const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
-  const int sub = threadIdx.x & 3;
-  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 2; i < n;
-       i += (static_cast<int64_t>(gridDim.x) * kBlock) >> 2) {
-    double s = 0.0;
+  __shared__ double sacc[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+  double s = 0.0;
+  if (i < n) {
     // N partials: column groups g whose tile exists for i's wave chunk: g*kSyCols <= w0 + 127
     const int64_t w0 = (i / kSyWaveRows) * kSyWaveRows;
     const int32_t gmax = static_cast<int32_t>((w0 + kSyWaveRows - 1) / kSyCols);
     const int32_t glast = static_cast<int32_t>((n - 1) / kSyCols);
-    for (int32_t g = sub; g <= gmax && g <= glast; g += 4) s += npart[static_cast<int64_t>(g) * ldp + i];
+    const int32_t gend = gmax < glast ? gmax : glast;
+    for (int32_t g = wid; g <= gend; g += 4) s += npart[static_cast<int64_t>(g) * ldp + i];
     // T partials: wave chunks w that processed the panel containing column i: w*128 + 127 >= panel start
     const int32_t wmin = static_cast<int32_t>(((i / kSyPanel) * kSyPanel) / kSyWaveRows);
-    for (int32_t w = wmin + sub; w < nwave; w += 4) s += tpart[static_cast<int64_t>(w) * ldp + i];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (sub == 0) y[i] = s;
+    for (int32_t w = wmin + wid; w < nwave; w += 4) s += tpart[static_cast<int64_t>(w) * ldp + i];
   }
+  sacc[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && i < n) y[i] = ((sacc[0][lane] + sacc[1][lane]) + sacc[2][lane]) + sacc[3][lane];
 }
 
 SymvPlan symv_plan(int64_t n, int64_t ld) {
@@ -198,9 +208,7 @@ void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, doub
                        const Ctrl* ctrl, hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(p.nrow), static_cast<unsigned>(p.ncol));
   hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kWave), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
-  int64_t blocks = ceil_div(4 * p.n, kBlock);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
+  const int64_t blocks = ceil_div(p.n, 64);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
                      p.ldp, p.n, p.nrow, y, ctrl);
 }
