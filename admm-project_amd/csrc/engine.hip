@@ -1370,7 +1370,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // Only worth it in the launch-bound regime (matrices up to 256 MB): capture + instantiate cost
   // about a millisecond, which a GPU-bound loop (8 GB per pass) never earns back.
   const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
-  const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG &&
+  // rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch when its tool library is preloaded:
+  // fall back to eager launches whenever a rocprofiler tool is attached to the process.
+  const char* preload = std::getenv("LD_PRELOAD");
+  const bool profiler_attached = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
+                                 (preload && std::strstr(preload, "rocprof") != nullptr);
+  const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG && !profiler_attached &&
                          heavy <= (int64_t{32} << 20) && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
   auto enqueue_iteration = [&]() -> int {
     {

@@ -24,7 +24,7 @@ def _randn_cols(rng_seed, rows, cols, threads=None):
             j1 = min(cols, j0 + 256)
             out[:, j0:j1] = rng.standard_normal((j1 - j0, rows)).T
         return out
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or int(os.environ.get("ADMM_SYNTH_THREADS", "0")) or min(32, os.cpu_count() or 1)
     blk = 64  # fixed column-block size: the data must not depend on the thread count
     blocks = [(j0, min(cols, j0 + blk)) for j0 in range(0, cols, blk)]
     seeds = np.random.SeedSequence(rng_seed).spawn(len(blocks))
@@ -45,7 +45,7 @@ def _unit_cols_rows(rng_seed, rows, cols, lo, hi, threads=None):
     """Rows [lo, hi) of the column-normalised randn(rows, cols) that ``_randn_cols`` (large path)
     + normalisation produce, without ever holding the full matrix (row-sharded ranks)."""
     out = np.empty((hi - lo, cols), dtype=np.float64, order="F")
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or int(os.environ.get("ADMM_SYNTH_THREADS", "0")) or min(32, os.cpu_count() or 1)
     blk = 64  # fixed column-block size: the data must not depend on the thread count
     blocks = [(j0, min(cols, j0 + blk)) for j0 in range(0, cols, blk)]
     seeds = np.random.SeedSequence(rng_seed).spawn(len(blocks))
