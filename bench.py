@@ -231,6 +231,18 @@ def main():
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "trsv_fwd/bwd_step kernels (x = L'\\(L\\y))"
+    # HBM bytes per x-solve from the committed PMC passes (profiles/r1_traffic.json; bench.py cannot
+    # run rocprofv3 on itself): valid for the default problem size and the symmetric-half kernel only
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if a.xsolve == "inverse" and n == 10000 and not os.environ.get("ADMM_HIP_FULL_SYMV") and os.path.exists(tfile):
+        with open(tfile) as fh:
+            tj = json.load(fh)
+        try:
+            traffic = sum(tj[k]["fetch_bytes_per_launch"] + tj[k]["write_bytes_per_launch"]
+                          for k in ("admm::symv_lower_kernel", "admm::symv_reduce_kernel"))
+        except KeyError:
+            traffic = None
     xs_avg_ms = xs_ms / max(1, xs_cnt)
     achieved = alg_bytes / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
     out = {
@@ -241,7 +253,7 @@ def main():
                                f"domaxiters=1, objevals=0, xsolve={a.xsolve}",
                    "rows": m, "cols": n, "rho": rho, "parallelism": f"rows{world}", "collective": transport},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": xs_avg_ms, "launches": xs_cnt},
         "setup_seconds": setup_s, "datagen_seconds": t_gen,
         "iters_per_s_without_event_timing": a.steps / dt_graph,
