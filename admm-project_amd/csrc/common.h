@@ -52,7 +52,25 @@ struct Ctrl {
   double restart_flag;     // 1 if the iteration in flight restarted
 };
 
+// Matrices larger than this are streamed with non-temporal loads: they cannot stay in L2 / Infinity
+// Cache between passes anyway, and the streaming hint is worth +13-15 % read bandwidth on MI355X
+// (dev/read_bw.hip: 6.2 -> 7.1 TB/s).  Smaller ones keep normal loads so that they stay cache-resident.
+constexpr int64_t kStreamBytes = int64_t{192} << 20;
+inline bool stream_hint(int64_t bytes) { return bytes > kStreamBytes; }
+
 #ifdef __HIPCC__
+typedef double admm_double2 __attribute__((ext_vector_type(2)));
+// 16-byte matrix load, NT = non-temporal (streaming) hint
+template <bool NT>
+__device__ __forceinline__ admm_double2 load2(const double* p) {
+  const admm_double2* q = reinterpret_cast<const admm_double2*>(p);
+  return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT>
+__device__ __forceinline__ double load1(const double* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
 // ---- wave / block reductions (wave64 shuffles, then LDS across the 4 waves) -------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

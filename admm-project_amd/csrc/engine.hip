@@ -94,7 +94,8 @@ struct admm_engine {
   double* F = nullptr;  // lower Cholesky factor, nF x nF
   int64_t nF = 0, ldF = 0;
   double* dinv = nullptr;
-  double* Minv = nullptr;  // explicit inverse (symmetric, full), ld = ldF
+  double* Minv = nullptr;  // explicit inverse (symmetric, full), ld = ldMinv (tile-padded, zeros outside)
+  int64_t ldMinv = 0;
   TrsvPlan trsv{};
   double* trsv_work = nullptr;
 
@@ -264,20 +265,24 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
     double* X = nullptr;
     ADMM_TRY(e->mem.alloc(&X, static_cast<size_t>(ld) * nF));
     ADMM_TRY(trtri_lower_from_diag(W, nF, ld, e->dinv, X, ld, e->stream));
-    ADMM_TRY(e->mem.alloc(&e->Minv, static_cast<size_t>(ld) * nF));
+    // Minv is stored padded to whole 128x128 tiles (zeros outside nF x nF): symv.hip has no edge path
+    e->planSy = symv_plan(nF);
+    const int64_t ldM = e->planSy.npad;
+    e->ldMinv = ldM;
+    ADMM_TRY(e->mem.alloc(&e->Minv, static_cast<size_t>(ldM) * ldM));
+    ADMM_HIP_TRY(hipMemsetAsync(e->Minv, 0, sizeof(double) * ldM * ldM, e->stream));
     // Minv = X' * X  (lower tiles, then mirrored)
-    launch_gemm(1, 0, nF, nF, nF, 1.0, X, ld, X, ld, 0.0, e->Minv, ld, true, e->stream);
-    launch_symmetrize_lower(e->Minv, nF, ld, e->stream);
+    launch_gemm(1, 0, nF, nF, nF, 1.0, X, ld, X, ld, 0.0, e->Minv, ldM, true, e->stream);
+    launch_symmetrize_lower(e->Minv, nF, ldM, e->stream);
     ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
     // X is no longer needed
     (void)hipFree(X);
     for (auto& p : e->mem.ptrs)
       if (p == X) p = nullptr;
-    e->planSq = gemv_t_plan(nF, nF, ld);
+    e->planSq = gemv_t_plan(nF, nF, ldM);
     ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
     e->sy_half = std::getenv("ADMM_HIP_FULL_SYMV") == nullptr;
     if (e->sy_half) {
-      e->planSy = symv_plan(nF, ld);
       ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
       ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));
     }
@@ -293,7 +298,7 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 // chunk partials in partSq unless `materialize`.
 void solve_factor(admm_engine* e, const double* y, double* out) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
-    launch_symv_lower(e->planSy, e->Minv, y, e->syN, e->syT, out, e->ctrl, e->stream);
+    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream);
   } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
     launch_gemv_t(e->planSq, e->Minv, y, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
     launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldg, e->nF, out, e->ctrl, e->stream);
@@ -847,7 +852,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
     case ADMM_PROB_LASSO:
       if (!e->fat) {
         if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
-          launch_symv_lower(e->planSy, e->Minv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+          launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
         } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
           launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
           *axsrc = e->partSq;
@@ -869,7 +874,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       break;
     case ADMM_PROB_QP_BOUNDED:
       if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
-        launch_symv_lower(e->planSy, e->Minv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+        launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
       } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
         // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
         const GemvTPlan& p = e->planSq;

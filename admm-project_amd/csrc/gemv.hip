@@ -19,7 +19,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 // gemv_n: thread owns a pair of rows, loops over the columns of its chunk.
 //   grid.x = row blocks (512 rows each), grid.y = column chunks.
 // ------------------------------------------------------------------------------------
-template <int UNROLL>
+template <int UNROLL, bool NT>
 __global__ __launch_bounds__(kBlock) void gemv_n_kernel(const double* __restrict__ D, int64_t m, int64_t n,
                                                         int64_t ld, const double* __restrict__ x,
                                                         double* __restrict__ ypart, int64_t ldy,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void gemv_n_kernel(const double* __restrict
     for (; j + UNROLL <= j1; j += UNROLL) {
       double2_t d[UNROLL];
 #pragma unroll
-      for (int k = 0; k < UNROLL; ++k) d[k] = *reinterpret_cast<const double2_t*>(p + k * ld);
+      for (int k = 0; k < UNROLL; ++k) d[k] = load2<NT>(p + k * ld);
 #pragma unroll
       for (int k = 0; k < UNROLL; ++k) {
         const double xj = x[j + k];  // wave-uniform -> scalar load
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void gemv_n_kernel(const double* __restrict
       p += UNROLL * ld;
     }
     for (; j < j1; ++j) {
-      const double2_t d = *reinterpret_cast<const double2_t*>(p);
+      const double2_t d = load2<NT>(p);
       const double xj = x[j];
       acc[0].x = __builtin_fma(d.x, xj, acc[0].x);
       acc[0].y = __builtin_fma(d.y, xj, acc[0].y);
@@ -95,8 +95,12 @@ GemvNPlan gemv_n_plan(int64_t m, int64_t n, int64_t ld) {
 void launch_gemv_n(const GemvNPlan& p, const double* D, const double* x, double* ypart, const Ctrl* ctrl,
                    hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(ceil_div(ceil_div(p.m, 2), kBlock)), static_cast<unsigned>(p.nchunk));
-  hipLaunchKernelGGL(gemv_n_kernel<8>, grid, dim3(kBlock), 0, stream, D, p.m, p.n, p.ld, x, ypart, p.ldy,
-                     p.cols_per_chunk, ctrl);
+  if (stream_hint(8 * p.m * p.n))
+    hipLaunchKernelGGL((gemv_n_kernel<8, true>), grid, dim3(kBlock), 0, stream, D, p.m, p.n, p.ld, x, ypart, p.ldy,
+                       p.cols_per_chunk, ctrl);
+  else
+    hipLaunchKernelGGL((gemv_n_kernel<8, false>), grid, dim3(kBlock), 0, stream, D, p.m, p.n, p.ld, x, ypart, p.ldy,
+                       p.cols_per_chunk, ctrl);
 }
 
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __restrict__ part, int32_t nchunk,
@@ -129,7 +133,7 @@ void launch_sum_partials(const double* part, int32_t nchunk, int64_t ld, int64_t
 constexpr int kTCols = 32;  // columns per block
 constexpr int kTColsPerWavePass = 4;
 
-template <int NRHS>
+template <int NRHS, bool NT>
 __global__ __launch_bounds__(kBlock) void gemv_t_kernel(const double* __restrict__ D, int64_t m, int64_t n,
                                                         int64_t ld, const double* __restrict__ v0,
                                                         const double* __restrict__ v1,
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(const double* __restrict
       for (int k = 0; k < U; ++k)
 #pragma unroll
         for (int c = 0; c < kTColsPerWavePass; ++c)
-          d[k][c] = *reinterpret_cast<const double2_t*>(col[c] + 2 * (p + 64 * k));
+          d[k][c] = load2<NT>(col[c] + 2 * (p + 64 * k));
 #pragma unroll
       for (int k = 0; k < U; ++k) {
 #pragma unroll
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void gemv_t_kernel(const double* __restrict
         const double2_t vv = *reinterpret_cast<const double2_t*>(&sV[r * rows_per_chunk + 2 * p]);
 #pragma unroll
         for (int c = 0; c < kTColsPerWavePass; ++c) {
-          const double2_t dd = *reinterpret_cast<const double2_t*>(col[c] + 2 * p);
+          const double2_t dd = load2<NT>(col[c] + 2 * p);
           acc[c][r] = __builtin_fma(dd.x, vv.x, acc[c][r]);
           acc[c][r] = __builtin_fma(dd.y, vv.y, acc[c][r]);
         }
@@ -244,20 +248,25 @@ void launch_gemv_t(const GemvTPlan& p, const double* D, const double* v0, const 
                    int nrhs, double* gpart, const Ctrl* ctrl, hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(ceil_div(p.n, kTCols)), static_cast<unsigned>(p.nchunk));
   const size_t lds = static_cast<size_t>(nrhs) * p.rows_per_chunk * sizeof(double);
+  const bool nt = stream_hint(8 * p.m * p.n);
+#define ADMM_LAUNCH_GEMV_T(NR, NTV)                                                                                 \
+  hipLaunchKernelGGL((gemv_t_kernel<NR, NTV>), grid, dim3(kBlock), lds, stream, D, p.m, p.n, p.ld, v0, v1, v2, gpart, \
+                     p.ldg, p.rows_per_chunk, ctrl)
   switch (nrhs) {
     case 1:
-      hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(kBlock), lds, stream, D, p.m, p.n, p.ld, v0, v1, v2, gpart,
-                         p.ldg, p.rows_per_chunk, ctrl);
+      if (nt) ADMM_LAUNCH_GEMV_T(1, true);
+      else ADMM_LAUNCH_GEMV_T(1, false);
       break;
     case 2:
-      hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(kBlock), lds, stream, D, p.m, p.n, p.ld, v0, v1, v2, gpart,
-                         p.ldg, p.rows_per_chunk, ctrl);
+      if (nt) ADMM_LAUNCH_GEMV_T(2, true);
+      else ADMM_LAUNCH_GEMV_T(2, false);
       break;
     default:
-      hipLaunchKernelGGL(gemv_t_kernel<3>, grid, dim3(kBlock), lds, stream, D, p.m, p.n, p.ld, v0, v1, v2, gpart,
-                         p.ldg, p.rows_per_chunk, ctrl);
+      if (nt) ADMM_LAUNCH_GEMV_T(3, true);
+      else ADMM_LAUNCH_GEMV_T(3, false);
       break;
   }
+#undef ADMM_LAUNCH_GEMV_T
 }
 
 __global__ __launch_bounds__(kBlock) void sum_partials_t_kernel(const double* __restrict__ gpart, int32_t nchunk,

@@ -37,17 +37,17 @@ void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, do
                            const Ctrl* ctrl, hipStream_t stream);
 
 // y = M*x for symmetric M from its lower triangle only (half the bytes of a full GEMV).
+// M must be stored npad x npad (npad = round_up(n,128), ld >= npad) with zeros outside n x n.
 struct SymvPlan {
-  int64_t n, ld;
-  int64_t ldp;    // row stride of the partial arrays
-  int32_t nrow;   // 512-row chunks  -> tpart is [nrow][ldp]
-  int32_t ncol;   // 128-column groups -> npart is [ncol][ldp]
-  size_t npart_elems() const { return static_cast<size_t>(ncol) * ldp; }
-  size_t tpart_elems() const { return static_cast<size_t>(nrow) * ldp; }
+  int64_t n, npad;
+  int64_t ldp;     // row stride of the partial arrays (= npad)
+  int32_t ntile;   // 128-row wave chunks = 128-column groups: npart and tpart are [ntile][ldp]
+  size_t npart_elems() const { return static_cast<size_t>(ntile) * ldp; }
+  size_t tpart_elems() const { return static_cast<size_t>(ntile) * ldp; }
 };
-SymvPlan symv_plan(int64_t n, int64_t ld);
-void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
-                       const Ctrl* ctrl, hipStream_t stream);
+SymvPlan symv_plan(int64_t n);
+void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
+                       double* y, const Ctrl* ctrl, hipStream_t stream);
 
 // ---------------------------------------------------------------- dense setup (dense.hip)
 // C = alpha*op(A)*op(B) + beta*C, column-major fp64 on the MFMA f64 path.  transA/transB: 0 = N, 1 = T.

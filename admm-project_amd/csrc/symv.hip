@@ -4,92 +4,92 @@
 // Every element M[r,j] (r >= j) is loaded once and used twice:
 //   N-part  yN[r] += M[r,j]*x[j]        register accumulation per row (like gemv_n)
 //   T-part  yT[j] += M[r,j]*x[r], r > j per-column sums over the rows (like gemv_t)
-// A WAVE is the unit of work (one-wave workgroups: 128 rows x 128 columns, 16-byte loads, lane
-// owns a row pair), so the triangular tile set load-balances finely and nothing synchronises.
-// The T-part column sums of an 8-column panel are combined inside the wave by a 10-shuffle
-// reduce-scatter; the loads of the NEXT panel are issued before that reduction (two register
-// buffers, hand-pipelined), so the memory pipe never drains while a wave shuffles.
+// A WAVE is the unit of work (one-wave workgroups on 128x128 tiles, 16-byte loads, lane owns a row
+// pair), so the triangular tile set load-balances finely and nothing synchronises.  The storage is
+// padded to whole tiles with zeros (SymvPlan::npad), so the hot loop has no edge handling at all.
+// The T-part column sums of a 4-column panel are combined inside the wave WITHOUT the LDS crossbar:
+// two gfx950 v_permlane{32,16}_swap exchange steps (a reduce-scatter over lane bits 5 and 4) and a
+// DPP butterfly inside each 16-lane row -- measured 25 us cheaper per 400 MB pass than the
+// ds_bpermute (__shfl_xor) form, which was the limiter (dev/symv_bench.hip).  The next panel's
+// loads are issued before the reduction of the current one.
 // Partials (npart per 128-column group, tpart per 128-row wave chunk) are added by a second small
 // kernel in a fixed order: bitwise reproducible, no float atomics.
-#include <cstdlib>
-
 #include "kernels.h"
 
 namespace admm {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-constexpr int kSyWaveRows = 128;  // rows per wave = per workgroup (64 lanes x 2)
-constexpr int kSyCols = 128;      // columns per workgroup
-constexpr int kSyPanel = 8;       // columns per panel = loads per buffer = T-part accumulators
+constexpr int kSyTile = 128;  // rows per wave (64 lanes x 2) = columns per tile
+constexpr int kSyPanel = 4;   // columns per panel = loads per buffer = T-part accumulators
 
-// reduce-scatter of 8 per-lane values over the 64 lanes of a wave: on return every lane holds the
-// wave-wide sum of element *col (its lane bits 5..3 select the column); 7 + 3 shuffles.
-__device__ __forceinline__ double reduce_scatter8(const double (&t)[kSyPanel], int lane, int* col) {
-  double a4[4], a2[2];
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double keep = b5 ? t[k + 4] : t[k];
-    const double send = b5 ? t[k] : t[k + 4];
-    a4[k] = keep + __shfl_xor(send, 32, 64);
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const double keep = b4 ? a4[k + 2] : a4[k];
-    const double send = b4 ? a4[k] : a4[k + 2];
-    a2[k] = keep + __shfl_xor(send, 16, 64);
-  }
-  const double keep = b3 ? a2[1] : a2[0];
-  const double send = b3 ? a2[0] : a2[1];
-  double r = keep + __shfl_xor(send, 8, 64);
-  r += __shfl_xor(r, 4, 64);
-  r += __shfl_xor(r, 2, 64);
-  r += __shfl_xor(r, 1, 64);
-  *col = (b5 ? 4 : 0) + (b4 ? 2 : 0) + (b3 ? 1 : 0);
+// a.upper32 <-> b.lower32: afterwards a + b holds, in the lower 32 lanes, the 2-way sum of the old
+// a and, in the upper 32 lanes, the 2-way sum of the old b.
+__device__ __forceinline__ void swap_half(double& a, double& b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  a = __hiloint2double(r1[0], r0[0]);
+  b = __hiloint2double(r1[1], r0[1]);
+}
+// odd 16-lane rows of a <-> even rows of b: same idea one level down
+__device__ __forceinline__ void swap_row(double& a, double& b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  a = __hiloint2double(r1[0], r0[0]);
+  b = __hiloint2double(r1[1], r0[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// reduce-scatter of 4 per-lane values over the 64 lanes: every lane returns the wave-wide sum of
+// element (lane >> 4)  [lane bit 5 -> +2, bit 4 -> +1].
+__device__ __forceinline__ double reduce_scatter4(double (&t)[kSyPanel]) {
+  swap_half(t[0], t[2]);
+  swap_half(t[1], t[3]);
+  t[0] += t[2];
+  t[1] += t[3];
+  swap_row(t[0], t[1]);
+  double r = t[0] + t[1];
+  r += dpp_mov<0x128>(r);  // row_ror:8
+  r += dpp_mov<0x124>(r);  // row_ror:4
+  r += dpp_mov<0x4E>(r);   // quad_perm [2,3,0,1]
+  r += dpp_mov<0xB1>(r);   // quad_perm [1,0,3,2]
   return r;
 }
 
 struct SyLane {  // per-lane constants of a tile
   const double* M;
   const double* x;
-  int64_t ld, r, cend;
-  int r32;  // r as a 32-bit element offset from the wave-uniform column base
-  bool live0, live1;
+  int64_t ld, n;
+  int r;  // this lane's row pair (r, r+1), also its element offset from a column base
   double xr0, xr1;
 };
 
-// FAST: every row of the wave and every column of the panel is inside the matrix -> no guards at
-// all on the hot path (straight-line loads).  DIAG: the tile intersects the diagonal -> mask.
-template <bool FAST>
+template <bool NT>
 __device__ __forceinline__ void sy_load(const SyLane& s, int64_t cp, double2_t (&d)[kSyPanel]) {
 #pragma unroll
-  for (int k = 0; k < kSyPanel; ++k) {
-    const int64_t j = cp + k;
-    const double* cb = s.M + j * s.ld;  // wave-uniform column base
-    if (FAST) {
-      d[k] = *reinterpret_cast<const double2_t*>(cb + s.r32);
-    } else {
-      d[k] = double2_t{0.0, 0.0};
-      if (j < s.cend) {
-        if (s.live1) d[k] = *reinterpret_cast<const double2_t*>(cb + s.r32);
-        else if (s.live0) d[k].x = cb[s.r32];
-      }
-    }
-  }
+  for (int k = 0; k < kSyPanel; ++k) d[k] = load2<NT>(s.M + (cp + k) * s.ld + s.r);  // wave-uniform column base
 }
 
-template <bool FAST, bool DIAG>
+// DIAG: the tile intersects the diagonal -> mask element-wise (N-part j <= row, T-part row > j)
+template <bool DIAG>
 __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const double2_t (&d)[kSyPanel], double& n0,
                                            double& n1, double* __restrict__ tout, int lane) {
   double tacc[kSyPanel];
 #pragma unroll
   for (int k = 0; k < kSyPanel; ++k) {
     const int64_t j = cp + k;
-    const double xj = (FAST || j < s.cend) ? s.x[j] : 0.0;  // wave-uniform -> scalar load
+    const double xj = s.x[j < s.n ? j : s.n - 1];  // wave-uniform -> scalar load; padding columns are 0
     double a0 = d[k].x, a1 = d[k].y;
     double t0 = a0, t1 = a1;
-    if (DIAG) {  // lower triangle only: N-part j <= row, T-part row > j
+    if (DIAG) {
       t0 = (s.r > j) ? a0 : 0.0;
       t1 = (s.r + 1 > j) ? a1 : 0.0;
       a0 = (j <= s.r) ? a0 : 0.0;
@@ -99,123 +99,101 @@ __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const do
     n0 = __builtin_fma(a0, xj, n0);
     n1 = __builtin_fma(a1, xj, n1);
   }
-  int col;
-  const double sum = reduce_scatter8(tacc, lane, &col);
-  if ((lane & 7) == 0 && (FAST || cp + col < s.cend)) tout[cp + col] = sum;
+  const double sum = reduce_scatter4(tacc);
+  if ((lane & 15) == 0) tout[cp + (lane >> 4)] = sum;
 }
 
-// the panels [c0, limit) of one tile, next panel's loads issued before this panel's reduction
-template <bool FAST, bool DIAG>
-__device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, int64_t limit, double& n0, double& n1,
+// the 32 panels of one tile, next panel's loads issued before this panel's reduction
+template <bool DIAG, bool NT>
+__device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, double& n0, double& n1,
                                         double* __restrict__ tout, int lane) {
   double2_t bufA[kSyPanel], bufB[kSyPanel];
-  int64_t cp = c0;
-  sy_load<FAST>(s, cp, bufA);
+  sy_load<NT>(s, c0, bufA);
 #pragma unroll 1
-  for (;;) {
-    const bool haveB = cp + kSyPanel < limit;
-    if (haveB) sy_load<FAST>(s, cp + kSyPanel, bufB);
-    sy_compute<FAST, DIAG>(s, cp, bufA, n0, n1, tout, lane);
-    if (!haveB) break;
-    const bool haveA = cp + 2 * kSyPanel < limit;
-    if (haveA) sy_load<FAST>(s, cp + 2 * kSyPanel, bufA);
-    sy_compute<FAST, DIAG>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
-    if (!haveA) break;
-    cp += 2 * kSyPanel;
+  for (int64_t cp = c0; cp < c0 + kSyTile; cp += 2 * kSyPanel) {
+    sy_load<NT>(s, cp + kSyPanel, bufB);
+    sy_compute<DIAG>(s, cp, bufA, n0, n1, tout, lane);
+    if (cp + 2 * kSyPanel < c0 + kSyTile) sy_load<NT>(s, cp + 2 * kSyPanel, bufA);
+    sy_compute<DIAG>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
   }
 }
 
+// M: npad x npad (npad = round_up(n, 128)) with ld >= npad, zero outside n x n; x: n elements.
+template <bool NT>
 __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
                                                            const double* __restrict__ x, double* __restrict__ npart,
                                                            double* __restrict__ tpart, int64_t ldp,
                                                            const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
+  if (blockIdx.x < blockIdx.y) return;  // tile strictly above the diagonal
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyWaveRows;  // wave's first row
-  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyCols;
-  if (w0 >= n || w0 + kSyWaveRows - 1 < c0) return;  // nothing of the lower triangle in this tile
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyTile;  // wave's first row
+  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyTile;
   SyLane s;
   s.M = M;
   s.x = x;
   s.ld = ld;
-  s.r = w0 + 2 * lane;  // this lane's row pair (r, r+1)
-  s.r32 = static_cast<int>(s.r);
-  s.live0 = s.r < n;
-  s.live1 = s.r + 1 < n;
-  s.xr0 = s.live0 ? x[s.r] : 0.0;
-  s.xr1 = s.live1 ? x[s.r + 1] : 0.0;
-  s.cend = (c0 + kSyCols < n) ? c0 + kSyCols : n;
-  const bool diag = w0 < c0 + kSyCols;  // tile intersects the diagonal: mask element-wise
-  // panels at or beyond this column lie strictly above the diagonal for every row of the wave
-  const int64_t limit = (s.cend < w0 + kSyWaveRows) ? s.cend : w0 + kSyWaveRows;
-  const bool fast = (w0 + kSyWaveRows <= n) && ((limit - c0) % kSyPanel == 0);
+  s.n = n;
+  s.r = static_cast<int>(w0) + 2 * lane;
+  s.xr0 = x[s.r < n ? s.r : n - 1];  // rows >= n multiply zero padding
+  s.xr1 = x[s.r + 1 < n ? s.r + 1 : n - 1];
   double* __restrict__ tout = tpart + static_cast<int64_t>(blockIdx.x) * ldp;
   double n0 = 0.0, n1 = 0.0;
-  if (fast) {
-    if (diag) sy_tile<true, true>(s, c0, limit, n0, n1, tout, lane);
-    else sy_tile<true, false>(s, c0, limit, n0, n1, tout, lane);
-  } else {
-    // ragged edge tiles (last row chunk / last column group): one buffer, no pipelining -- keeps the
-    // register budget of the kernel set by the fast path.  Masking is harmless off the diagonal.
-    double2_t buf[kSyPanel];
-#pragma unroll 1
-    for (int64_t cp = c0; cp < limit; cp += kSyPanel) {
-      sy_load<false>(s, cp, buf);
-      sy_compute<false, true>(s, cp, buf, n0, n1, tout, lane);
-    }
-  }
-  if (s.live1) *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
-  else if (s.live0) npart[static_cast<int64_t>(blockIdx.y) * ldp + s.r] = n0;
+  if (blockIdx.x == blockIdx.y) sy_tile<true, NT>(s, c0, n0, n1, tout, lane);
+  else sy_tile<false, NT>(s, c0, n0, n1, tout, lane);
+  *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
 }
 
-// y[i] = sum_g npart[g][i] + sum_w tpart[w][i] over the partials that exist for element i.
-// Workgroup = 64 consecutive elements; lanes run along i (coalesced 512-byte rows), the 4 waves
-// split the partial rows and are combined through LDS in a fixed order.
+// y[i] = sum_{g <= d} npart[g][i] + sum_{w >= d} tpart[w][i],  d = i / 128 (i's diagonal tile).
+// Workgroup = 16 consecutive elements x 16 slots that split the T+1 partial rows; the slots are
+// combined through LDS in a fixed order.
 __global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __restrict__ npart,
                                                              const double* __restrict__ tpart, int64_t ldp,
-                                                             int64_t n, int32_t nwave, double* __restrict__ y,
+                                                             int64_t n, int32_t ntile, double* __restrict__ y,
                                                              const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
-  __shared__ double sacc[4][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+  __shared__ double sacc[16][17];
+  const int ii = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + ii;
   double s = 0.0;
   if (i < n) {
-    // N partials: column groups g whose tile exists for i's wave chunk: g*kSyCols <= w0 + 127
-    const int64_t w0 = (i / kSyWaveRows) * kSyWaveRows;
-    const int32_t gmax = static_cast<int32_t>((w0 + kSyWaveRows - 1) / kSyCols);
-    const int32_t glast = static_cast<int32_t>((n - 1) / kSyCols);
-    const int32_t gend = gmax < glast ? gmax : glast;
-    for (int32_t g = wid; g <= gend; g += 4) s += npart[static_cast<int64_t>(g) * ldp + i];
-    // T partials: wave chunks w that processed the panel containing column i: w*128 + 127 >= panel start
-    const int32_t wmin = static_cast<int32_t>(((i / kSyPanel) * kSyPanel) / kSyWaveRows);
-    for (int32_t w = wmin + wid; w < nwave; w += 4) s += tpart[static_cast<int64_t>(w) * ldp + i];
+    const int32_t d = static_cast<int32_t>(i / kSyTile);
+    // unified partial index p in [0, ntile]: p <= d -> npart[p], else tpart[p - 1]
+#pragma unroll 4
+    for (int32_t p = slot; p <= ntile; p += 16) {
+      const double* src = (p <= d) ? npart + static_cast<int64_t>(p) * ldp : tpart + static_cast<int64_t>(p - 1) * ldp;
+      s += src[i];
+    }
   }
-  sacc[wid][lane] = s;
+  sacc[slot][ii] = s;
   __syncthreads();
-  if (wid == 0 && i < n) y[i] = ((sacc[0][lane] + sacc[1][lane]) + sacc[2][lane]) + sacc[3][lane];
+  if (slot == 0 && i < n) {
+    double t = sacc[0][ii];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sacc[k][ii];
+    y[i] = t;
+  }
 }
 
-SymvPlan symv_plan(int64_t n, int64_t ld) {
+SymvPlan symv_plan(int64_t n) {
   SymvPlan p{};
   p.n = n;
-  p.ld = ld;
-  p.ldp = round_up(n, 2);
-  p.nrow = static_cast<int32_t>(ceil_div(n, kSyWaveRows));  // tpart rows (wave chunks)
-  p.ncol = static_cast<int32_t>(ceil_div(n, kSyCols));      // npart rows (column groups)
+  p.npad = round_up(n, kSyTile);
+  p.ldp = p.npad;
+  p.ntile = static_cast<int32_t>(p.npad / kSyTile);
   return p;
 }
 
-void launch_symv_lower(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart, double* y,
-                       const Ctrl* ctrl, hipStream_t stream) {
-  dim3 grid(static_cast<unsigned>(p.nrow), static_cast<unsigned>(p.ncol));
-  // Measured at n = 10^4 (MI355X): 104-114 us for the 400 MB lower triangle at 8-12 resident waves per
-  // CU, flat in occupancy (an LDS-padding sweep moved it by < 4 %) -> ~3.7 TB/s; with the 8 us reduce
-  // the x-solve takes 122 us against 141 us for the full 800 MB column-dot GEMV.
-  hipLaunchKernelGGL(symv_lower_kernel, grid, dim3(kWave), 0, stream, M, p.n, p.ld, x, npart, tpart, p.ldp, ctrl);
-  const int64_t blocks = ceil_div(p.n, 64);
+void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
+                       double* y, const Ctrl* ctrl, hipStream_t stream) {
+  dim3 grid(static_cast<unsigned>(p.ntile), static_cast<unsigned>(p.ntile));
+  if (stream_hint(4 * p.npad * p.npad))
+    hipLaunchKernelGGL(symv_lower_kernel<true>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp, ctrl);
+  else
+    hipLaunchKernelGGL(symv_lower_kernel<false>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp, ctrl);
+  const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
-                     p.ldp, p.n, p.nrow, y, ctrl);
+                     p.ldp, p.n, p.ntile, y, ctrl);
 }
 
 }  // namespace admm
