@@ -1,0 +1,103 @@
+// gemv_real.hip -- developer microbenchmark: the PRODUCT gemv kernels (gemv.hip included verbatim) under
+// different plans, against the pure-read ceiling measured by gemv_pattern.hip.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o gemv_real gemv_real.hip && ./gemv_real [m] [n]
+#include "../gemv.hip"
+
+#include <cstdlib>
+#include <vector>
+
+namespace admm {
+void set_error(const std::string&) {}
+int fail(int code, const std::string&) { return code; }
+}  // namespace admm
+
+using namespace admm;
+
+#define CK(e)                                                                   \
+  do {                                                                          \
+    hipError_t _e = (e);                                                        \
+    if (_e != hipSuccess) {                                                     \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      exit(1);                                                                  \
+    }                                                                           \
+  } while (0)
+
+static hipEvent_t e0, e1;
+
+template <typename F>
+void timeit(const char* name, F launch, double bytes) {
+  for (int i = 0; i < 2; ++i) launch();
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("%-64s %8.3f ms  %6.3f TB/s\n", name, ms / reps, bytes / (ms / reps) * 1e-9);
+  fflush(stdout);
+}
+
+template <int U>
+void run_n(const double* D, int64_t m, int64_t n, int64_t ld, const double* x, double* ypart, int chunks) {
+  GemvNPlan p = gemv_n_plan(m, n, ld);
+  p.cols_per_chunk = ceil_div(n, chunks);
+  p.nchunk = static_cast<int32_t>(ceil_div(n, p.cols_per_chunk));
+  dim3 grid(static_cast<unsigned>(ceil_div(ceil_div(p.m, 2), kBlock)), static_cast<unsigned>(p.nchunk));
+  char name[128];
+  snprintf(name, sizeof name, "gemv_n U=%2d chunks=%3d cols/chunk=%4lld grid=%u", U, p.nchunk, (long long)p.cols_per_chunk,
+           grid.x * grid.y);
+  timeit(name,
+         [&] {
+           hipLaunchKernelGGL((gemv_n_kernel<U, true>), grid, dim3(kBlock), 0, 0, D, p.m, p.n, p.ld, x, ypart, p.ldy,
+                              p.cols_per_chunk, nullptr);
+         },
+         8.0 * m * n);
+}
+
+template <int NR>
+void run_t(const double* D, int64_t m, int64_t n, int64_t ld, const double* v, double* gpart, int rc) {
+  GemvTPlan p = gemv_t_plan(m, n, ld);
+  p.rows_per_chunk = rc;
+  p.nchunk = static_cast<int32_t>(ceil_div(m, rc));
+  dim3 grid(static_cast<unsigned>(ceil_div(p.n, kTCols)), static_cast<unsigned>(p.nchunk));
+  const size_t lds = static_cast<size_t>(NR) * p.rows_per_chunk * sizeof(double);
+  char name[128];
+  snprintf(name, sizeof name, "gemv_t nrhs=%d rows/chunk=%5d chunks=%3d grid=%u lds=%zu", NR, rc, p.nchunk, grid.x * grid.y, lds);
+  timeit(name,
+         [&] {
+           hipLaunchKernelGGL((gemv_t_kernel<NR, true>), grid, dim3(kBlock), lds, 0, D, p.m, p.n, p.ld, v, v + m, v + 2 * m,
+                              gpart, p.ldg, p.rows_per_chunk, nullptr);
+         },
+         8.0 * m * n);
+}
+
+int main(int argc, char** argv) {
+  const int64_t m = argc > 1 ? atoll(argv[1]) : 100000;
+  const int64_t n = argc > 2 ? atoll(argv[2]) : 10000;
+  const int64_t ld = argc > 3 ? atoll(argv[3]) : round_up(m, 16);
+  double *D, *x, *ypart, *v, *gpart;
+  CK(hipMalloc(&D, sizeof(double) * ld * n));
+  CK(hipMalloc(&x, sizeof(double) * n));
+  CK(hipMalloc(&v, sizeof(double) * 3 * m));
+  CK(hipMalloc(&ypart, sizeof(double) * round_up(m, 2) * 256));
+  CK(hipMalloc(&gpart, sizeof(double) * round_up(n, 2) * 3 * 512));
+  CK(hipMemset(D, 0, sizeof(double) * ld * n));
+  CK(hipMemset(x, 0, sizeof(double) * n));
+  CK(hipMemset(v, 0, sizeof(double) * 3 * m));
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  printf("m=%lld n=%lld ld=%lld  %.2f GB\n", (long long)m, (long long)n, (long long)ld, 8.0 * m * n * 1e-9);
+  {
+    GemvNPlan p = gemv_n_plan(m, n, ld);
+    printf("default gemv_n plan: chunks=%d cols/chunk=%lld\n", p.nchunk, (long long)p.cols_per_chunk);
+    GemvTPlan q = gemv_t_plan(m, n, ld);
+    printf("default gemv_t plan: rows/chunk=%d chunks=%d\n", q.rows_per_chunk, q.nchunk);
+  }
+  for (int chunks : {8, 16, 21, 32}) run_n<8>(D, m, n, ld, x, ypart, chunks);
+  for (int rc : {2048, 4096}) run_t<1>(D, m, n, ld, v, gpart, rc);
+  for (int rc : {1024, 2048}) run_t<3>(D, m, n, ld, v, gpart, rc);
+  return 0;
+}

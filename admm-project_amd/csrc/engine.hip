@@ -164,7 +164,9 @@ int upload(DevMem& mem, double** dst, const double* src, size_t elems, int memki
 // copy a column-major m x n matrix into a zero-padded device buffer with leading dimension ld
 int upload_matrix(DevMem& mem, double** dst, int64_t* ld_out, const double* src, int64_t rows, int64_t cols,
                   int64_t ld_src, int memkind, hipStream_t stream) {
-  const int64_t ld = round_up(rows, 16);
+  // 128-byte aligned columns always; 4 KiB aligned columns for tall matrices: measured +5 % on the
+  // gemv_n stream (dev/gemv_real.hip, ld 100000 vs 98304) for 0.35 % more memory
+  const int64_t ld = rows >= 8192 ? round_up(rows, 512) : round_up(rows, 16);
   ADMM_TRY(mem.alloc(dst, static_cast<size_t>(ld) * cols));
   if (ld != rows) ADMM_HIP_TRY(hipMemsetAsync(*dst, 0, sizeof(double) * ld * cols, stream));
   ADMM_HIP_TRY(hipMemcpy2DAsync(*dst, ld * sizeof(double), src, ld_src * sizeof(double), rows * sizeof(double), cols,
