@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # error codes
 OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
@@ -19,6 +19,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -
 # problem kinds
 PROB_LASSO, PROB_LASSO_CONSENSUS, PROB_LAD, PROB_HUBERFIT = 1, 2, 3, 4
 PROB_LINEARSVM, PROB_TOTALVARIATION, PROB_QP_BOUNDED, PROB_BASISPURSUIT = 5, 6, 7, 8
+PROB_MODEL = 9
 LOSS_HINGE, LOSS_01 = 0, 1
 XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -48,7 +49,14 @@ class ProblemDesc(C.Structure):
         ("slices", C.POINTER(C.c_int64)),
         ("comm", C.c_void_p),
         ("cg_tol", C.c_double), ("cg_maxit", C.c_int32), ("reserved0", C.c_int32),
+        ("Q", _dp), ("qz", _dp), ("D2", _dp), ("m2", C.c_int64), ("ldD2", C.c_int64), ("s2", _dp), ("c", _dp),
     ]
+
+
+# caller-supplied prox operators / objective (device pointers as integers; see admm_engine.h)
+PROX_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                            C.c_int64, C.c_void_p)
+OBJ_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 
 class Options(C.Structure):
@@ -85,6 +93,8 @@ _SIGNATURES = {
     "admm_options_default": (None, [C.POINTER(Options)]),
     "admm_problem_desc_default": (None, [C.POINTER(ProblemDesc)]),
     "admm_engine_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    "admm_engine_set_callbacks": (C.c_int, [C.c_void_p, PROX_CALLBACK, C.c_void_p, PROX_CALLBACK, C.c_void_p,
+                                            OBJ_CALLBACK, C.c_void_p]),
     "admm_engine_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary)]),
     "admm_engine_fetch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "admm_engine_setup_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
@@ -116,6 +126,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AdmmError(E_DEVICE, f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                                   f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if os.environ.get("ADMM_HIP_NO_TORCH") != "1":
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  Whichever runtime is loaded first owns
+        # the GPU: if ours (/opt/rocm) came first, torch would later report "No HIP GPUs are available" and
+        # RCCL sharing / device-tensor prox callbacks could not work.  Importing torch first makes
+        # libadmm_hip.so bind to the runtime already in the process (same soname).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

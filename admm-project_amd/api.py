@@ -7,7 +7,11 @@
 x-/z-update and share one device-resident problem (data + cached factor).  When ``admm``
 receives a matching pair it runs the whole loop (admm.m:496-743) on the device through
 the C ABI.  ``options`` and ``results`` are dicts with the reference's field names.
-There is no CPU fallback: user-supplied Python callables are rejected loudly.
+Caller-supplied prox handles (the reference's plain function handles, as in
+examples/convergencechecking.m) are supported for A = 1, B = -1: they are called with
+zero-copy CUDA tensors of the engine's state on the engine's HIP stream and must return
+CUDA tensors; the rest of the iteration stays in the fused kernels.  There is no CPU
+fallback: a handle that returns a host array is rejected loudly.
 """
 from __future__ import annotations
 
@@ -152,6 +156,18 @@ def getproxops(problem, args):
         n = P.shape[0]
         eng = Engine(L.PROB_BASISPURSUIT, P=P, q=q, device=dev)
         prob = _Problem("basispursuit", eng, dict(A=1, c=0.0, nA=n, nB=n))
+    elif kind == "model":
+        # getProxOps.m:83-89: the Gram data; engine-side extension: args.P/Q/r/s (the matrices
+        # themselves) let the device evaluate model.m:133-134's objective when objevals is set
+        PtP, Ptr = _get(args, "PtP"), _get(args, "Ptr")
+        QtQ, Qts = _get(args, "QtQ"), _get(args, "Qts")
+        n = int(args.get("n", np.asarray(PtP).shape[0]))
+        objdata = {}
+        if all(k in args for k in ("P", "Q", "r", "s")):
+            objdata = dict(D=args["P"], s=args["r"], D2=args["Q"], s2=args["s"])
+        eng = Engine(L.PROB_MODEL, P=PtP, q=Ptr, Q=QtQ, qz=Qts, nvec=n, rho=float(args.get("rho", 1.0)),
+                     xsolve=xs, device=dev, **objdata)
+        prob = _Problem("model", eng, dict(A=1, c=0.0, nA=n, nB=n))
     else:
         raise NotImplementedError(f"problem '{kind}' is outside the engine's hot-path scope (SURVEY.md section 8)")
     return ProxOp(prob, "x"), ProxOp(prob, "z"), extra
@@ -199,19 +215,68 @@ def _check_constraint(options, prob):
             raise ValueError(f"options.{key} does not match the problem size")
 
 
+_CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "basispursuit")  # A = 1 problems
+
+
+def _generic_problem(options):
+    """Both prox operators are the caller's handles: the state, the u-update, residuals, histories
+    and stop logic of admm.m:496-743 still run on the device; only A = 1, B = -1 (the shorthand
+    examples/convergencechecking.m:110-115 uses) is engine-native."""
+    A, B = options.get("A"), options.get("B")
+    if A is None:
+        raise ValueError("Must specify a matrix A in constraint Ax + Bz = c!")
+    if B is None:
+        raise ValueError("Must specify a matrix B in constraint Ax + Bz = c!")
+    if not (np.isscalar(A) and float(A) == 1.0 and np.isscalar(B) and float(B) == -1.0):
+        raise NotImplementedError("caller-supplied prox handles run with A = 1, B = -1; general constraint "
+                                  "matrices are only engine-native through the library's own problems")
+    c = options.get("c", 0.0)
+    n = int(options.get("nA", 0) or options.get("nB", 0) or options.get("m", 0))
+    cvec = None
+    if not np.isscalar(c):
+        cvec = np.asarray(c, dtype=np.float64).reshape(-1)
+        n = n or cvec.size
+        if cvec.size != n:
+            raise ValueError("Given vector c does not match the problem size")
+    elif float(c) != 0.0:
+        raise NotImplementedError("scalar non-zero c is not supported")
+    if n <= 0:
+        raise ValueError("Given vector c is scalar and no length m has been provided")
+    eng = Engine(L.PROB_MODEL, nvec=n, c=cvec, rho=float(_setopt(options, "rho", 1.0)),
+                 device=int(options.get("device", 0)))
+    return _Problem("generic", eng, dict(A=1, c=0.0, nA=n, nB=n))
+
+
 def admm(xminf, zming, options):
     """Run ADMM on the device (admm.m:24).  See the module docstring."""
     if not isinstance(options, dict):
         raise TypeError("Given options is not a struct! At least pass empty struct!")
-    if not (isinstance(xminf, ProxOp) and isinstance(zming, ProxOp)):
-        raise NotImplementedError(
-            "admm() on MI355X needs engine-native proximal operators from getproxops(); arbitrary "
-            "host callables would require a CPU loop, which this package deliberately lacks")
-    if xminf.problem is not zming.problem or xminf.role != "x" or zming.role != "z":
-        raise ValueError("xminf/zming must be the (minx, minz) pair returned by one getproxops call")
-    prob = xminf.problem
+    x_lib, z_lib = isinstance(xminf, ProxOp), isinstance(zming, ProxOp)
+    for f, name in ((xminf, "xminf"), (zming, "zming")):
+        if not (isinstance(f, ProxOp) or callable(f)):
+            raise TypeError(f"Given {name} is not a function handle!")  # admm.m:33-45
+    if x_lib and z_lib:
+        if xminf.problem is not zming.problem or xminf.role != "x" or zming.role != "z":
+            raise ValueError("xminf/zming must be the (minx, minz) pair returned by one getproxops call")
+        prob = xminf.problem
+    elif x_lib or z_lib:
+        # one library operator + one caller-supplied handle (examples/convergencechecking.m:125-136)
+        op = xminf if x_lib else zming
+        if op.role != ("x" if x_lib else "z"):
+            raise ValueError("a library proximal operator was passed in the wrong slot")
+        prob = op.problem
+        if prob.kind not in _CALLBACK_KINDS:
+            raise NotImplementedError(f"caller-supplied prox handles cannot be mixed with the '{prob.kind}' operators "
+                                      "(supported: " + ", ".join(_CALLBACK_KINDS) + ")")
+    else:
+        prob = _generic_problem(options)  # both handles are the caller's: admm.m:24 as is (A = 1, B = -1)
     eng = prob.engine
     _check_constraint(options, prob)
+    user_obj = options.get("obj") if callable(options.get("obj")) else None
+    if user_obj is not None and prob.kind not in _CALLBACK_KINDS + ("generic",):
+        user_obj = None  # the solver-supplied objective of this problem is engine-native (objevals switch)
+    callbacks = dict(xmin=None if x_lib else xminf, zmin=None if z_lib else zming, obj=user_obj)
+    use_callbacks = any(v is not None for v in callbacks.values())
     for hook in ("altu", "specialnorms", "preprocess"):
         h = options.get(hook)
         if h is None:
@@ -251,15 +316,21 @@ def admm(xminf, zming, options):
         if v0 is not None and np.asarray(v0).size != ln:
             raise ValueError(f"options.{name} has the wrong length")
 
-    summ = eng.run(rho=rho, maxiters=N, domaxiters=_setopt(options, "domaxiters", 0),
-                   relax=_setopt(options, "relax", 1), fast=alg, objevals=objevals, convtest=convtest,
-                   convtol=_setopt(options, "convtol", 1e-10),
-                   stopcond=stopcond,
-                   nodualerror=_setopt(options, "nodualerror", 0), abstol=_setopt(options, "abstol", 1e-5),
-                   reltol=_setopt(options, "reltol", 1e-3), Hnormtol=_setopt(options, "Hnormtol", 1e-6),
-                   restart=_setopt(options, "restart", 0.999), dvaltol=_setopt(options, "dvaltol", 1e-8),
-                   record_history=record_history, check_every=int(options.get("check_every", 0)),
-                   x0=x0, z0=z0, u0=u0)
+    if use_callbacks:
+        eng.set_callbacks(**callbacks)
+    try:
+        summ = eng.run(rho=rho, maxiters=N, domaxiters=_setopt(options, "domaxiters", 0),
+                       relax=_setopt(options, "relax", 1), fast=alg, objevals=objevals, convtest=convtest,
+                       convtol=_setopt(options, "convtol", 1e-10),
+                       stopcond=stopcond,
+                       nodualerror=_setopt(options, "nodualerror", 0), abstol=_setopt(options, "abstol", 1e-5),
+                       reltol=_setopt(options, "reltol", 1e-3), Hnormtol=_setopt(options, "Hnormtol", 1e-6),
+                       restart=_setopt(options, "restart", 0.999), dvaltol=_setopt(options, "dvaltol", 1e-8),
+                       record_history=record_history, check_every=int(options.get("check_every", 0)),
+                       x0=x0, z0=z0, u0=u0)
+    finally:
+        if use_callbacks:
+            eng.set_callbacks()  # the library operators are the engine's default again
     steps = int(summ.steps)
     results = {}
     results["x0"] = np.zeros(nA) if x0 is None else np.array(x0, dtype=np.float64).reshape(-1)

@@ -131,6 +131,20 @@ struct admm_engine {
   double *cX = nullptr, *cU = nullptr, *csums = nullptr, *czc = nullptr, *cxave = nullptr, *cxaveprev = nullptr,
          *cubar = nullptr, *cy = nullptr, *cobjpart = nullptr;
   int64_t cldn = 0;
+  // model problem (getProxOps.m:60-95) and caller-supplied prox operators: split z-update (PROX_GIVEN)
+  SliceFactor zfac{};        // cached factor of QtQ + rho*I (zminModel, getProxOps.m:1005-1012)
+  bool has_xfac = true;      // an engine-native x-update exists (false: model created without PtP)
+  bool has_zfac = false;
+  double* qz = nullptr;      // Qts
+  double *xext = nullptr, *zext = nullptr, *xh = nullptr, *rz = nullptr;
+  double* D2 = nullptr;      // the matrix Q of the model objective (model.m:134)
+  int64_t ldD2 = 0, m2 = 0;
+  double* s2 = nullptr;
+  GemvNPlan planD2N{};
+  double* partD2N = nullptr;
+  admm_prox_callback xcb = nullptr, zcb = nullptr;
+  admm_obj_callback ocb = nullptr;
+  void *xuser = nullptr, *zuser = nullptr, *ouser = nullptr;
   double* part = nullptr;     // [S_COUNT][kMaxPartBlocks]
   double* objpart = nullptr;  // [kMaxPartBlocks]
   Ctrl* ctrl = nullptr;
@@ -623,6 +637,63 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->xsolve = ADMM_XSOLVE_INVERSE;  // x = P*(z-u) + q is a GEMV by construction
       break;
     }
+    case ADMM_PROB_MODEL: {
+      // model.m:111-128 + getProxOps.m:83-95: x - z = c with quadratic f and g given by their Gram data.
+      // Either half may be left out (NULL): it must then be supplied by admm_engine_set_callbacks.
+      if (n <= 0) return bail(fail(ADMM_E_INVALID, "the model / generic problem needs n (args.n, getProxOps.m:89)"));
+      if ((desc->P != nullptr) != (desc->q != nullptr) || (desc->Q != nullptr) != (desc->qz != nullptr))
+        return bail(fail(ADMM_E_INVALID, "model: PtP comes with Ptr and QtQ with Qts (getProxOps.m:83-88)"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_GIVEN;
+      e->rhs_kind = RHS_RHO_DTS;  // y = rho*(z-u) + Ptr   (getProxOps.m:978)
+      if (xs == ADMM_XSOLVE_CG) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg needs a data matrix"));
+      if (desc->c) {
+        E_TRY(upload(e->mem, &e->s, desc->c, n, mk, e->stream));
+        e->c = e->s;
+      }
+      e->has_xfac = desc->P != nullptr;
+      if (desc->P) {
+        E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+        e->rhs_add = e->q;
+        double* W = nullptr;
+        int64_t ld = 0;
+        E_TRY(upload_matrix(e->mem, &W, &ld, desc->P, n, n, n, mk, e->stream));
+        launch_add_diag(W, n, ld, desc->rho, e->stream);  // getProxOps.m:972-975
+        E_TRY(factorize(e, W, n, ld, nullptr, mk));
+      } else {
+        e->rhs_kind = RHS_NONE;
+      }
+      if (desc->Q) {
+        E_TRY(upload(e->mem, &e->qz, desc->qz, n, mk, e->stream));
+        double* W = nullptr;
+        int64_t ld = 0;
+        E_TRY(upload_matrix(e->mem, &W, &ld, desc->Q, n, n, n, mk, e->stream));
+        launch_add_diag(W, n, ld, desc->rho, e->stream);  // getProxOps.m:1005-1008
+        E_TRY(build_slice_factor(e, e->zfac, W, n, ld));
+        e->has_zfac = true;
+      }
+      // optional: the matrices of the objective 1/2||P*x-r||^2 + 1/2||Q*z-s||^2 (model.m:133-134)
+      if (desc->D && desc->s && desc->D2 && desc->s2 && m > 0 && desc->m2 > 0) {
+        E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+        E_TRY(upload(e->mem, &e->ell, desc->s, m, mk, e->stream));  // r (kept apart from the constraint vector)
+        e->planDN = gemv_n_plan(m, n, e->ldD);
+        E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
+        e->m2 = desc->m2;
+        E_TRY(upload_matrix(e->mem, &e->D2, &e->ldD2, desc->D2, e->m2, n, desc->ldD2 ? desc->ldD2 : e->m2, mk,
+                            e->stream));
+        E_TRY(upload(e->mem, &e->s2, desc->s2, e->m2, mk, e->stream));
+        e->planD2N = gemv_n_plan(e->m2, n, e->ldD2);
+        E_TRY(e->mem.alloc(&e->partD2N, e->planD2N.part_elems()));
+      }
+      const int64_t n2 = round_up(n, 2);
+      E_TRY(e->mem.alloc(&e->xext, n2));
+      E_TRY(e->mem.alloc(&e->zext, n2));
+      E_TRY(e->mem.alloc(&e->xh, n2));
+      E_TRY(e->mem.alloc(&e->rz, n2));
+      break;
+    }
     case ADMM_PROB_TOTALVARIATION: {
       // totalvariation.m:122-157: s is the (column) signal, D = spdiags([1 -1],0:1,n,n) is implicit
       const int64_t nn = n > 0 ? n : m;
@@ -748,7 +819,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   e->tv_zA = e->z;
   e->tv_uA = e->u;
   E_TRY(e->mem.alloc(&e->part, static_cast<size_t>(S_COUNT) * kMaxPartBlocks));
-  E_TRY(e->mem.alloc(&e->objpart, kMaxPartBlocks));
+  E_TRY(e->mem.alloc(&e->objpart, 2 * kMaxPartBlocks));  // the model objective has two residual terms
   {
     double* cd = nullptr;
     E_TRY(e->mem.alloc(&cd, (sizeof(Ctrl) + 7) / 8));
@@ -843,26 +914,27 @@ static int cg_solve(admm_engine* e, const double* y) {
   return ADMM_OK;
 }
 
+static void factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld);
+
 // one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
 static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   *axsrc = e->x;
   *naxpart = 1;
   *axld = 0;
+  if (e->xcb) {  // x = xminf(x, z, u, rho), fast ADMM: xminf(x, v, uhat, rho)   (admm.m:502, 506)
+    const bool fastalg = e->last_opts.fast != ADMM_FAST_OFF;
+    if (e->xcb(e->xuser, e->x, fastalg ? e->v : e->z, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
+               static_cast<void*>(e->stream)) != 0)
+      return fail(ADMM_E_INVALID, "the xminf callback reported a failure");
+    *axsrc = e->xext;  // the fused kernel stores it into x (guarded by the device stop flag)
+    return ADMM_OK;
+  }
   if (e->xsolve == ADMM_XSOLVE_CG) return cg_solve(e, e->a_identity ? e->rhs : e->g);
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
-        if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
-          launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
-        } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
-          launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
-          *axsrc = e->partSq;
-          *naxpart = e->planSq.nchunk;
-          *axld = e->planSq.ldg;
-        } else {
-          launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
-        }
+        factor_x_update(e, axsrc, naxpart, axld);
       } else {
         // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
         launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
@@ -874,19 +946,9 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
                        e->x, e->n, e->ctrl, e->stream);
       }
       break;
-    case ADMM_PROB_QP_BOUNDED:
-      if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
-        launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
-      } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-        // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
-        const GemvTPlan& p = e->planSq;
-        launch_gemv_t(p, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
-        *axsrc = e->partSq;
-        *naxpart = p.nchunk;
-        *axld = p.ldg;
-      } else {
-        launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
-      }
+    case ADMM_PROB_QP_BOUNDED:  // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
+    case ADMM_PROB_MODEL:
+      factor_x_update(e, axsrc, naxpart, axld);
       break;
     case ADMM_PROB_BASISPURSUIT:
       launch_gemv_t(e->planSq, e->Pmat, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
@@ -897,6 +959,44 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       solve_factor(e, e->g, e->x);
       break;
   }
+  return ADMM_OK;
+}
+
+// the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
+static void factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+  if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
+    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
+    launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+    *axsrc = e->partSq;
+    *naxpart = e->planSq.nchunk;
+    *axld = e->planSq.ldg;
+  } else {
+    launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
+  }
+}
+
+int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
+                              void* zuser, admm_obj_callback obj, void* objuser) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  if ((xmin || zmin || obj) &&
+      !(e->problem == ADMM_PROB_MODEL || e->problem == ADMM_PROB_QP_BOUNDED || e->problem == ADMM_PROB_BASISPURSUIT ||
+        (e->problem == ADMM_PROB_LASSO && !e->fat && e->xsolve != ADMM_XSOLVE_CG)))
+    return fail(ADMM_E_UNSUPPORTED,
+                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, bounded QP, basis pursuit)");
+  if ((xmin || zmin || obj) && e->comm && comm_nranks(e->comm) > 1)
+    return fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines");
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  const int64_t n2 = round_up(e->len, 2);
+  if (!e->xext) ADMM_TRY(e->mem.alloc(&e->xext, n2));
+  if (!e->zext) ADMM_TRY(e->mem.alloc(&e->zext, n2));
+  if (!e->xh) ADMM_TRY(e->mem.alloc(&e->xh, n2));
+  e->xcb = xmin;
+  e->xuser = xuser;
+  e->zcb = zmin;
+  e->zuser = zuser;
+  e->ocb = obj;
+  e->ouser = objuser;
   return ADMM_OK;
 }
 
@@ -911,7 +1011,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   if (o.restart <= 0.0 || o.restart >= 1.0) o.restart = 0.999;  // admm.m:285-287
   if (o.fast != ADMM_FAST_OFF && o.fast != ADMM_FAST_WEAK && o.fast != ADMM_FAST_STRONG)
     return fail(ADMM_E_INVALID, "bad options.fast");
-  if (o.rho != e->rho_factor && e->F && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
+  if (o.rho != e->rho_factor && (e->F || e->has_zfac) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
       e->problem != ADMM_PROB_LINEARSVM)
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)
@@ -921,6 +1021,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
                 "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");
   if (o.relax != 1.0 && (e->problem == ADMM_PROB_LAD || e->problem == ADMM_PROB_HUBERFIT)) {
     // lad.m:124-126 switches to the userelax closures, which take Axhat directly: same fused formula
+  }
+  if (e->problem == ADMM_PROB_MODEL) {
+    if (!e->has_xfac && !e->xcb)
+      return fail(ADMM_E_INVALID, "no x-update: the model was created without PtP/Ptr and no xminf callback is set");
+    if (!e->has_zfac && !e->zcb)
+      return fail(ADMM_E_INVALID, "no z-update: the model was created without QtQ/Qts and no zming callback is set");
   }
   e->last_opts = o;
   const int alg = o.fast;  // 0, 1 (strong), 2 (weak)
@@ -982,8 +1088,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   fa.obj_scale_part = 0.0;
   pa.objz = OBJZ_NONE;
   pa.objx = OBJX_NONE;
-  bool obj_lasso_gemv = false, obj_qp_gemv = false;
-  if (o.objevals) {
+  bool obj_lasso_gemv = false, obj_qp_gemv = false, obj_model_gemv = false;
+  if (o.objevals && e->ocb) {  // options.obj is the caller's handle (admm.m:603-605)
+    fa.obj_scale_part = 1.0;
+  } else if (o.objevals) {
     switch (e->problem) {
       case ADMM_PROB_LASSO:
         obj_lasso_gemv = true;
@@ -1013,6 +1121,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         pa.objx = OBJX_ABS;
         fa.obj_scale_x = 1.0;
         break;
+      case ADMM_PROB_MODEL:  // 1/2||P*x - r||^2 + 1/2||Q*z - s||^2   (model.m:133-134)
+        if (!e->D || !e->D2)
+          return fail(ADMM_E_INVALID, "objevals on the model problem needs the matrices P, Q and vectors r, s "
+                                      "(or an objective callback)");
+        obj_model_gemv = true;
+        fa.obj_scale_part = 0.5;
+        break;
       default:
         break;
     }
@@ -1041,8 +1156,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   pa.part = e->part;
   pa.rho = o.rho;
   pa.relax = o.relax;
-  pa.prox = e->prox;
-  pa.rhs_kind = e->rhs_kind;
+  const bool split_z = e->zcb != nullptr || e->problem == ADMM_PROB_MODEL;  // z is computed between two kernels
+  pa.prox = split_z ? PROX_GIVEN : e->prox;
+  pa.zgiven = e->zext;
+  pa.rhs_kind = e->xcb ? RHS_NONE : e->rhs_kind;
   pa.alg = alg;
   pa.a_identity = e->a_identity ? 1 : 0;
   switch (e->prox) {
@@ -1110,7 +1227,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   xa.vhist = e->vhist;
   xa.uhathist = e->uhathist;
   xa.rho = o.rho;
-  xa.rhs_kind = e->rhs_kind;
+  xa.rhs_kind = e->xcb ? RHS_NONE : e->rhs_kind;
 
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS) {
     if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for consensus lasso");
@@ -1383,7 +1500,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   const bool profiler_attached = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
                                  (preload && std::strstr(preload, "rocprof") != nullptr);
   const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG && !profiler_attached &&
-                         heavy <= (int64_t{32} << 20) && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr;
+                         heavy <= (int64_t{32} << 20) && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr &&
+                         !e->xcb && !e->zcb && !e->ocb;  // host callbacks cannot be captured
   auto enqueue_iteration = [&]() -> int {
     {
       const double* axsrc;
@@ -1398,6 +1516,29 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         axld = e->planDN.ldy;
       }
       int nblk = 1;
+      if (split_z) {  // z = zming(x or Axhat, z, u or uhat, rho) between the two halves of the fused kernel
+        TimerScope ts(e, ADMM_K_PROX);
+        PreZArgs za{};
+        za.len = len;
+        za.axsrc = axsrc;
+        za.naxpart = naxpart;
+        za.axld = axld;
+        za.c = e->c;
+        za.z = e->z;
+        za.uo = (alg == 0) ? e->u : e->uhat;
+        za.add = e->qz;
+        za.xh = e->xh;
+        za.rz = e->zcb ? nullptr : e->rz;
+        za.rho = o.rho;
+        za.relax = o.relax;
+        launch_prez(za, e->ctrl, e->stream);
+        if (e->zcb) {
+          if (e->zcb(e->zuser, e->xh, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
+            return fail(ADMM_E_INVALID, "the zming callback reported a failure");
+        } else {  // zminModel: (QtQ + rho I) \ (Qts + rho*(x + u))   getProxOps.m:1012
+          apply_slice_factor(e, e->zfac, e->rz, e->zext);
+        }
+      }
       {
         TimerScope ts(e, ADMM_K_PROX);
         pa.axsrc = axsrc;
@@ -1453,6 +1594,22 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 1, e->stream));
           fa.objp_reduced = e->red + 16;
         }
+      } else if (o.objevals && e->ocb) {  // objevals(i) = obj(x, z) with the caller's handle (admm.m:604)
+        if (e->ocb(e->ouser, e->x, nA, e->z, len, e->objpart, static_cast<void*>(e->stream)) != 0)
+          return fail(ADMM_E_INVALID, "the objective callback reported a failure");
+        fa.objpart = e->objpart;
+        fa.nobjpart = 1;
+      } else if (obj_model_gemv) {
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob1 = 0, nob2 = 0;
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        launch_residual_sq(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->ell, e->m, e->objpart, &nob1, e->ctrl,
+                           e->stream);
+        launch_gemv_n(e->planD2N, e->D2, e->z, e->partD2N, e->ctrl, e->stream);
+        launch_residual_sq(e->partD2N, e->planD2N.nchunk, e->planD2N.ldy, e->s2, e->m2, e->objpart + nob1, &nob2,
+                           e->ctrl, e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob1 + nob2;
       } else if (obj_qp_gemv) {  // 1/2 x'Px + q'x + r  (quadraticprogram.m:242)
         int nob = 0;
         const GemvTPlan& p = e->planSq;  // P is symmetric

@@ -10,7 +10,9 @@ enum ProxKind : int32_t {
   PROX_HUBER = 1,  // (rho*v + soft(v, 1+1/rho))/(1+rho)               1529-1539
   PROX_HINGE = 2,  // v + ell.*max(min(1-ell.*v, C/rho),0)             1084-1096
   PROX_01 = 3,     // ell.*minz01(ell.*v, rho/C)                       1100, 1158-1180
-  PROX_BOX = 4     // min(ub,max(lb,v))                                1470-1474
+  PROX_BOX = 4,    // min(ub,max(lb,v))                                1470-1474
+  PROX_GIVEN = 5   // z was computed outside the fused kernel (a linear solve: zminModel 990-1013,
+                   // or a caller-supplied zming callback) and is read from ProxArgs::zgiven
 };
 
 // what the NEXT x-update's right-hand side is, written by the prox/extrapolation kernel
@@ -54,6 +56,7 @@ struct ProxArgs {
   const double* ell;
   const double* lb;
   const double* ub;
+  const double* zgiven;    // PROX_GIVEN: the new z
   double* z;
   double* u;
   double* uhat;            // fast only
@@ -133,6 +136,23 @@ struct FinArgs {
   Ctrl* ctrl;
 };
 
+// First half of a split z-update (PROX_GIVEN): what the z-prox is called with (admm.m:515-530).
+//   xh  = Axhat = relax*Ax - (1-relax)*(B zprev - c)   (= Ax when relax == 1)
+//   rz  = add + rho*((xh + uo) - c)                    right-hand side of zminModel (getProxOps.m:1012)
+struct PreZArgs {
+  int64_t len;
+  const double* axsrc;  // Ax partials, as ProxArgs
+  int32_t naxpart;
+  int64_t axld;
+  const double* c;
+  const double* z;      // z_prev
+  const double* uo;     // u (alg 0) or uhat
+  const double* add;    // nullable
+  double* xh;
+  double* rz;           // nullable
+  double rho, relax;
+};
+void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 void launch_fast_decide(const FinArgs& a, hipStream_t stream);   // alg 2: d, restart decision, alpha
 void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream);

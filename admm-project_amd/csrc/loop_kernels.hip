@@ -89,6 +89,9 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
         zn = l * y;
         break;
       }
+      case PROX_GIVEN:
+        zn = a.zgiven[i];
+        break;
       default:  // PROX_BOX
         zn = fmin(a.ub[i], fmax(a.lb[i], v));
         break;
@@ -154,6 +157,28 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
     }
   }
   block_reduce_slots(acc, a.part);
+}
+
+__global__ __launch_bounds__(kBlock) void prez_kernel(PreZArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double ax = 0.0;
+    for (int32_t cidx = 0; cidx < a.naxpart; ++cidx) ax += a.axsrc[static_cast<int64_t>(cidx) * a.axld + i];
+    const double zp = a.z[i];
+    const double ci = a.c ? a.c[i] : 0.0;
+    // same expression as prox_kernel, so the split update is bit-identical to the fused one
+    const double axh = (a.relax != 1.0) ? a.relax * ax - (1.0 - a.relax) * ((-zp) - ci) : ax;
+    a.xh[i] = axh;
+    if (a.rz) a.rz[i] = (a.add ? a.add[i] : 0.0) + a.rho * ((axh + a.uo[i]) - ci);
+  }
+}
+
+void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(prez_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
 }
 
 void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {

@@ -19,7 +19,8 @@ class Engine:
 
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
-                 device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None):
+                 device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
+                 Q=None, qz=None, D2=None, s2=None, c=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -47,8 +48,25 @@ class Engine:
             if D is None:
                 d.m = Pm.shape[0]
             d.P = L.as_dp(Pm)
-        if nvec is not None:  # problems without a data matrix (total variation): vector length
-            d.m = d.n = int(nvec)
+        if nvec is not None:  # problems without a data matrix (total variation, generic admm): vector length
+            if D is None:
+                d.m = int(nvec)
+            d.n = int(nvec)
+        if Q is not None:  # model problem: QtQ, Qts and the optional objective data (getProxOps.m:83-89)
+            Qm = _f64(Q)
+            keep.append(Qm)
+            d.Q = L.as_dp(Qm)
+        if qz is not None:
+            d.qz = vec(qz)
+        if D2 is not None:
+            D2m = _f64(D2)
+            keep.append(D2m)
+            d.D2 = L.as_dp(D2m)
+            d.m2, d.ldD2 = D2m.shape[0], D2m.shape[0]
+        if s2 is not None:
+            d.s2 = vec(s2)
+        if c is not None:
+            d.c = vec(c)
         if s is not None:
             d.s = vec(s)
         if ell is not None:
@@ -90,7 +108,82 @@ class Engine:
         self._lib = lib
         self.problem = problem
         self.m, self.n = int(d.m), int(d.n)
+        self.device = int(d.device)
+        self._cb_keep = None
+        self._cb_error = None
         del keep
+
+    # ------------------------------------------------------------------ caller-supplied prox operators
+    def set_callbacks(self, xmin=None, zmin=None, obj=None):
+        """Replace the x-/z-update (and the objective hook) by Python callables working on DEVICE
+        tensors: ``xmin(x, z, u, rho)``, ``zmin(xh, z, u, rho)`` return a float64 CUDA tensor,
+        ``obj(x, z)`` a scalar (tensor or float).  The arguments are zero-copy torch views of the
+        engine's state; the calls run on the engine's HIP stream (admm_engine.h: admm_prox_callback).
+        ``None`` keeps / restores the engine-native operator."""
+        if xmin is None and zmin is None and obj is None:
+            L.check(self._lib.admm_engine_set_callbacks(self._h, C.cast(None, L.PROX_CALLBACK), None,
+                                                        C.cast(None, L.PROX_CALLBACK), None,
+                                                        C.cast(None, L.OBJ_CALLBACK), None))
+            self._cb_keep = None
+            return
+        import torch  # device memory / stream plumbing only
+
+        dev = torch.device("cuda", self.device)
+        n = self.n
+
+        class _View:  # __cuda_array_interface__ carrier: torch.as_tensor makes a zero-copy tensor of it
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                                 "version": 2}
+
+        def view(ptr, count):
+            return torch.as_tensor(_View(ptr, count), device=dev)
+
+        def as_result(val, count, what):
+            if not (isinstance(val, torch.Tensor) and val.is_cuda):
+                raise TypeError(f"{what} must return a CUDA tensor: host arrays would need a CPU path, "
+                                "which this package does not have")
+            if val.numel() != count:
+                raise ValueError(f"{what} returned {val.numel()} elements, expected {count}")
+            return val.to(torch.float64).reshape(-1)
+
+        def wrap_prox(fn, what):
+            if fn is None:
+                return C.cast(None, L.PROX_CALLBACK)
+
+            def cb(_user, x, z, u, rho, out, nout, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        res = fn(view(x, n), view(z, n), view(u, n), float(rho))
+                        view(out, nout).copy_(as_result(res, nout, what))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
+                    self._cb_error = exc
+                    return 1
+
+            return L.PROX_CALLBACK(cb)
+
+        def wrap_obj(fn):
+            if fn is None:
+                return C.cast(None, L.OBJ_CALLBACK)
+
+            def cb(_user, x, nA, z, nB, out, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        val = fn(view(x, nA), view(z, nB))
+                        if not isinstance(val, torch.Tensor):
+                            val = torch.tensor(float(val), dtype=torch.float64, device=dev)
+                        view(out, 1).copy_(val.to(device=dev, dtype=torch.float64).reshape(1))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001
+                    self._cb_error = exc
+                    return 1
+
+            return L.OBJ_CALLBACK(cb)
+
+        keep = (wrap_prox(xmin, "xminf"), wrap_prox(zmin, "zming"), wrap_obj(obj))
+        L.check(self._lib.admm_engine_set_callbacks(self._h, keep[0], None, keep[1], None, keep[2], None))
+        self._cb_keep = keep  # the C side holds raw pointers to these thunks
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -151,7 +244,12 @@ class Engine:
                 keep.append(a)
                 setattr(o, name, L.as_dp(a))
         s = L.RunSummary()
-        L.check(self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s)))
+        self._cb_error = None
+        rc = self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s))
+        if rc != L.OK and self._cb_error is not None:  # a Python prox callback raised: surface ITS exception
+            exc, self._cb_error = self._cb_error, None
+            raise exc
+        L.check(rc)
         self.last = s
         return s
 

@@ -16,7 +16,7 @@ from .api import admm, getproxops
 from .errorcheck import is_nonnegative_real, is_positive_real, slicemaker
 
 __all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit",
-           "totalvariation"]
+           "totalvariation", "model"]
 
 _ENGINE_OBJ = "<engine-native objective>"
 
@@ -270,3 +270,36 @@ class _ShapeOnly:
 
     def __init__(self, shape):
         self.shape = shape
+
+
+def model(P, Q, r, s, options=None):
+    """results = model(P, Q, r, s, options)   (solvers/model.m:47-143)
+
+    minimise 1/2*||P*x - r||_2^2 + 1/2*||Q*z - s||_2^2 subject to x - z = 0.  The host forms the
+    Gram data exactly as model.m:111-121 does and passes it to ``getproxops('model', args)``; the
+    matrices themselves travel along (engine-side extension) so that the device can evaluate the
+    objective of model.m:133-134 when ``objevals`` is set.
+    """
+    if options is None:
+        options = {}
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    P = _matrix(P, "P")
+    Q = _matrix(Q, "Q")
+    r = _colvec(r, "r")
+    s = _colvec(s, "s")
+    if P.shape[1] != Q.shape[1]:
+        raise ValueError("Matrices P and Q must have the same number of columns!")
+    if r.size != P.shape[0] or s.size != Q.shape[0]:
+        raise ValueError("Vectors r and s must match the rows of P and Q!")
+    n = P.shape[1]
+    rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
+    args = dict(PtP=P.T @ P, Ptr=P.T @ r, QtQ=Q.T @ Q, Qts=Q.T @ s, n=n, rho=rho, P=P, Q=Q, r=r, s=s)
+    minx, minz, _ = getproxops("Model", _engine_args(options, args))
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)  # model.m:124-130
+    options["obj"] = _ENGINE_OBJ
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADMM_ABI_VERSION 1
+#define ADMM_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -44,7 +44,10 @@ enum {
   ADMM_PROB_LINEARSVM = 5,        /* getProxOps.m:202-310, 1062-1180 */
   ADMM_PROB_TOTALVARIATION = 6,   /* getProxOps.m:145-199, 1044-1048 */
   ADMM_PROB_QP_BOUNDED = 7,       /* getProxOps.m:631-641, 1441-1474 */
-  ADMM_PROB_BASISPURSUIT = 8      /* getProxOps.m:98-142, 1027-1032 */
+  ADMM_PROB_BASISPURSUIT = 8,     /* getProxOps.m:98-142, 1027-1032 */
+  ADMM_PROB_MODEL = 9             /* getProxOps.m:60-95, x: 952-979, z: 990-1013 (model.m); with both prox
+                                     callbacks set and no data it is the generic admm(xminf, zming, options)
+                                     of admm.m:24 for A = 1, B = -1 */
 };
 
 /* linear-SVM loss (getProxOps.m:1094: anything but '01' runs the hinge prox) */
@@ -69,6 +72,22 @@ enum { ADMM_STOP_STANDARD = 0, ADMM_STOP_HNORM = 1, ADMM_STOP_BOTH = 2,
 enum { ADMM_FAST_OFF = 0, ADMM_FAST_WEAK = 2 /* accelerated, alg 2 */, ADMM_FAST_STRONG = 1 /* alg 1 */ };
 
 typedef struct admm_engine admm_engine; /* opaque */
+
+/*
+ * Caller-supplied proximal operators: the `xminf` / `zming` function handles of admm.m:24 when they are
+ * NOT the library's own (examples/convergencechecking.m:125-136 mixes both kinds).  All pointers are
+ * DEVICE pointers into the engine's state; the callback enqueues its work on `hip_stream` (a hipStream_t)
+ * or synchronises before returning, and writes its result to `out` (never aliased with an input).
+ *   xmin: out[nA] = xminf(x[nA], z[nB], u[nB], rho)   admm.m:502 (fast ADMM passes v, uhat: 506)
+ *   zmin: out[nB] = zming(xh[nB], z[nB], u[nB], rho)  admm.m:521-530; xh is x, A*x or the relaxed Axhat
+ *   obj : *out    = obj(x[nA], z[nB])                 admm.m:603-605
+ * A non-zero return aborts the run with ADMM_E_INVALID.  Speculatively enqueued iterations after a stop
+ * condition still invoke the callbacks; their outputs are discarded on the device.
+ */
+typedef int (*admm_prox_callback)(void* user, const double* x, const double* z, const double* u, double rho,
+                                  double* out, int64_t nout, void* hip_stream);
+typedef int (*admm_obj_callback)(void* user, const double* x, int64_t nA, const double* z, int64_t nB, double* out,
+                                 void* hip_stream);
 typedef struct admm_comm admm_comm;     /* opaque RCCL communicator wrapper */
 
 /*
@@ -106,6 +125,15 @@ typedef struct admm_problem_desc {
   double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
   int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
   int32_t reserved0;
+  /* ADMM_PROB_MODEL (getProxOps.m:83-89): P = args.PtP, q = args.Ptr above; and */
+  const double* Q;     /* n x n: args.QtQ */
+  const double* qz;    /* length n: args.Qts */
+  /* optional data of the model objective 1/2||P*x - r||^2 + 1/2||Q*z - s||^2 (model.m:133-134):
+   * D = P (m x n), s = r above; and */
+  const double* D2;    /* m2 x n: the matrix Q */
+  int64_t m2, ldD2;
+  const double* s2;    /* length m2: the vector s */
+  const double* c;     /* optional constraint vector (length n) of x - z = c; NULL = 0 (model.m:127) */
 } admm_problem_desc;
 
 /* POD mirror of the `options` struct read by admm.m:51-76 (defaults: setopt, 780-971). */
@@ -171,6 +199,11 @@ int admm_device_info(int device, char* name, size_t cap, int64_t* hbm_bytes, int
 void admm_options_default(admm_options* opts);
 void admm_problem_desc_default(admm_problem_desc* desc);
 int admm_engine_create(const admm_problem_desc* desc, admm_engine** out);
+/* replace the x- and/or z-update (and the objective hook) of an A = 1 problem (lasso, bounded QP,
+ * basis pursuit, model) by caller-supplied callbacks; NULL keeps the engine-native operator.
+ * ADMM_PROB_MODEL created without Gram data REQUIRES the corresponding callback. */
+int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
+                              void* zuser, admm_obj_callback obj, void* objuser);
 int admm_engine_run(admm_engine* eng, const admm_options* opts, admm_run_summary* summary);
 int admm_engine_fetch(admm_engine* eng, int field, double* dst, size_t cap, size_t* written);
 /* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */

@@ -38,7 +38,7 @@ def test_struct_sizes_and_defaults(ap):
     d = ap._lib.ProblemDesc()
     lib.admm_problem_desc_default(C.byref(d))
     assert d.struct_size == C.sizeof(ap._lib.ProblemDesc)
-    assert lib.admm_abi_version() == 1
+    assert lib.admm_abi_version() == 2
 
 
 def test_enum_values_match_header(ap):
@@ -79,11 +79,16 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"#include\s*[<\"][^>\"]*oracle", src), f
 
 
-def test_admm_rejects_host_callables(ap):
-    with pytest.raises(NotImplementedError):
+def test_admm_handle_validation(ap):
+    # caller-supplied handles need a device (they run on CUDA tensors): on a CPU box the engine fails loudly
+    with pytest.raises(ap.AdmmError, match="no HIP device"):
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=-1, c=0, m=4, nA=4, nB=4))
+    with pytest.raises(NotImplementedError, match="A = 1, B = -1"):
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=np.eye(4), B=-1, c=0, m=4, nA=4, nB=4))
     with pytest.raises(TypeError):
         ap.admm(None, None, "not a struct")
+    with pytest.raises(TypeError, match="not a function handle"):
+        ap.admm(3, lambda x, z, u, r: z, {})
 
 
 def test_getproxops_argument_errors(ap):

@@ -1,0 +1,190 @@
+"""GPU parity of the model problem (model.m, getProxOps.m:60-95) and of admm() driven by the CALLER's
+prox handles (examples/convergencechecking.m:125-136): the handles run as torch closures on the device,
+everything else in the fused kernels; the oracle runs the same closures in NumPy."""
+import numpy as np
+import pytest
+
+from oracle import admm_ref as A
+from oracle import proxops_ref as PR
+from oracle import solvers_ref as S
+from tests.test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def _model_data(ap, seed, rows, cols):
+    p = ap.synth.model_problem(seed, rows, cols)
+    return p["P"], p["Q"], p["r"], p["s"]
+
+
+# ---------------------------------------------------------------------------- model problem, engine-native
+@pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
+@pytest.mark.parametrize("opts", [
+    dict(), dict(objevals=1), dict(relax=1.5, objevals=1), dict(fast=1, fasttype="strong", maxiters=60),
+    dict(fast=1, fasttype="weak", maxiters=60, objevals=1), dict(convtest=1, stopcond="both", maxiters=300),
+    dict(rho=3.0, objevals=1), dict(stopcond="hnorm", maxiters=80), dict(domaxiters=1, maxiters=25),
+])
+def test_model_parity(gpu, opts, xsolve):
+    P, Q, r, s = _model_data(gpu, 0, 128, 128)  # modeltest.m default size
+    got = gpu.model(P, Q, r, s, dict(opts, xsolve=xsolve))
+    ref = S.model(P, Q, r, s, dict(opts))
+    _compare(got, ref, tol=TOL)
+    if opts.get("objevals"):
+        assert got["objopt"] == pytest.approx(ref["objopt"], rel=1e-8)
+
+
+@pytest.mark.parametrize("rows,cols,seed", [(200, 200, 1), (300, 90, 2), (70, 130, 3)])
+def test_model_shapes(gpu, rows, cols, seed):
+    P, Q, r, s = _model_data(gpu, seed, rows, cols)
+    o = dict(objevals=1, maxiters=150)
+    _compare(gpu.model(P, Q, r, s, o), S.model(P, Q, r, s, o), tol=TOL)
+
+
+def test_model_closed_form(gpu):  # modeltest.m:122, 149-157: the reference's own pass criterion
+    P, Q, r, s = _model_data(gpu, 0, 128, 128)
+    res = gpu.model(P, Q, r, s, dict(objevals=1, maxiters=10000, convtest=1, stopcond="both", record_history=0))
+    xt = np.linalg.solve(P.T @ P + Q.T @ Q, P.T @ r + Q.T @ s)
+    obj = lambda x: 0.5 * np.sum((P @ x - r) ** 2) + 0.5 * np.sum((Q @ x - s) ** 2)
+    assert abs(1 - obj(res["xopt"]) / obj(xt)) <= 1e-3
+    assert np.linalg.norm(xt - res["xopt"]) <= 1e-3
+
+
+def test_model_objective_needs_matrices(gpu):
+    P, Q, r, s = _model_data(gpu, 0, 64, 64)
+    args = dict(PtP=P.T @ P, Ptr=P.T @ r, QtQ=Q.T @ Q, Qts=Q.T @ s, n=64)
+    minx, minz, _ = gpu.getproxops("model", args)
+    o = dict(A=1, B=-1, c=0, m=64, nA=64, nB=64, maxiters=20)
+    res = gpu.admm(minx, minz, o)  # without objevals the Gram data is all that is needed
+    assert res["steps"] >= 1
+    with pytest.raises(gpu.AdmmError, match="objevals on the model problem needs"):
+        gpu.admm(minx, minz, dict(o, objevals=1))
+
+
+# ---------------------------------------------------------------------------- caller-supplied handles
+def _torch_model_closures(P, Q, r, s, broken_x=False, broken_z=False):
+    """convergencechecking.m:169-215 as device closures (torch) and as host closures (NumPy)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = P.shape[1]
+    PtP, Ptr, QtQ, Qts = P.T @ P, P.T @ r, Q.T @ Q, Q.T @ s
+    tPtP, tPtr = torch.tensor(PtP, device=dev), torch.tensor(Ptr, device=dev)
+    tQtQ, tQts = torch.tensor(QtQ, device=dev), torch.tensor(Qts, device=dev)
+    eye = torch.eye(n, dtype=torch.float64, device=dev)
+    sx = 1.0 if broken_x else -1.0  # ERROR in the broken handle: z + u instead of z - u
+    sz = -1.0 if broken_z else 1.0  # ERROR in the broken handle: x - u instead of x + u
+
+    def xmin_t(_x, z, u, rho):
+        return torch.linalg.solve(tPtP + rho * eye, tPtr + rho * (z + sx * u))
+
+    def zmin_t(x, _z, u, rho):
+        return torch.linalg.solve(tQtQ + rho * eye, tQts + rho * (x + sz * u))
+
+    def xmin_n(_x, z, u, rho):
+        return np.linalg.solve(PtP + rho * np.eye(n), Ptr + rho * (z + sx * u))
+
+    def zmin_n(x, _z, u, rho):
+        return np.linalg.solve(QtQ + rho * np.eye(n), Qts + rho * (x + sz * u))
+
+    return (xmin_t, zmin_t), (xmin_n, zmin_n), dict(PtP=PtP, Ptr=Ptr, QtQ=QtQ, Qts=Qts, n=n)
+
+
+def _constraint(n, **kw):
+    return dict(A=1, B=-1, c=0, m=n, nA=n, nB=n, **kw)
+
+
+@pytest.mark.parametrize("which", ["x", "z", "both"])
+def test_broken_handles_hnorm_history(gpu, which):
+    """convergencechecking.m:125-127: convtol = Inf, so the run completes and shows the H-norm values."""
+    P, Q, r, s = _model_data(gpu, 0, 64, 64)
+    (xt, zt), (xn, zn), args = _torch_model_closures(P, Q, r, s, broken_x=which in ("x", "both"),
+                                                     broken_z=which in ("z", "both"))
+    o = _constraint(64, convtest=1, convtol=np.inf, maxiters=15, domaxiters=1)
+    minx, minz, _ = gpu.getproxops("model", args)
+    rminx, rminz, _ = PR.getproxops("model", args)
+    if which == "x":
+        got, ref = gpu.admm(xt, minz, dict(o)), A.admm(xn, rminz, dict(o))
+    elif which == "z":
+        got, ref = gpu.admm(minx, zt, dict(o)), A.admm(rminx, zn, dict(o))
+    else:
+        got, ref = gpu.admm(xt, zt, dict(o)), A.admm(xn, zn, dict(o))
+    _compare(got, ref, tol=1e-7)
+    # the engine-native operators are the default again afterwards
+    _compare(gpu.admm(minx, minz, dict(o)), A.admm(rminx, rminz, dict(o)), tol=TOL)
+
+
+def test_broken_handle_is_detected(gpu):
+    """convergencechecking.m:134-136: with a machine-level convtol the H-norm test aborts the run (q4)."""
+    P, Q, r, s = _model_data(gpu, 0, 64, 64)
+    (xt, _zt), (xn, _zn), args = _torch_model_closures(P, Q, r, s, broken_x=True)
+    o = _constraint(64, convtest=1, convtol=1e-16, maxiters=40, domaxiters=1)
+    _, minz, _ = gpu.getproxops("model", args)
+    _, rminz, _ = PR.getproxops("model", args)
+    got, ref = gpu.admm(xt, minz, dict(o)), A.admm(xn, rminz, dict(o))
+    assert "steps" not in ref and ref["convtest_failed_at"] > 0
+    _compare(got, ref, tol=1e-7)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(relax=1.4), dict(fast=1, fasttype="strong"),
+                                  dict(fast=1, fasttype="weak"), dict(objevals=1)])
+def test_generic_lasso_handles(gpu, opts):
+    """Both handles are the caller's (a lasso written by the user), c a vector, user objective."""
+    import torch
+    dev = torch.device("cuda", 0)
+    p = gpu.synth.lasso_problem(3, 300, 80)
+    D, s_, lam = p["D"], p["s"], p["lam"]
+    n, rho = D.shape[1], 1.0
+    cvec = 0.01 * np.arange(n) / n
+    M = D.T @ D + rho * np.eye(n)
+    Dts = D.T @ s_
+    tM, tDts, tD, ts = (torch.tensor(a, device=dev) for a in (M, Dts, D, s_))
+
+    def soft_t(v, t):
+        return torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0.0)
+
+    def soft_n(v, t):
+        return np.sign(v) * np.maximum(np.abs(v) - t, 0.0)
+
+    cn = cvec
+    ct = torch.tensor(cvec, device=dev)
+    xt = lambda _x, z, u, r_: torch.linalg.solve(tM, tDts + r_ * (z + ct - u))
+    xn = lambda _x, z, u, r_: np.linalg.solve(M, Dts + r_ * (z + cn - u))
+    zt = lambda x, _z, u, r_: soft_t(x + u - ct, lam / r_)
+    zn = lambda x, _z, u, r_: soft_n(x + u - cn, lam / r_)
+    o = dict(A=1, B=-1, c=cvec, m=n, nA=n, nB=n, maxiters=120, **opts)
+    og, orf = dict(o), dict(o)
+    if opts.get("objevals"):
+        og["obj"] = lambda x, z: 0.5 * torch.sum((tD @ x - ts) ** 2) + lam * torch.sum(torch.abs(z))
+        orf["obj"] = lambda x, z: 0.5 * np.sum((D @ x - s_) ** 2) + lam * np.sum(np.abs(z))
+    got, ref = gpu.admm(xt, zt, og), A.admm(xn, zn, orf)
+    _compare(got, ref, tol=1e-7)
+
+
+def test_library_x_with_user_z_on_lasso(gpu):
+    """A library x-update (cached factor, symmetric-half GEMV) with the caller's z-prox."""
+    import torch
+    p = gpu.synth.lasso_problem(5, 400, 120)
+    D, s_, lam = p["D"], p["s"], p["lam"]
+    n = D.shape[1]
+    minx, _minz, _ = gpu.getproxops("lasso", {"D": D, "s": s_, "lambda": lam, "rho": 1.0, "xsolve": "inverse"})
+    rminx, _rminz, _ = PR.getproxops("lasso", {"D": D, "Dts": D.T @ s_, "lambda": lam, "rho": 1.0,
+                                                 "L": np.linalg.cholesky(D.T @ D + np.eye(n)),
+                                                 "U": np.linalg.cholesky(D.T @ D + np.eye(n)).T, "m": D.shape[0],
+                                                 "n": n})
+    # elastic-net style prox: soft-threshold then shrink -- not one of the library's operators
+    zt = lambda x, _z, u, r_: torch.sign(x + u) * torch.clamp(torch.abs(x + u) - lam / r_, min=0.0) / (1.0 + 0.1 / r_)
+    zn = lambda x, _z, u, r_: np.sign(x + u) * np.maximum(np.abs(x + u) - lam / r_, 0.0) / (1.0 + 0.1 / r_)
+    o = _constraint(n, maxiters=80)
+    _compare(gpu.admm(minx, zt, dict(o)), A.admm(rminx, zn, dict(o)), tol=1e-7)
+
+
+def test_host_handles_are_rejected(gpu):
+    o = _constraint(16, maxiters=5)
+    with pytest.raises(TypeError, match="CUDA tensor"):
+        gpu.admm(lambda x, z, u, r: np.zeros(16), lambda x, z, u, r: np.zeros(16), o)
+    with pytest.raises(NotImplementedError, match="A = 1, B = -1"):
+        gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=np.eye(16)))
+    p = gpu.synth.lad_problem(0, 64, 8)
+    minx, _mz, _ = gpu.getproxops("lad", {"D": p["D"], "s": p["s"]})
+    with pytest.raises(NotImplementedError, match="cannot be mixed"):
+        gpu.admm(minx, lambda x, z, u, r: z, dict(A=p["D"], B=-1, c=p["s"], m=64, nA=8, nB=64))
