@@ -89,7 +89,21 @@ def main():
     p = ap.synth.tv_problem(0, 512)
     o = dict(objevals=1, maxiters=10000)
     save("tv_512", dict(s=p["s"], lam=p["lam"], truex=p["truex"]), o, S.totalvariation(p["s"], p["lam"], o))
+    model_fixtures()
+
+
+def model_fixtures():
+    """fast-ADMM weak & strong on the model problem 200x200, plus the plain run."""
+    p = ap.synth.model_problem(0, 200, 200)
+    inp = dict(P=p["P"], Q=p["Q"], r=p["r"], s=p["s"])
+    for tag, o in (("plain", dict(objevals=1, maxiters=80, convtest=1)),
+                   ("fast_weak", dict(objevals=1, fast=1, fasttype="weak", maxiters=80)),
+                   ("fast_strong", dict(objevals=1, fast=1, fasttype="strong", maxiters=80))):
+        save(f"model_{tag}_200", inp, o, S.model(p["P"], p["Q"], p["r"], p["s"], o))
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["model"]:
+        model_fixtures()  # add the model fixtures without touching the others
+    else:
+        main()

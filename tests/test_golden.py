@@ -25,7 +25,8 @@ def test_fixture_inventory():
     names = {os.path.basename(f) for f in FILES}
     for want in ("lasso_tall_256x64.npz", "lasso_fat_32x256.npz", "lad_512x64.npz", "lad_512x64_relax.npz",
                  "huber_512x64.npz", "svm_hinge_256x2.npz", "svm_01_256x2.npz", "qp_bounded_128.npz",
-                 "lasso_fast_weak.npz", "lasso_fast_strong.npz", "lasso_tall_relax.npz", "basispursuit_32x96.npz"):
+                 "lasso_fast_weak.npz", "lasso_fast_strong.npz", "lasso_tall_relax.npz", "basispursuit_32x96.npz",
+                 "model_plain_200.npz", "model_fast_weak_200.npz", "model_fast_strong_200.npz"):
         assert want in names
 
 
@@ -47,6 +48,8 @@ def test_oracle_reproduces_fixture(path):
         r = S.quadraticprogram_bounded(inp["P"], inp["q"], float(inp["r"]), inp["lb"], inp["ub"], o)
     elif name.startswith("tv"):
         r = S.totalvariation(inp["s"], float(inp["lam"]), o)
+    elif name.startswith("model"):
+        r = S.model(inp["P"], inp["Q"], inp["r"], inp["s"], o)
     else:
         r = S.basispursuit(inp["D"], inp["s"], o)
     assert r["steps"] == int(z["steps"])

@@ -377,6 +377,8 @@ def test_golden_fixture(gpu, path):
         got = gpu.basispursuit(inp["D"], inp["s"], o)
     elif name.startswith("tv"):
         got = gpu.totalvariation(inp["s"], float(inp["lam"]), o)
+    elif name.startswith("model"):
+        got = gpu.model(inp["P"], inp["Q"], inp["r"], inp["s"], o)
     else:
         pytest.fail(f"no runner for fixture {name}")
     ref = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
