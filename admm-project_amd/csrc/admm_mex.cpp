@@ -62,6 +62,7 @@ int problem_code(const std::string& p, const mxArray* args) {
   if (p == "totalvariation") return ADMM_PROB_TOTALVARIATION;
   if (p == "quadraticprogram") return ADMM_PROB_QP_BOUNDED;
   if (p == "basispursuit") return ADMM_PROB_BASISPURSUIT;
+  if (p == "model") return ADMM_PROB_MODEL;
   mexErrMsgIdAndTxt("admm:problem", "Invalid input for problem - given string is not a solver!");
   return 0;
 }
@@ -144,6 +145,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     d.rho = opt_scalar(args, "rho", 1.0);
     d.userelax = static_cast<int32_t>(opt_scalar(args, "userelax", 0.0));
     d.loss = str_is(args, "lossfunction", "01") ? ADMM_LOSS_01 : ADMM_LOSS_HINGE;
+    if (d.problem == ADMM_PROB_MODEL) {  // getProxOps.m:83-89: args.PtP, Ptr, QtQ, Qts, n
+      d.n = static_cast<int64_t>(opt_scalar(args, "n", 0.0));
+      d.m = d.n;
+      d.P = opt_vec(args, "PtP");
+      d.q = opt_vec(args, "Ptr");
+      d.Q = opt_vec(args, "QtQ");
+      d.qz = opt_vec(args, "Qts");
+    }
     d.device = static_cast<int32_t>(opt_scalar(args, "device", 0.0));
     admm_engine* e = nullptr;
     check(admm_engine_create(&d, &e));
