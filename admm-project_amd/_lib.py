@@ -19,7 +19,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -
 # problem kinds
 PROB_LASSO, PROB_LASSO_CONSENSUS, PROB_LAD, PROB_HUBERFIT = 1, 2, 3, 4
 PROB_LINEARSVM, PROB_TOTALVARIATION, PROB_QP_BOUNDED, PROB_BASISPURSUIT = 5, 6, 7, 8
-PROB_MODEL = 9
+PROB_MODEL, PROB_LINEARPROGRAM, PROB_QP_STANDARD = 9, 10, 11
 LOSS_HINGE, LOSS_01 = 0, 1
 XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -50,6 +50,7 @@ class ProblemDesc(C.Structure):
         ("comm", C.c_void_p),
         ("cg_tol", C.c_double), ("cg_maxit", C.c_int32), ("reserved0", C.c_int32),
         ("Q", _dp), ("qz", _dp), ("D2", _dp), ("m2", C.c_int64), ("ldD2", C.c_int64), ("s2", _dp), ("c", _dp),
+        ("K", _dp), ("k0", _dp),
     ]
 
 

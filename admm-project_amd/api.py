@@ -73,6 +73,24 @@ def _get(args, name):
     return args[name]
 
 
+def _reduce_kkt(P, D, s, rho):
+    """[M D'; D 0] \\ [y; s] = K*y + k0 with M = P + rho*I (P = None: rho*I), S = D inv(M) D':
+    K = inv(M) - inv(M) D' inv(S) D inv(M) (symmetric), k0 = inv(M) D' inv(S) s."""
+    n = D.shape[1]
+    if P is None:
+        Minv = np.eye(n) / rho
+    else:
+        Minv = np.linalg.inv(P + rho * np.eye(n))
+        Minv = 0.5 * (Minv + Minv.T)
+    MD = Minv @ D.T                      # n x m
+    S = D @ MD                           # m x m
+    SinvDM = np.linalg.solve(S, MD.T)    # m x n
+    K = Minv - MD @ SinvDM
+    K = 0.5 * (K + K.T)
+    k0 = MD @ np.linalg.solve(S, s)
+    return np.asfortranarray(K), k0
+
+
 def getproxops(problem, args):
     """Prox-operator factory (getProxOps.m:13-917).  ``args`` uses the reference's field names.
 
@@ -136,11 +154,24 @@ def getproxops(problem, args):
         eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
                      loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev, comm=comm, **cg)
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
+    elif kind == "linearprogram" or (kind == "quadraticprogram" and _get(args, "constraint") == "standard"):
+        # getProxOps.m:1363 / 1410 solve [M D'; D 0] \ [rho*(z-u) - q; s] every iteration (M = rho*I for the
+        # LP, P + rho*I for the QP).  The binding reduces that KKT system ONCE (cold path, host LAPACK, like
+        # basis pursuit's projector) to x = K*y + k0; the per-iteration n x n GEMV runs on the device.
+        D, s = _get(args, "D"), np.asarray(_get(args, "s"), dtype=np.float64).reshape(-1)
+        D = np.asarray(D, dtype=np.float64)
+        n = D.shape[1]
+        rho = float(args.get("rho", 1.0))
+        lp = kind == "linearprogram"
+        q = np.asarray(_get(args, "b" if lp else "q"), dtype=np.float64).reshape(-1)
+        P = None if lp else np.asarray(_get(args, "P"), dtype=np.float64)
+        K, k0 = _reduce_kkt(P, D, s, rho)
+        if lp:
+            eng = Engine(L.PROB_LINEARPROGRAM, q=q, K=K, k0=k0, rho=rho, device=dev)
+        else:
+            eng = Engine(L.PROB_QP_STANDARD, P=P, q=q, K=K, k0=k0, rho=rho, r=float(args.get("r", 0.0)), device=dev)
+        prob = _Problem(kind, eng, dict(A=1, c=0.0, nA=n, nB=n))
     elif kind == "quadraticprogram":
-        if _get(args, "constraint") != "bounded":
-            raise NotImplementedError("standard-form QP (KKT solve per iteration) is not engine-native")
-        if "altproxg" in args:
-            raise NotImplementedError("args.altproxg (user prox) needs a CPU path; not supported")
         P, q = _get(args, "P"), _get(args, "q")
         n = P.shape[0]
         eng = Engine(L.PROB_QP_BOUNDED, P=P, q=q, lb=_get(args, "lb"), ub=_get(args, "ub"),
@@ -215,7 +246,7 @@ def _check_constraint(options, prob):
             raise ValueError(f"options.{key} does not match the problem size")
 
 
-_CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "basispursuit")  # A = 1 problems
+_CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "linearprogram", "basispursuit")  # A = 1 problems
 
 
 def _generic_problem(options):

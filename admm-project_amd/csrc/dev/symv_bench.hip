@@ -102,7 +102,7 @@ __device__ __forceinline__ double reduce_scatter_fast(double (&t)[P], int lane, 
 
 // Q: double2 per column per lane (rows per wave = 128*Q), P: columns per panel, NB: panel buffers,
 // C: columns per tile, MODE 0 full, 1 no cross-lane reduction, 2 loads + one add only.
-template <int Q, int P, int NB, int C, int MODE, bool DIAG>
+template <int Q, int P, int NB, int C, int MODE, bool DIAG, bool NT>
 __device__ __forceinline__ void tile_body(const double* __restrict__ M, int64_t ld, const double* __restrict__ x,
                                           int64_t w0, int64_t c0, int64_t limit, double* __restrict__ nout,
                                           double* __restrict__ tout, int lane) {
@@ -124,7 +124,9 @@ __device__ __forceinline__ void tile_body(const double* __restrict__ M, int64_t 
     for (int k = 0; k < P; ++k) {
       const double* cb = M + (c0 + static_cast<int64_t>(pan) * P + k) * ld;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) b[k][q] = *reinterpret_cast<const double2_t*>(cb + roff[q]);
+      for (int q = 0; q < Q; ++q)
+        b[k][q] = NT ? __builtin_nontemporal_load(reinterpret_cast<const double2_t*>(cb + roff[q]))
+                     : *reinterpret_cast<const double2_t*>(cb + roff[q]);
     }
   };
   auto compute = [&](double2_t(&b)[P][Q], int pan) {
@@ -193,7 +195,7 @@ __device__ __forceinline__ void tile_body(const double* __restrict__ M, int64_t 
   }
 }
 
-template <int Q, int P, int NB, int C, int MODE>
+template <int Q, int P, int NB, int C, int MODE, bool NT>
 __global__ __launch_bounds__(64) void symv_var(const double* __restrict__ M, int64_t ld, const double* __restrict__ x,
                                                double* __restrict__ npart, double* __restrict__ tpart, int64_t ldp,
                                                const int2* __restrict__ tiles) {
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(64) void symv_var(const double* __restrict__ M, int
   const bool diag = w0 < c0 + C;
   double* nout = npart + static_cast<int64_t>(tl.y) * ldp;
   double* tout = tpart + static_cast<int64_t>(tl.x) * ldp;
-  if (diag) tile_body<Q, P, NB, C, MODE, true>(M, ld, x, w0, c0, limit, nout, tout, lane);
-  else tile_body<Q, P, NB, C, MODE, false>(M, ld, x, w0, c0, limit, nout, tout, lane);
+  if (diag) tile_body<Q, P, NB, C, MODE, true, NT>(M, ld, x, w0, c0, limit, nout, tout, lane);
+  else tile_body<Q, P, NB, C, MODE, false, NT>(M, ld, x, w0, c0, limit, nout, tout, lane);
 }
 
 struct Result {
@@ -216,7 +218,7 @@ struct Result {
 
 enum Order { COLMAJOR = 0, ROWMAJOR = 1, ALTERNATE = 2 };
 
-template <int Q, int P, int NB, int C, int MODE>
+template <int Q, int P, int NB, int C, int MODE, bool NT = true>
 Result run_variant(const char* name, int64_t n, const double* dM, const double* dx, const std::vector<double>& yref,
                    int order, int reps) {
   constexpr int R = 128 * Q;
@@ -248,7 +250,7 @@ Result run_variant(const char* name, int64_t n, const double* dM, const double* 
   CK(hipEventCreate(&e1));
   auto launch = [&](int it) {
     const int2* t = (order == ALTERNATE && (it & 1)) ? dtr : dt;
-    hipLaunchKernelGGL((symv_var<Q, P, NB, C, MODE>), dim3(static_cast<unsigned>(tiles.size())), dim3(64), 0, 0, dM, n,
+    hipLaunchKernelGGL((symv_var<Q, P, NB, C, MODE, NT>), dim3(static_cast<unsigned>(tiles.size())), dim3(64), 0, 0, dM, n,
                        dx, np, tp, ldp, t);
   };
   for (int i = 0; i < 4; ++i) launch(i);
@@ -278,7 +280,7 @@ Result run_variant(const char* name, int64_t n, const double* dM, const double* 
   const double bytes = 8.0 * n * (n + 1) / 2;
   int nregs = 0;
   hipFuncAttributes fa;
-  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(symv_var<Q, P, NB, C, MODE>)) == hipSuccess) nregs = fa.numRegs;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(symv_var<Q, P, NB, C, MODE, NT>)) == hipSuccess) nregs = fa.numRegs;
   printf("%-34s Q=%d P=%2d NB=%d C=%4d mode=%d order=%d tiles=%6zu vgpr=%3d  %8.2f us  %6.3f TB/s  err=%.2e\n", name, Q,
          P, NB, C, MODE, order, tiles.size(), nregs, res.us, bytes / res.us * 1e-6, res.err);
   fflush(stdout);
@@ -332,19 +334,20 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(yref.data(), dy, sizeof(double) * n, hipMemcpyDeviceToHost));
   printf("n=%lld  lower triangle %.1f MB\n", static_cast<long long>(n), 8.0 * n * (n + 1) / 2 * 1e-6);
 
-  run_variant<1, 8, 2, 128, 0>("base 128x128 p8 nb2", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 8, 2, 128, 2>("base, loads only", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 8, 2, 128, 3>("128x128 p8 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 8, 3, 128, 3>("128x128 p8 nb3 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 8, 2, 64, 3>("128x64 p8 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 4, 2, 128, 3>("128x128 p4 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<1, 4, 4, 128, 3>("128x128 p4 nb4 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 4, 2, 128, 3>("256x128 p4 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 4, 3, 128, 3>("256x128 p4 nb3 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 4, 2, 64, 3>("256x64 p4 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 4, 2, 256, 3>("256x256 p4 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 8, 2, 128, 3>("256x128 p8 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<4, 4, 2, 64, 3>("512x64 p4 nb2 fast", n, dM, dx, yref, COLMAJOR, reps);
-  run_variant<2, 4, 2, 128, 3>("256x128 p4 nb2 fast rowmajor", n, dM, dx, yref, ROWMAJOR, reps);
+  run_variant<1, 4, 2, 128, 3, false>("128x128 p4 nb2 fast, plain loads", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 128, 3>("128x128 p4 nb2 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 128, 2>("128x128 p4 nb2 loads only NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 128, 1>("128x128 p4 nb2 no reduce NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 4, 128, 3>("128x128 p4 nb4 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 4, 128, 2>("128x128 p4 nb4 loads only NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 8, 2, 128, 2>("128x128 p8 nb2 loads only NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<2, 4, 2, 128, 3>("256x128 p4 nb2 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<2, 4, 2, 128, 2>("256x128 p4 nb2 loads only NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<2, 4, 3, 128, 3>("256x128 p4 nb3 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<4, 4, 2, 128, 3>("512x128 p4 nb2 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<4, 2, 2, 128, 2>("512x128 p2 nb2 loads only NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 256, 3>("128x256 p4 nb2 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 64, 3>("128x64 p4 nb2 fast NT", n, dM, dx, yref, COLMAJOR, reps);
+  run_variant<1, 4, 2, 128, 3>("128x128 p4 nb2 fast NT rowmajor", n, dM, dx, yref, ROWMAJOR, reps);
   return 0;
 }

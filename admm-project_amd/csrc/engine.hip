@@ -89,6 +89,11 @@ struct admm_engine {
   double* rhs_add = nullptr;  // Dts (lasso) or q (QP)
   double* Pmat = nullptr;     // QP P (for the objective) or BP projector
   int64_t ldP = 0;
+  double* Kmat = nullptr;     // LP / standard-form QP: x = K*y + k0 (Schur-reduced KKT solve)
+  int64_t ldK = 0;
+  double* k0 = nullptr;
+  GemvTPlan planK{};
+  double* partK = nullptr;
 
   // cached factor
   double* F = nullptr;  // lower Cholesky factor, nF x nF
@@ -473,7 +478,9 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (!(desc->rho > 0.0)) return bail(fail(ADMM_E_INVALID, "rho must be a positive real (lasso.m:138)"));
 
   int xs = desc->xsolve;
-  if (xs == ADMM_XSOLVE_AUTO) xs = ADMM_XSOLVE_TRSV;
+  // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, ~1 ms at n = 10^4);
+  // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
+  if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
     return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg applies to problems whose x-update solves with D'D (+ rho I)"));
@@ -692,6 +699,32 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(e->mem.alloc(&e->zext, n2));
       E_TRY(e->mem.alloc(&e->xh, n2));
       E_TRY(e->mem.alloc(&e->rz, n2));
+      break;
+    }
+    case ADMM_PROB_LINEARPROGRAM:
+    case ADMM_PROB_QP_STANDARD: {
+      const bool qp = desc->problem == ADMM_PROB_QP_STANDARD;
+      if (!desc->K || !desc->k0 || !desc->q || n <= 0 || (qp && !desc->P))
+        return bail(fail(ADMM_E_INVALID, qp ? "standard-form QP needs P, q and the reduced KKT map K, k0"
+                                            : "linear program needs b (as q) and the reduced KKT map K, k0"));
+      e->a_identity = true;
+      e->nA = n;
+      e->len = n;
+      e->prox = PROX_POS;                 // getProxOps.m:1381, 1425
+      e->rhs_kind = RHS_RHO_MINUS_Q;      // y = rho*(z-u) - b   (getProxOps.m:1363, 1410)
+      E_TRY(upload_matrix(e->mem, &e->Kmat, &e->ldK, desc->K, n, n, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->k0, desc->k0, n, mk, e->stream));
+      E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+      e->rhs_add = e->q;
+      e->ell = e->q;                      // objective b'*x (linearprogram.m:178) reads it as the dot vector
+      e->planK = gemv_t_plan(n, n, e->ldK);
+      E_TRY(e->mem.alloc(&e->partK, e->planK.part_elems(1)));
+      if (qp) {  // the objective 1/2 x'Px + q'x + r needs P*x
+        E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
+        e->planSq = gemv_t_plan(n, n, e->ldP);
+        E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
+      }
+      e->xsolve = ADMM_XSOLVE_INVERSE;  // a GEMV by construction
       break;
     }
     case ADMM_PROB_TOTALVARIATION: {
@@ -950,6 +983,12 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
     case ADMM_PROB_MODEL:
       factor_x_update(e, axsrc, naxpart, axld);
       break;
+    case ADMM_PROB_LINEARPROGRAM:
+    case ADMM_PROB_QP_STANDARD:  // x = K*y + k0: the KKT solve of getProxOps.m:1363 / 1410, reduced once
+      launch_gemv_t(e->planK, e->Kmat, e->rhs, nullptr, nullptr, 1, e->partK, e->ctrl, e->stream);
+      launch_combine(e->partK, e->planK.nchunk, e->planK.ldg, 1.0, nullptr, 0.0, e->k0, e->x, e->n, e->ctrl,
+                     e->stream);
+      break;
     case ADMM_PROB_BASISPURSUIT:
       launch_gemv_t(e->planSq, e->Pmat, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
       launch_combine(e->partSq, e->planSq.nchunk, e->planSq.ldg, 1.0, nullptr, 0.0, e->q, e->x, e->n, e->ctrl,
@@ -981,9 +1020,10 @@ int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xus
   if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
   if ((xmin || zmin || obj) &&
       !(e->problem == ADMM_PROB_MODEL || e->problem == ADMM_PROB_QP_BOUNDED || e->problem == ADMM_PROB_BASISPURSUIT ||
+        e->problem == ADMM_PROB_LINEARPROGRAM || e->problem == ADMM_PROB_QP_STANDARD ||
         (e->problem == ADMM_PROB_LASSO && !e->fat && e->xsolve != ADMM_XSOLVE_CG)))
     return fail(ADMM_E_UNSUPPORTED,
-                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, bounded QP, basis pursuit)");
+                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, QP, LP, basis pursuit)");
   if ((xmin || zmin || obj) && e->comm && comm_nranks(e->comm) > 1)
     return fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines");
   ADMM_HIP_TRY(hipSetDevice(e->device));
@@ -1011,7 +1051,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   if (o.restart <= 0.0 || o.restart >= 1.0) o.restart = 0.999;  // admm.m:285-287
   if (o.fast != ADMM_FAST_OFF && o.fast != ADMM_FAST_WEAK && o.fast != ADMM_FAST_STRONG)
     return fail(ADMM_E_INVALID, "bad options.fast");
-  if (o.rho != e->rho_factor && (e->F || e->has_zfac) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
+  if (o.rho != e->rho_factor && (e->F || e->has_zfac || e->Kmat) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
       e->problem != ADMM_PROB_LINEARSVM)
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)
@@ -1113,9 +1153,14 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         fa.obj_half_xnorm = 0.5;
         break;
       case ADMM_PROB_QP_BOUNDED:
+      case ADMM_PROB_QP_STANDARD:
         obj_qp_gemv = true;
         fa.obj_scale_part = 1.0;
         fa.obj_const = e->rconst;
+        break;
+      case ADMM_PROB_LINEARPROGRAM:  // b'*x   (linearprogram.m:178)
+        pa.objx = OBJX_DOT;
+        fa.obj_scale_x = 1.0;
         break;
       case ADMM_PROB_BASISPURSUIT:
         pa.objx = OBJX_ABS;

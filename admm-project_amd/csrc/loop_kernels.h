@@ -11,6 +11,7 @@ enum ProxKind : int32_t {
   PROX_HINGE = 2,  // v + ell.*max(min(1-ell.*v, C/rho),0)             1084-1096
   PROX_01 = 3,     // ell.*minz01(ell.*v, rho/C)                       1100, 1158-1180
   PROX_BOX = 4,    // min(ub,max(lb,v))                                1470-1474
+  PROX_POS = 6,    // max(v, 0)   (CVX pos)                            1378-1382, 1422-1426
   PROX_GIVEN = 5   // z was computed outside the fused kernel (a linear solve: zminModel 990-1013,
                    // or a caller-supplied zming callback) and is read from ProxArgs::zgiven
 };
@@ -27,7 +28,8 @@ enum RhsKind : int32_t {
 // z-side objective terms accumulated by the prox kernel
 enum ObjZKind : int32_t { OBJZ_NONE = 0, OBJZ_ABS = 1, OBJZ_HUBER = 2 };
 // Ax-side / x-side terms
-enum ObjXKind : int32_t { OBJX_NONE = 0, OBJX_HINGE = 1, OBJX_ZEROONE = 2, OBJX_ABS = 3 };
+enum ObjXKind : int32_t { OBJX_NONE = 0, OBJX_HINGE = 1, OBJX_ZEROONE = 2, OBJX_ABS = 3,
+                          OBJX_DOT = 4 /* sum ell_i * x_i: b'*x, linearprogram.m:178 */ };
 
 // reduction slots (per-block partials, summed in block order by the finalize kernel)
 enum Slot : int32_t {

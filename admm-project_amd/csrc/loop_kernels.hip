@@ -92,6 +92,9 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
       case PROX_GIVEN:
         zn = a.zgiven[i];
         break;
+      case PROX_POS:
+        zn = fmax(v, 0.0);
+        break;
       default:  // PROX_BOX
         zn = fmin(a.ub[i], fmax(a.lb[i], v));
         break;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
       const double q = 1.0 - a.ell[i] * ax;
       acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
     } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
+    else if (a.objx == OBJX_DOT) acc[S_OBJX] += a.ell[i] * ax;
 
     a.z[i] = zn;
     a.u[i] = un;

@@ -20,7 +20,7 @@ class Engine:
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
                  device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
-                 Q=None, qz=None, D2=None, s2=None, c=None):
+                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -67,6 +67,14 @@ class Engine:
             d.s2 = vec(s2)
         if c is not None:
             d.c = vec(c)
+        if K is not None:  # LP / standard-form QP: reduced KKT map x = K*y + k0
+            Km = _f64(K)
+            keep.append(Km)
+            d.K = L.as_dp(Km)
+            d.n = Km.shape[0]
+            if D is None:
+                d.m = Km.shape[0]
+            d.k0 = vec(k0)
         if s is not None:
             d.s = vec(s)
         if ell is not None:

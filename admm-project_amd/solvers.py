@@ -16,7 +16,7 @@ from .api import admm, getproxops
 from .errorcheck import is_nonnegative_real, is_positive_real, slicemaker
 
 __all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit",
-           "totalvariation", "model"]
+           "totalvariation", "model", "linearprogram"]
 
 _ENGINE_OBJ = "<engine-native objective>"
 
@@ -168,7 +168,9 @@ def linearsvm(D, ell, C, options=None):
 def quadraticprogram(P, q, r, cons1, cons2, options=None):
     """results = quadraticprogram(P, q, r, cons1, cons2, options)  (solvers/quadraticprogram.m:99-246)
 
-    Only the 'bounded' form (cons1 = lb, cons2 = ub vectors) is engine-native.
+    'bounded' form: cons1 = lb, cons2 = ub vectors.  'standard' form: one matrix D and one vector s
+    (either order, quadraticprogram.m:321-329) for D*x = s, x >= 0.  ``options['altproxg']`` (a handle on
+    device tensors) replaces the z-prox as in quadraticprogram.m:221-227.
     """
     if not isinstance(options, dict):
         raise TypeError("Argument options is not a struct!")
@@ -181,8 +183,27 @@ def quadraticprogram(P, q, r, cons1, cons2, options=None):
     if q.size != P.shape[0]:
         raise ValueError("The dimensions of square matrix P and vector q do not match!")
     c1, c2 = np.asarray(cons1, dtype=np.float64), np.asarray(cons2, dtype=np.float64)
-    if not (c1.ndim <= 1 or 1 in c1.shape) or not (c2.ndim <= 1 or 1 in c2.shape):
-        raise NotImplementedError("standard-form QP (matrix constraint) is not engine-native")
+    vec1, vec2 = (c1.ndim <= 1 or 1 in c1.shape), (c2.ndim <= 1 or 1 in c2.shape)
+    if not vec1 and not vec2:
+        raise ValueError("Constraint inputs do not specify a bounded or a standard-form problem!")
+    if not (vec1 and vec2):  # 'standard': D*x = s, x >= 0   (quadraticprogram.m:319-345)
+        Dm, sv = (c2, c1) if vec1 else (c1, c2)
+        sv = sv.reshape(-1)
+        if Dm.shape[1] != P.shape[0]:
+            raise ValueError("The number of columns of constraint matrix D does not match the size of P!")
+        if Dm.shape[0] != sv.size:
+            raise ValueError("The number of rows in matrix D must match the length of vector s!")
+        n = P.shape[0]
+        rho = float(options.get("rho", 1.0))
+        args = _engine_args(options, dict(P=P, q=q, D=Dm, s=sv, rho=rho, n=n, constraint="standard", r=float(r)))
+        minx, minz, _ = getproxops("quadraticprogram", args)
+        if callable(options.get("altproxg")):
+            minz = options["altproxg"]
+        options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
+        options["obj"] = _ENGINE_OBJ  # quadraticprogram.m:242
+        results = admm(minx, minz, options)
+        results["solverruntime"] = time.perf_counter() - t0
+        return results
     lb, ub = c1.reshape(-1), c2.reshape(-1)
     if lb.size != ub.size:
         raise ValueError("Lengths of lower and upper bound constraints on solution x do not match!")
@@ -196,8 +217,43 @@ def quadraticprogram(P, q, r, cons1, cons2, options=None):
     rho = float(options.get("rho", 1.0))
     args = _engine_args(options, dict(P=P, q=q, lb=lb, ub=ub, rho=rho, n=n, constraint="bounded", r=float(r)))
     minx, minz, _ = getproxops("quadraticprogram", args)
+    if callable(options.get("altproxg")):  # quadraticprogram.m:221-227
+        minz = options["altproxg"]
     options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
     options["obj"] = _ENGINE_OBJ  # quadraticprogram.m:242
+    results = admm(minx, minz, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def linearprogram(b, D, s, options=None):
+    """results = linearprogram(b, D, s, options)   (solvers/linearprogram.m:81-185)
+
+    minimise b'*x subject to D*x = s, x >= 0.  The reference solves the (n+m) x (n+m) KKT system in
+    every x-update (getProxOps.m:1363); here it is reduced once on the host to x = K*y + k0 and the
+    per-iteration n x n GEMV, the pos() prox, the u-update and the residuals run on the device.
+    """
+    if options is None:
+        options = {}
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    D = _matrix(D, "D")
+    b = _colvec(b, "b")
+    s = _colvec(s, "s")
+    m, n = D.shape
+    if b.size != n:
+        raise ValueError("The length of cost vector b must match the number of columns of D!")
+    if s.size != m:
+        raise ValueError("The number of rows in matrix D must match the length of vector s!")
+    rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
+    args = _engine_args(options, dict(D=D, Dt=D.T, b=b, s=s, n=n, rho=rho))
+    minx, minz, _ = getproxops("LinearProgram", args)
+    if callable(options.get("altproxg")):  # linearprogram.m:158-164
+        minz = options["altproxg"]
+    options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)  # linearprogram.m:172-177
+    options["obj"] = _ENGINE_OBJ  # linearprogram.m:178  b'*x
     results = admm(minx, minz, options)
     results["solverruntime"] = time.perf_counter() - t0
     return results

@@ -167,6 +167,30 @@ def qp_bounded_problem(seed=0, n=2 ** 7):
     return dict(P=P, q=q, r=0.0, lb=lb, ub=ub)
 
 
+def lp_problem(seed=0, rows=2 ** 6, cols=2 ** 7):
+    """testers/linearprogramtest.m:107-111: b = rand+0.5, truexopt = |randn|, D = |randn|, s = D*truexopt."""
+    rng = np.random.default_rng(seed)
+    b = rng.random(cols) + 0.5
+    truex = np.abs(rng.standard_normal(cols))
+    D = np.asfortranarray(np.abs(rng.standard_normal((rows, cols))))
+    return dict(b=b, D=D, s=D @ truex, truex=truex)
+
+
+def qp_standard_problem(seed=0, rows=2 ** 6, cols=2 ** 7):
+    """testers/quadraticprogramtest.m:120-131: P = V*diag(1+rand)*V' from the eigenvectors of a random
+    symmetric matrix, q = randn, r = randn, D = |randn|, s = D*|randn|."""
+    rng = np.random.default_rng(seed)
+    G = rng.random((cols, cols))
+    _, V = np.linalg.eigh(G + G.T)
+    P = np.asfortranarray(V @ np.diag(1.0 + rng.random(cols)) @ V.T)
+    P = 0.5 * (P + P.T)
+    q = rng.standard_normal(cols)
+    r = float(rng.standard_normal())
+    truex = np.abs(rng.standard_normal(cols))
+    D = np.asfortranarray(np.abs(rng.standard_normal((rows, cols))))
+    return dict(P=P, q=q, r=r, D=D, s=D @ truex, truex=truex)
+
+
 def basispursuit_problem(seed=0, rows=2 ** 6, cols=2 ** 7):
     """testers/basispursuittest.m:106-109: fat D, s = D*testx.  The reference asks for
     ``sprandn(cols, 1, 0.1*cols)``, i.e. a density of 0.1*cols >= 1 for cols >= 10, which

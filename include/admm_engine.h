@@ -45,6 +45,8 @@ enum {
   ADMM_PROB_TOTALVARIATION = 6,   /* getProxOps.m:145-199, 1044-1048 */
   ADMM_PROB_QP_BOUNDED = 7,       /* getProxOps.m:631-641, 1441-1474 */
   ADMM_PROB_BASISPURSUIT = 8,     /* getProxOps.m:98-142, 1027-1032 */
+  ADMM_PROB_LINEARPROGRAM = 10,   /* getProxOps.m:459-542, x: 1357-1366 (KKT solve), z: 1378-1382 */
+  ADMM_PROB_QP_STANDARD = 11,     /* getProxOps.m:624-630, x: 1397-1412 (KKT solve), z: 1422-1426 */
   ADMM_PROB_MODEL = 9             /* getProxOps.m:60-95, x: 952-979, z: 990-1013 (model.m); with both prox
                                      callbacks set and no data it is the generic admm(xminf, zming, options)
                                      of admm.m:24 for A = 1, B = -1 */
@@ -55,7 +57,7 @@ enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1 };
 
 /* how the cached-factor x-update is applied every iteration */
 enum {
-  ADMM_XSOLVE_AUTO = 0,
+  ADMM_XSOLVE_AUTO = 0,    /* TRSV up to n = 256, INVERSE beyond */
   ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form) */
   ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once */
   ADMM_XSOLVE_CG = 3       /* matrix-free conjugate gradients on (D'D + rho I), A-streaming */
@@ -134,6 +136,12 @@ typedef struct admm_problem_desc {
   int64_t m2, ldD2;
   const double* s2;    /* length m2: the vector s */
   const double* c;     /* optional constraint vector (length n) of x - z = c; NULL = 0 (model.m:127) */
+  /* ADMM_PROB_LINEARPROGRAM / ADMM_PROB_QP_STANDARD: the KKT solve [M D'; D 0] \ [y; s] of
+   * getProxOps.m:1363 / 1410 (M = rho*I or P + rho*I) reduced ONCE by the binding to the affine map
+   * x = K*y + k0,  K = inv(M) - inv(M) D' inv(S) D inv(M) (symmetric, n x n),  k0 = inv(M) D' inv(S) s,
+   * S = D inv(M) D'  (built for desc.rho).  y = rho*(z-u) - q with q = the linear cost (args.b / args.q). */
+  const double* K;
+  const double* k0;
 } admm_problem_desc;
 
 /* POD mirror of the `options` struct read by admm.m:51-76 (defaults: setopt, 780-971). */

@@ -188,3 +188,44 @@ def test_host_handles_are_rejected(gpu):
     minx, _mz, _ = gpu.getproxops("lad", {"D": p["D"], "s": p["s"]})
     with pytest.raises(NotImplementedError, match="cannot be mixed"):
         gpu.admm(minx, lambda x, z, u, r: z, dict(A=p["D"], B=-1, c=p["s"], m=64, nA=8, nB=64))
+
+
+# ---------------------------------------------------------------------------- LP / standard-form QP
+@pytest.mark.parametrize("opts", [dict(objevals=1, maxiters=400), dict(objevals=1, rho=2.0, maxiters=300),
+                                  dict(relax=1.5, maxiters=300), dict(fast=1, fasttype="weak", maxiters=100),
+                                  dict(convtest=1, stopcond="both", maxiters=200)])
+def test_linearprogram_parity(gpu, opts):
+    p = gpu.synth.lp_problem(0, 32, 96)
+    _compare(gpu.linearprogram(p["b"], p["D"], p["s"], dict(opts)), S.linearprogram(p["b"], p["D"], p["s"], dict(opts)),
+             tol=1e-7)
+
+
+def test_linearprogram_criterion(gpu):  # linearprogramtest.m:122-134
+    p = gpu.synth.lp_problem(1)
+    r = gpu.linearprogram(p["b"], p["D"], p["s"], dict(objevals=1, maxiters=10000, record_history=0))
+    x = r["xopt"]
+    Dx = p["D"] @ x
+    assert np.mean(np.abs((Dx - p["s"]) / Dx)) <= 1e-3
+    assert r["objopt"] == pytest.approx(float(p["b"] @ x), rel=1e-9)
+
+
+@pytest.mark.parametrize("opts", [dict(objevals=1, maxiters=300), dict(objevals=1, rho=0.5, maxiters=300),
+                                  dict(relax=1.3, maxiters=200), dict(fast=1, fasttype="strong", maxiters=80)])
+def test_qp_standard_parity(gpu, opts):
+    p = gpu.synth.qp_standard_problem(0, 24, 80)
+    got = gpu.quadraticprogram(p["P"], p["q"], p["r"], p["D"], p["s"], dict(opts))
+    ref = S.quadraticprogram_standard(p["P"], p["q"], p["r"], p["D"], p["s"], dict(opts))
+    _compare(got, ref, tol=1e-7)
+    # the constraint arguments may come in either order (quadraticprogram.m:325-329)
+    got2 = gpu.quadraticprogram(p["P"], p["q"], p["r"], p["s"], p["D"], dict(opts))
+    assert got2["steps"] == got["steps"]
+
+
+def test_altproxg_handle(gpu):
+    """linearprogram.m:158-164: options.altproxg replaces the z-prox (here: the same pos() written by hand)."""
+    import torch
+    p = gpu.synth.lp_problem(2, 16, 48)
+    o = dict(maxiters=150)
+    ref = S.linearprogram(p["b"], p["D"], p["s"], dict(o))
+    got = gpu.linearprogram(p["b"], p["D"], p["s"], dict(o, altproxg=lambda x, z, u, rho: torch.clamp(x + u, min=0.0)))
+    _compare(got, ref, tol=1e-7)

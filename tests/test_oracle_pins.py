@@ -141,3 +141,27 @@ def test_prox_primitives():
     np.testing.assert_array_equal(soft_threshold(v, 1.0), [-1.0, -0.0, 0.0, 0.0, 1.0])
     s = np.array([1.0, 0.999, 1 - np.sqrt(2 / 4.0) - 1e-9, 1 - np.sqrt(2 / 4.0) + 1e-9])
     np.testing.assert_array_equal(minz01(s, 4.0), [1.0, 1.0, s[2], 1.0])
+
+
+def test_linearprogram_criterion(ap):  # linearprogramtest.m:122-134
+    p = ap.synth.lp_problem(1)
+    r = S.linearprogram(p["b"], p["D"], p["s"], dict(objevals=1, maxiters=10000))
+    x = r["xopt"]
+    Dx = p["D"] @ x
+    assert np.mean(np.abs((Dx - p["s"]) / Dx)) <= 1e-3
+    assert abs(r["objopt"] - float(p["b"] @ x)) <= 1e-9 * abs(r["objopt"])
+
+
+def test_kkt_reduction_matches_the_kkt_solve(ap):
+    """api._reduce_kkt: the affine map the device applies == the (n+m) x (n+m) solve of getProxOps.m:1363/1410."""
+    from admm_project_amd.api import _reduce_kkt
+    p = ap.synth.qp_standard_problem(3, 12, 40)
+    rng = np.random.default_rng(0)
+    for P, rho in ((None, 1.0), (None, 2.5), (p["P"], 1.0), (p["P"], 0.3)):
+        K, k0 = _reduce_kkt(P, p["D"], p["s"], rho)
+        n, m = 40, 12
+        M = rho * np.eye(n) if P is None else P + rho * np.eye(n)
+        kkt = np.block([[M, p["D"].T], [p["D"], np.zeros((m, m))]])
+        y = rng.standard_normal(n)
+        x = np.linalg.solve(kkt, np.concatenate([y, p["s"]]))[:n]
+        np.testing.assert_allclose(K @ y + k0, x, rtol=1e-10, atol=1e-12)
