@@ -57,6 +57,77 @@ void run_n(const double* D, int64_t m, int64_t n, int64_t ld, const double* x, d
          8.0 * m * n);
 }
 
+// NOTE: gemv_n_exp has NO tail loop: it streams floor(cols_per_chunk/U)*U columns of every chunk, so its
+// TB/s must be scaled by that fraction (a chunk of 63 columns at U=16 reads only 48: the "7.9 TB/s" such a
+// run prints is 6.0).  Findings (MI355X): x loads, accumulator count, unroll depth 8..24 and rows per
+// thread all land within 2 % of the product kernel; the pure-read pattern ceiling is ~6 % above it.
+// experimental variants of gemv_n: MODE 0 = product structure, 1 = no x loads (constant), 2 = x chunk staged
+// in LDS, 3 = product structure with RPT double2 per thread per column (512*RPT rows per block)
+template <int U, int RPT, int MODE, int NACC = U>
+__global__ __launch_bounds__(kBlock) void gemv_n_exp(const double* __restrict__ D, int64_t m, int64_t n, int64_t ld,
+                                                     const double* __restrict__ x, double* __restrict__ ypart,
+                                                     int64_t ldy, int64_t cols_per_chunk) {
+  extern __shared__ double sx[];
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (512 * RPT) + 2 * threadIdx.x;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * cols_per_chunk;
+  const int64_t j1 = (j0 + cols_per_chunk < n) ? j0 + cols_per_chunk : n;
+  if (MODE == 2) {
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += kBlock) sx[j - j0] = x[j];
+    __syncthreads();
+  }
+  if (row + 512 * (RPT - 1) + 1 >= m) return;  // benchmark: full blocks only
+  const double* p = D + row + j0 * ld;
+  double2_t acc[NACC][RPT];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k)
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) acc[k][q] = double2_t{0.0, 0.0};
+  int64_t j = j0;
+  for (; j + U <= j1; j += U) {
+    double2_t d[U][RPT];
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) d[k][q] = load2<true>(p + k * ld + q * 512);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const double xj = (MODE == 1) ? 1.0001 : ((MODE == 2) ? sx[j - j0 + k] : x[j + k]);
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        acc[k % NACC][q].x = __builtin_fma(d[k][q].x, xj, acc[k % NACC][q].x);
+        acc[k % NACC][q].y = __builtin_fma(d[k][q].y, xj, acc[k % NACC][q].y);
+      }
+    }
+    p += U * ld;
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    double2_t s = acc[0][q];
+#pragma unroll
+    for (int k = 1; k < NACC; ++k) {
+      s.x += acc[k][q].x;
+      s.y += acc[k][q].y;
+    }
+    *reinterpret_cast<double2_t*>(ypart + static_cast<int64_t>(blockIdx.y) * ldy + row + q * 512) = s;
+  }
+}
+
+template <int U, int RPT, int MODE, int NACC = U>
+void run_exp(const double* D, int64_t m, int64_t n, int64_t ld, const double* x, double* ypart, int chunks) {
+  const int64_t cpc = ceil_div(n, chunks);
+  const int nch = static_cast<int>(ceil_div(n, cpc));
+  dim3 grid(static_cast<unsigned>(ceil_div(m, 512 * RPT)), static_cast<unsigned>(nch));
+  char name[128];
+  snprintf(name, sizeof name, "gemv_n EXP U=%d RPT=%d mode=%d nacc=%d chunks=%3d grid=%u", U, RPT, MODE, NACC, nch, grid.x * grid.y);
+  const size_t lds = MODE == 2 ? static_cast<size_t>(cpc) * 8 : 0;
+  timeit(name,
+         [&] {
+           hipLaunchKernelGGL((gemv_n_exp<U, RPT, MODE, NACC>), grid, dim3(kBlock), lds, 0, D, m, n, ld, x, ypart,
+                              round_up(m, 2), cpc);
+         },
+         8.0 * m * n);
+}
+
 template <int NR>
 void run_t(const double* D, int64_t m, int64_t n, int64_t ld, const double* v, double* gpart, int rc) {
   GemvTPlan p = gemv_t_plan(m, n, ld);
@@ -96,7 +167,13 @@ int main(int argc, char** argv) {
     GemvTPlan q = gemv_t_plan(m, n, ld);
     printf("default gemv_t plan: rows/chunk=%d chunks=%d\n", q.rows_per_chunk, q.nchunk);
   }
-  for (int chunks : {8, 16, 21, 32}) run_n<8>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {21, 32}) run_n<8>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {60, 80, 100, 125, 160, 200}) run_exp<16, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {80, 125, 160}) run_exp<16, 1, 0, 4>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {80, 125, 160}) run_exp<16, 1, 0, 1>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {80, 125, 160}) run_exp<8, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {80, 125}) run_exp<24, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {80, 125}) run_exp<8, 2, 0, 2>(D, m, n, ld, x, ypart, chunks);
   for (int rc : {2048, 4096}) run_t<1>(D, m, n, ld, v, gpart, rc);
   for (int rc : {1024, 2048}) run_t<3>(D, m, n, ld, v, gpart, rc);
   return 0;
