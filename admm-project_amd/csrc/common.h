@@ -67,6 +67,12 @@ __device__ __forceinline__ admm_double2 load2(const double* p) {
   return NT ? __builtin_nontemporal_load(q) : *q;
 }
 template <bool NT>
+__device__ __forceinline__ void store2(double* p, admm_double2 v) {
+  admm_double2* q = reinterpret_cast<admm_double2*>(p);
+  if (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+template <bool NT>
 __device__ __forceinline__ double load1(const double* p) {
   return NT ? __builtin_nontemporal_load(p) : *p;
 }

@@ -119,6 +119,7 @@ struct admm_engine {
   double *v = nullptr, *uhat = nullptr, *zprev = nullptr, *uprev = nullptr;
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
+  double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
   size_t tv_bprefix_cap = 0;
@@ -740,6 +741,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->rhs_kind = RHS_NONE;
       E_TRY(upload(e->mem, &e->s, desc->s, nn, mk, e->stream));
       E_TRY(e->mem.alloc(&e->tv_y, round_up(nn, 2)));
+      E_TRY(e->mem.alloc(&e->tv_y2, round_up(nn, 2)));
       E_TRY(e->mem.alloc(&e->tv_zB, round_up(nn, 2)));
       E_TRY(e->mem.alloc(&e->tv_uB, round_up(nn, 2)));
       break;
@@ -1437,11 +1439,26 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     ta.halo = halo;
     ta.elems = elems;
     ta.tile = tile;
+    ta.ftile = 256 * elems - 2 * halo - 4;
     ta.objevals = o.objevals;
     ta.xhist = e->xhist;
     ta.zhist = e->zhist;
     ta.uhist = e->uhist;
     ta.part = e->part;
+    // one fused launch per iteration (8 vector passes) when the halo is small; the three-kernel form otherwise
+    const bool tv_fused = tv_fused_ok(ta) && std::getenv("ADMM_HIP_TV_UNFUSED") == nullptr;
+    double* tv_part = nullptr;  // per-tile partials of the fused kernel (one column per tile)
+    if (tv_fused) {
+      ta.part_stride = round_up(ceil_div(e->n, ta.ftile), 2);
+      ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * S_COUNT * ta.part_stride));
+      ta.part = tv_part;
+    }
+    struct DevFree {
+      void* p;
+      ~DevFree() {
+        if (p) (void)hipFree(p);
+      }
+    } tv_part_guard{tv_part};
     fa.g = nullptr;
     fa.x = nullptr;
     fa.xhist = nullptr;
@@ -1454,6 +1471,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     const auto t0 = std::chrono::steady_clock::now();
     int32_t done = 0;
     bool stop_seen = false;
+    if (tv_fused) {  // the forward sweep of iteration 0; every later one is produced by the fused kernel
+      TimerScope ts(e, ADMM_K_XSOLVE);
+      ta.z = e->tv_zA;
+      ta.u = e->tv_uA;
+      ta.y = e->tv_y;
+      launch_tv_sweep(ta, false, e->ctrl, e->stream);
+    }
     while (done < N && !stop_seen) {
       const int32_t batch = (N - done < check_tv) ? N - done : check_tv;
       for (int32_t b = 0; b < batch; ++b) {
@@ -1462,13 +1486,19 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         ta.u = a_cur ? e->tv_uA : e->tv_uB;
         ta.zo = a_cur ? e->tv_zB : e->tv_zA;
         ta.uo = a_cur ? e->tv_uB : e->tv_uA;
-        {
-          TimerScope ts(e, ADMM_K_XSOLVE);
-          launch_tv_sweep(ta, false, e->ctrl, e->stream);
-          launch_tv_sweep(ta, true, e->ctrl, e->stream);
-        }
         int nblk = 1;
-        {
+        if (tv_fused) {
+          TimerScope ts(e, ADMM_K_XSOLVE);
+          ta.yin = a_cur ? e->tv_y : e->tv_y2;
+          ta.yout = a_cur ? e->tv_y2 : e->tv_y;
+          launch_tv_fused(ta, e->red, e->ctrl, e->stream);
+          fa.slots_reduced = e->red;
+        } else {
+          {
+            TimerScope ts(e, ADMM_K_XSOLVE);
+            launch_tv_sweep(ta, false, e->ctrl, e->stream);
+            launch_tv_sweep(ta, true, e->ctrl, e->stream);
+          }
           TimerScope ts(e, ADMM_K_PROX);
           launch_tv_prox(ta, e->ctrl, &nblk, e->stream);
         }

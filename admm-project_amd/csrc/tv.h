@@ -25,11 +25,21 @@ struct TvArgs {
   double* zhist;
   double* uhist;
   double* part;            // [S_COUNT][kMaxPartBlocks]
+  // fused iteration kernel (tv_fused_kernel): y ping-pong and its own tile size
+  const double* yin;       // forward-sweep result of THIS iteration (written by the previous launch)
+  double* yout;            // forward-sweep result for the NEXT iteration
+  int32_t ftile;           // owned positions per tile = 256*elems - 2*halo - 4
+  int64_t part_stride;     // fused kernel: part is [S_COUNT][part_stride], one column per tile
 };
 
 // pivots of I + rho*D'D and the launch geometry for a given rho
 int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, int* halo, int* elems, int* tile);
 void launch_tv_sweep(const TvArgs& a, bool backward, const Ctrl* ctrl, hipStream_t stream);
 void launch_tv_prox(const TvArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+// One launch per iteration: backward sweep (x) + z/u update + residual sums + the NEXT iteration's forward
+// sweep, 8 vector passes instead of 11.  Available when tv_fused_ok(a) (small halo: elems == 8).
+bool tv_fused_ok(const TvArgs& a);
+// slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced)
+void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream);
 
 }  // namespace admm

@@ -13,6 +13,8 @@
 // positions away by less than 1e-18 relative: each workgroup warms up on an H-element halo
 // instead of waiting for its predecessor -- no inter-workgroup communication, pure streaming.
 // The D / D' stencils and the rhs assembly are fused into the sweeps and the prox kernel.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "tv.h"
@@ -266,6 +268,286 @@ __global__ __launch_bounds__(kBlock) void tv_prox_kernel(TvArgs a, const Ctrl* _
     const int s = threadIdx.x;
     a.part[s * kMaxPartBlocks + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused iteration kernel.  Per tile [o0, o1) with window [w0, w1) = [o0-H-2, o1+H+2):
+//   1. stage y/b over the window, backward scan             -> x on [w0, w1-H)
+//   2. z/u update with the D stencil on [w0, o1)             -> z+, u+, t = z+ - u+, every residual sum
+//   3. r = s + rho*D'(t) on [o0-H, o1), forward scan         -> y of the NEXT iteration on [o0, o1)
+// so an iteration reads y, z, u, s and writes x, z, u, y: 8 vector passes instead of the 11 of the
+// three-kernel form, in one launch.  The halo elements are recomputed by both neighbours (2H+4 of
+// 2048 positions); their z+/u+ are bit-identical on both sides because they depend on x only through
+// positions whose backward-scan halo error is below 1e-18 relative -- the same argument as for the
+// sweeps -- and only the owner stores them.
+// A block-wide scan of y_out = c*y_in + r with zero incoming carry over `count` LDS positions
+// (pos(q) = q + (q >> 4)); COEF(q) gives the multiplier of position q.
+template <int E, typename COEF>
+__device__ __forceinline__ void tv_block_scan(double* __restrict__ lds, int count, COEF coef, double* wA, double* wB) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int q0 = tid * E;
+  double A = 1.0, B = 0.0;
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = q0 + k;
+    if (q < count) {
+      const double c = coef(q);
+      B = c * B + lds[q + (q >> 4)];
+      A = c * A;
+    }
+  }
+  double sA = A, sB = B;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double pA = __shfl_up(sA, off, 64), pB = __shfl_up(sB, off, 64);
+    if (lane >= off) {
+      sB = sA * pB + sB;
+      sA = sA * pA;
+    }
+  }
+  __syncthreads();  // wA/wB may still be read by the previous scan's tail
+  if (lane == 63) {
+    wA[wid] = sA;
+    wB[wid] = sB;
+  }
+  __syncthreads();
+  double carry = 0.0;
+  for (int w = 0; w < wid; ++w) carry = wA[w] * carry + wB[w];
+  double eA = __shfl_up(sA, 1, 64), eB = __shfl_up(sB, 1, 64);
+  if (lane == 0) {
+    eA = 1.0;
+    eB = 0.0;
+  }
+  double yin = eA * carry + eB;
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int q = q0 + k;
+    if (q < count) {
+      yin = coef(q) * yin + lds[q + (q >> 4)];
+      lds[q + (q >> 4)] = yin;
+    }
+  }
+  __syncthreads();
+}
+
+template <int E, bool NTS>
+__global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int kCap = E * kBlock;
+  double* __restrict__ L1 = lds;                        // y/b -> x (backward positions)
+  double* __restrict__ L2 = lds + kCap + (kCap >> 4) + 1;  // forward right-hand side -> next y
+  __shared__ double wA[4], wB[4];
+  __shared__ double sred[4][S_COUNT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t n = a.n, it = ctrl->iter;
+  const double rho = a.rho;
+  const double cstar = rho / a.bstar, ibstar = 1.0 / a.bstar;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+
+  {
+    const int64_t o0 = static_cast<int64_t>(blockIdx.x) * a.ftile;
+    const int64_t o1 = (o0 + a.ftile < n) ? o0 + a.ftile : n;
+    const int64_t w0 = (o0 - a.halo - 2 > 0) ? o0 - a.halo - 2 : 0;          // even
+    const int64_t w1 = (o1 + a.halo + 2 < n) ? o1 + a.halo + 2 : n;
+    const int64_t f0 = (o0 - a.halo > 0) ? o0 - a.halo : 0;                  // forward scan start (even)
+    const int count = static_cast<int>(w1 - w0);
+    const int fcount = static_cast<int>(o1 - f0);
+    auto qb = [&](int64_t i) -> int { const int q = static_cast<int>(w1 - 1 - i); return q + (q >> 4); };
+    auto qf = [&](int64_t i) -> int { const int q = static_cast<int>(i - f0); return q + (q >> 4); };
+
+    // ---- 1. y/b over the window into L1 (backward order)
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+      const int j = tid + k * kBlock;
+      const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+      const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+      double y0 = 0.0, y1 = 0.0;
+      if (live1) {
+        const admm_double2 yy = load2<true>(a.yin + i0);
+        y0 = yy.x;
+        y1 = yy.y;
+      } else if (live0) {
+        y0 = a.yin[i0];
+      }
+      if (live0) L1[qb(i0)] = y0 * ((i0 < a.nprefix) ? 1.0 / a.bprefix[i0] : ibstar);
+      if (live1) L1[qb(i0 + 1)] = y1 * ((i0 + 1 < a.nprefix) ? 1.0 / a.bprefix[i0 + 1] : ibstar);
+    }
+    __syncthreads();
+    tv_block_scan<E>(L1, count,
+                     [&](int q) { return tv_coef<true>(a, w1 - 1 - q, n, rho, cstar); }, wA, wB);
+
+    // ---- 2. z/u update (pairs, ascending), forward right-hand side into L2, owned outputs
+#pragma unroll 1
+    for (int k = 0; k < E / 2; ++k) {
+      const int j = tid + k * kBlock;
+      const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+      const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+      double zn0 = 0.0, zn1 = 0.0, un0 = 0.0, un1 = 0.0, dz0 = 0.0, dz1 = 0.0, s0 = 0.0, s1 = 0.0;
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, ax0 = 0.0, ax1 = 0.0, uo0 = 0.0, uo1 = 0.0;
+      if (live0) {
+        x0 = L1[qb(i0)];
+        if (live1) x1 = L1[qb(i0 + 1)];
+        if (i0 + 2 < w1) x2 = L1[qb(i0 + 2)];
+        double zp0, zp1 = 0.0;
+        if (live1) {
+          const admm_double2 zz = load2<true>(a.z + i0), uu = load2<true>(a.u + i0), ss = load2<true>(a.s + i0);
+          zp0 = zz.x;
+          zp1 = zz.y;
+          uo0 = uu.x;
+          uo1 = uu.y;
+          s0 = ss.x;
+          s1 = ss.y;
+        } else {
+          zp0 = a.z[i0];
+          uo0 = a.u[i0];
+          s0 = a.s[i0];
+        }
+        ax0 = (i0 + 1 < n) ? x0 - x1 : x0;  // D*x, last row is x_n (totalvariation.m:127)
+        zn0 = tv_soft(uo0 + ax0, a.thresh);  // getProxOps.m:199
+        un0 = uo0 + (ax0 + (-zn0));          // admm.m:548 (c = 0)
+        dz0 = zn0 - zp0;
+        if (live1) {
+          ax1 = (i0 + 2 < n) ? x1 - x2 : x1;
+          zn1 = tv_soft(uo1 + ax1, a.thresh);
+          un1 = uo1 + (ax1 + (-zn1));
+          dz1 = zn1 - zp1;
+        }
+      }
+      // the left neighbour (element i0-1) is the previous lane's second element
+      double znm = __shfl_up(zn1, 1, 64), unm = __shfl_up(un1, 1, 64), dzm = __shfl_up(dz1, 1, 64);
+      if (lane == 0 && live0 && i0 > w0) {  // wave boundary: recompute element i0-1
+        const double xm = L1[qb(i0 - 1)];
+        const double zpm = a.z[i0 - 1], uom = a.u[i0 - 1];
+        const double axm = xm - x0;
+        znm = tv_soft(uom + axm, a.thresh);
+        unm = uom + (axm + (-znm));
+        dzm = znm - zpm;
+      }
+      const bool left = i0 > 0;  // i0 == w0 > 0 never feeds an owned or forward position (window margin of 2)
+      if (live0) {
+        const double t0 = zn0 - un0, tm = znm - unm, t1 = zn1 - un1;
+        if (i0 >= f0 && i0 < o1) L2[qf(i0)] = s0 + rho * (left ? t0 - tm : t0);  // getProxOps.m:1047
+        if (live1 && i0 + 1 >= f0 && i0 + 1 < o1) L2[qf(i0 + 1)] = s1 + rho * (t1 - t0);
+        const bool own0 = i0 >= o0 && i0 < o1, own1 = live1 && i0 + 1 >= o0 && i0 + 1 < o1;
+        if (own0) {
+          const double r = ax0 + (-zn0), du = un0 - uo0;
+          const double g2 = left ? dz0 - dzm : dz0, g3 = left ? un0 - unm : un0;
+          acc[S_R2] += r * r;
+          acc[S_AX2] += ax0 * ax0;
+          acc[S_Z2] += zn0 * zn0;
+          acc[S_DZ2] += dz0 * dz0;
+          acc[S_U2] += un0 * un0;
+          acc[S_DU2] += du * du;
+          acc[S_G2] += g2 * g2;
+          acc[S_G3] += g3 * g3;
+          if (a.objevals) {  // totalvariation.m:134-135
+            if (i0 + 1 < n) acc[S_OBJZ] += fabs(x1 - x0);
+            const double e = x0 - s0;
+            acc[S_OBJX] += e * e;
+          }
+        }
+        if (own1) {
+          const double r = ax1 + (-zn1), du = un1 - uo1;
+          const double g2 = dz1 - dz0, g3 = un1 - un0;
+          acc[S_R2] += r * r;
+          acc[S_AX2] += ax1 * ax1;
+          acc[S_Z2] += zn1 * zn1;
+          acc[S_DZ2] += dz1 * dz1;
+          acc[S_U2] += un1 * un1;
+          acc[S_DU2] += du * du;
+          acc[S_G2] += g2 * g2;
+          acc[S_G3] += g3 * g3;
+          if (a.objevals) {
+            if (i0 + 2 < n) acc[S_OBJZ] += fabs(x2 - x1);
+            const double e = x1 - s1;
+            acc[S_OBJX] += e * e;
+          }
+        }
+        if (own0 && own1) {
+          store2<NTS>(a.x + i0, admm_double2{x0, x1});
+          store2<NTS>(a.zo + i0, admm_double2{zn0, zn1});
+          store2<NTS>(a.uo + i0, admm_double2{un0, un1});
+        } else {
+          if (own0) {
+            a.x[i0] = x0;
+            a.zo[i0] = zn0;
+            a.uo[i0] = un0;
+          }
+          if (own1) {
+            a.x[i0 + 1] = x1;
+            a.zo[i0 + 1] = zn1;
+            a.uo[i0 + 1] = un1;
+          }
+        }
+        if (a.xhist) {  // history columns start at it*n (odd-aligned for odd n): scalar stores
+          if (own0) {
+            a.xhist[it * n + i0] = x0;
+            a.zhist[it * n + i0] = zn0;
+            a.uhist[it * n + i0] = un0;
+          }
+          if (own1) {
+            a.xhist[it * n + i0 + 1] = x1;
+            a.zhist[it * n + i0 + 1] = zn1;
+            a.uhist[it * n + i0 + 1] = un1;
+          }
+        }
+      }
+    }
+    // block partials of the residual sums (before the second scan: keeps the accumulators short-lived)
+#pragma unroll
+    for (int s = 0; s < S_COUNT; ++s) {
+      const double w = wave_sum(acc[s]);
+      if (lane == 0) sred[wid][s] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < S_COUNT) {
+      const int s = threadIdx.x;
+      a.part[s * a.part_stride + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+    }
+    // ---- 3. forward scan of the next iteration's right-hand side, owned store
+    tv_block_scan<E>(L2, fcount, [&](int q) { return tv_coef<false>(a, f0 + q, n, rho, cstar); }, wA, wB);
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+      const int j = tid + k * kBlock;
+      const int64_t i0 = f0 + 2 * static_cast<int64_t>(j);
+      const bool own0 = 2 * j < fcount && i0 >= o0, own1 = 2 * j + 1 < fcount && i0 + 1 >= o0;
+      if (own0 && own1) {
+        store2<NTS>(a.yout + i0, admm_double2{L2[qf(i0)], L2[qf(i0 + 1)]});
+      } else {
+        if (own0) a.yout[i0] = L2[qf(i0)];
+        if (own1) a.yout[i0 + 1] = L2[qf(i0 + 1)];
+      }
+    }
+  }
+}
+
+// out16[s] = sum over the tiles of part[s][.], one workgroup per slot, fixed order
+__global__ __launch_bounds__(kBlock) void tv_pack_kernel(const double* __restrict__ part, int64_t stride, int32_t nblk,
+                                                         double* __restrict__ out16, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  const int s = blockIdx.x;
+  double v = 0.0;
+  for (int32_t b = threadIdx.x; b < nblk; b += kBlock) v += part[s * stride + b];
+  const double t = block_sum(v, scratch);
+  if (threadIdx.x == 0) out16[s] = t;
+}
+
+bool tv_fused_ok(const TvArgs& a) { return a.elems == 8 && a.ftile >= 512; }
+
+void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream) {
+  const int64_t ntiles = ceil_div(a.n, a.ftile);
+  constexpr int kCap = 8 * kBlock;
+  const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> 4) + 1) * sizeof(double);
+  // streaming stores once the eight vectors of an iteration cannot stay cache-resident: +7 % at n = 4096^2
+  const bool nts = stream_hint(8 * 8 * a.n);
+  if (nts) hipLaunchKernelGGL((tv_fused_kernel<8, true>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, ctrl);
+  else hipLaunchKernelGGL((tv_fused_kernel<8, false>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, ctrl);
+  hipLaunchKernelGGL(tv_pack_kernel, dim3(S_COUNT), dim3(kBlock), 0, stream, a.part, a.part_stride,
+                     static_cast<int32_t>(ntiles), slots16, ctrl);
 }
 
 // ---- host side -------------------------------------------------------------------------

@@ -347,6 +347,20 @@ def test_relax_with_svm_is_rejected(gpu):
         gpu.linearsvm(p["D"], p["ell"], p["C"], dict(relax=1.5, x0=p["x0"], z0=p["z0"], u0=p["u0"]))
 
 
+def test_tv_fused_equals_three_kernel_form_large(gpu, monkeypatch):
+    """n large enough for > 1024 tiles: the fused iteration kernel (one launch, per-tile partial sums packed
+    by a second kernel) against the forward / backward / prox kernels it replaces."""
+    n = 3_000_001  # odd: exercises the unpaired tail
+    p = gpu.synth.tv_problem(4, n)
+    o = dict(maxiters=12, domaxiters=1, objevals=1, record_history=0)
+    a = gpu.totalvariation(p["s"], p["lam"], dict(o))
+    monkeypatch.setenv("ADMM_HIP_TV_UNFUSED", "1")
+    b = gpu.totalvariation(p["s"], p["lam"], dict(o))
+    assert a["steps"] == b["steps"] == 12
+    for k in ("pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, a[k], b[k], 1e-11)
+
+
 # ---------------------------------------------------------------------------- golden fixtures
 def _opts(npz):
     o = {}
