@@ -4,6 +4,8 @@
 //   trtri     inverse of the lower factor, recursive-doubling over batched GEMMs
 // These replace MATLAB's `D'*D`, `chol` and the implicit factor inverse used by `\`.
 // MFMA is used here and only here (north_star: "MFMA used only for the one-time AtA build").
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace admm {
@@ -33,10 +35,76 @@ struct GemmArgs {
   int lower_only;            // skip tiles strictly above the diagonal (square C)
 };
 
+// One 128 x 16 operand tile, element (t, k) of op(X):
+//   KMAJOR storage (contiguous along k): X[k + t*ld]  -- op(A) with transA, op(B) without transB
+//   TMAJOR storage (contiguous along t): X[t + k*ld]
+// Each thread moves 4 pairs (16 bytes each): global -> registers (tile_load, issued one k-step ahead of the
+// MFMAs that consume it) and registers -> LDS (tile_store), LDS layout S[k*BTP + t].
+// FAST: the whole tile lies inside the matrix and pairs are 16-byte aligned -> no guards at all.
+template <bool KMAJOR, bool FAST>
+__device__ __forceinline__ void tile_load(const double* __restrict__ X, int64_t ld, int64_t t0, int64_t k0,
+                                          int64_t tvalid, int64_t kvalid, int tid, double2_t (&r)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (KMAJOR) {
+      const int kp = (tid & 7) * 2, tt = (tid >> 3) + s * 32;
+      const int64_t gt = t0 + tt, gk = k0 + kp;
+      const double* p = X + gk + gt * ld;
+      if (FAST) {
+        r[s] = *reinterpret_cast<const double2_t*>(p);
+      } else {
+        double2_t v{0.0, 0.0};
+        if (gt < tvalid) {
+          if (gk < kvalid) v.x = p[0];
+          if (gk + 1 < kvalid) v.y = p[1];
+        }
+        r[s] = v;
+      }
+    } else {
+      const int tp = (tid & 63) * 2, kk = (tid >> 6) + s * 4;
+      const int64_t gt = t0 + tp, gk = k0 + kk;
+      const double* p = X + gt + gk * ld;
+      if (FAST) {
+        r[s] = *reinterpret_cast<const double2_t*>(p);
+      } else {
+        double2_t v{0.0, 0.0};
+        if (gk < kvalid) {
+          if (gt < tvalid) v.x = p[0];
+          if (gt + 1 < tvalid) v.y = p[1];
+        }
+        r[s] = v;
+      }
+    }
+  }
+}
+
+// LDS image of a tile: element (k, t) at S[k*BMP + (t ^ swz(k))], swz(k) = ((k >> 1) & 3) * 8.
+// BMP = 16 mod 32 makes the MFMA operand reads (4 k-rows x 16 consecutive t per wave) exactly 2-way, which
+// is the floor for 512 bytes; the XOR spreads the TRANSPOSED stores of the k-major case (8 lanes hold 8
+// different even k of one t) over all banks instead of one (8-way conflict without it) and only permutes
+// 8-aligned groups, so the read pattern keeps its bank set.
+__device__ __forceinline__ int swz(int k) { return ((k >> 1) & 3) << 3; }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(double* __restrict__ S, int tid, const double2_t (&r)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (KMAJOR) {
+      const int kp = (tid & 7) * 2, tt = (tid >> 3) + s * 32;
+      S[kp * BMP + (tt ^ swz(kp))] = r[s].x;        // swz(kp) == swz(kp + 1): kp is even
+      S[(kp + 1) * BMP + (tt ^ swz(kp))] = r[s].y;
+    } else {
+      const int tp = (tid & 63) * 2, kk = (tid >> 6) + s * 4;
+      *reinterpret_cast<double2_t*>(&S[kk * BMP + (tp ^ swz(kk))]) = r[s];
+    }
+  }
+}
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(kBlock) void gemm_f64_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double As[BK * BMP];
-  __shared__ __attribute__((aligned(16))) double Bs[BK * BNP];
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_f64_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[2][BK * BMP];  // double-buffered: one barrier per k-step
+  __shared__ __attribute__((aligned(16))) double Bs[2][BK * BNP];
+  static_assert(BMP == BNP, "tile_store assumes one row stride");
   const int bz = blockIdx.z;
   const int64_t i0 = static_cast<int64_t>(blockIdx.x) * BM;
   const int64_t j0 = static_cast<int64_t>(blockIdx.y) * BN;
@@ -47,6 +115,13 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(GemmArgs g) {
   const int64_t a_rows = g.a_rows - bz * g.shrinkA_r, a_cols = g.a_cols - bz * g.shrinkA_c;
   const int64_t b_rows = g.b_rows - bz * g.shrinkB_r, b_cols = g.b_cols - bz * g.shrinkB_c;
   const int64_t c_rows = g.c_rows - bz * g.shrinkC_r, c_cols = g.c_cols - bz * g.shrinkC_c;
+  // valid extents of op(A) (M x K) and op(B) (K x N) in (tile, k) coordinates
+  const int64_t a_t = TA ? (g.M < a_cols ? g.M : a_cols) : (g.M < a_rows ? g.M : a_rows);
+  const int64_t a_k = TA ? (g.K < a_rows ? g.K : a_rows) : (g.K < a_cols ? g.K : a_cols);
+  const int64_t b_t = TB ? (g.N < b_rows ? g.N : b_rows) : (g.N < b_cols ? g.N : b_cols);
+  const int64_t b_k = TB ? (g.K < b_cols ? g.K : b_cols) : (g.K < b_rows ? g.K : b_rows);
+  const bool a_in = (i0 + BM <= a_t) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_in = (j0 + BN <= b_t) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((g.ldb & 1) == 0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -59,93 +134,64 @@ __global__ __launch_bounds__(kBlock) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
 
-  for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
-    // ---- stage op(A)[i0:i0+BM, k0:k0+BK] as As[k][i]
-    if (!TA) {
-      // A stored M x K: contiguous along i.  thread -> (pair of rows, k)
-#pragma unroll
-      for (int s = 0; s < (BM * BK / 2) / kBlock; ++s) {
-        const int idx = tid + s * kBlock;  // 0 .. 1023
-        const int ip = (idx & 63) * 2, kk = idx >> 6;
-        const int64_t gi = i0 + ip, gk = k0 + kk;
-        double2_t v{0.0, 0.0};
-        if (gk < g.K && gk < a_cols) {
-          const double* p = A + gi + gk * g.lda;
-          if (gi < g.M && gi < a_rows) v.x = p[0];
-          if (gi + 1 < g.M && gi + 1 < a_rows) v.y = p[1];
-        }
-        As[kk * BMP + ip] = v.x;
-        As[kk * BMP + ip + 1] = v.y;
-      }
-    } else {
-      // A stored K x M: contiguous along k.  thread -> (pair of k, i)
-#pragma unroll
-      for (int s = 0; s < (BM * BK / 2) / kBlock; ++s) {
-        const int idx = tid + s * kBlock;
-        const int kp = (idx & 7) * 2, ii = idx >> 3;  // ii 0..127
-        const int64_t gi = i0 + ii, gk = k0 + kp;
-        double2_t v{0.0, 0.0};
-        if (gi < g.M && gi < a_cols) {
-          const double* p = A + gk + gi * g.lda;
-          if (gk < g.K && gk < a_rows) v.x = p[0];
-          if (gk + 1 < g.K && gk + 1 < a_rows) v.y = p[1];
-        }
-        As[kp * BMP + ii] = v.x;
-        As[(kp + 1) * BMP + ii] = v.y;
-      }
-    }
-    // ---- stage op(B)[k0:k0+BK, j0:j0+BN] as Bs[k][j]
-    if (!TB) {
-      // B stored K x N: contiguous along k
-#pragma unroll
-      for (int s = 0; s < (BN * BK / 2) / kBlock; ++s) {
-        const int idx = tid + s * kBlock;
-        const int kp = (idx & 7) * 2, jj = idx >> 3;
-        const int64_t gj = j0 + jj, gk = k0 + kp;
-        double2_t v{0.0, 0.0};
-        if (gj < g.N && gj < b_cols) {
-          const double* p = B + gk + gj * g.ldb;
-          if (gk < g.K && gk < b_rows) v.x = p[0];
-          if (gk + 1 < g.K && gk + 1 < b_rows) v.y = p[1];
-        }
-        Bs[kp * BNP + jj] = v.x;
-        Bs[(kp + 1) * BNP + jj] = v.y;
-      }
-    } else {
-      // B stored N x K: contiguous along j
-#pragma unroll
-      for (int s = 0; s < (BN * BK / 2) / kBlock; ++s) {
-        const int idx = tid + s * kBlock;
-        const int jp = (idx & 63) * 2, kk = idx >> 6;
-        const int64_t gj = j0 + jp, gk = k0 + kk;
-        double2_t v{0.0, 0.0};
-        if (gk < g.K && gk < b_cols) {
-          const double* p = B + gj + gk * g.ldb;
-          if (gj < g.N && gj < b_rows) v.x = p[0];
-          if (gj + 1 < g.N && gj + 1 < b_rows) v.y = p[1];
-        }
-        Bs[kk * BNP + jp] = v.x;
-        Bs[kk * BNP + jp + 1] = v.y;
-      }
-    }
+  // Pipeline per k-step: the MFMAs of tile k run from LDS buffer `cur` while (a) tile k+1 moves from registers
+  // into the other LDS buffer and (b) the global loads of tile k+2 are in flight -- both issued between the
+  // MFMA groups, so the matrix pipe (64 cycles per f64 MFMA) hides them; one barrier per k-step.  The loop
+  // body is branch-free (loads past the end are clamped onto the last tile and never consumed): with control
+  // flow inside it the register allocator shuttles the 128 accumulator registers between AGPRs and VGPRs on
+  // every k-step -- and it still does so for the loop-carried values unless the MFMAs take their C/D operand
+  // in VGPRs (this file is built with -mllvm -amdgpu-mfma-vgpr-form, see the Makefile: at one wave per SIMD
+  // the 512-entry unified register file has room for the accumulators and everything else).  FAST = interior tile, aligned, K a multiple of BK: no guards on the loads.
+  auto mainloop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    double2_t ra[4], rb[4];
+    const int64_t klast = (g.K > BK) ? ((g.K - 1) / BK) * BK : 0;  // first k of the last tile
+    auto load = [&](int64_t k0) {
+      const int64_t kc = k0 < klast ? k0 : klast;
+      tile_load<TA, FAST>(A, g.lda, i0, kc, a_t, a_k, tid, ra);
+      tile_load<!TB, FAST>(B, g.ldb, j0, kc, b_t, b_k, tid, rb);
+    };
+    load(0);
+    tile_store<TA>(As[0], tid, ra);
+    tile_store<!TB>(Bs[0], tid, rb);
     __syncthreads();
+    load(BK);
+    int cur = 0;
+#pragma unroll 1
+    for (int64_t k0 = 0; k0 < g.K; k0 += BK, cur ^= 1) {
+      const double* __restrict__ Ac = As[cur];
+      const double* __restrict__ Bc = Bs[cur];
+      // operand fragments are read one sub-step ahead of the MFMAs that use them
+      double af[2][4], bf[2][4];
+      auto read_frag = [&](int slot, int kk) {
+        const int krow = kk + lq, sw = swz(krow);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 4) {
-      double af[4], bf[4];
+        for (int t = 0; t < 4; ++t) {
+          af[slot][t] = Ac[krow * BMP + ((wi + t * 16 + l15) ^ sw)];
+          bf[slot][t] = Bc[krow * BNP + ((wj + t * 16 + l15) ^ sw)];
+        }
+      };
+      read_frag(0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        af[t] = As[(kk + lq) * BMP + wi + t * 16 + l15];
-        bf[t] = Bs[(kk + lq) * BNP + wj + t * 16 + l15];
+      for (int kk = 0; kk < BK; kk += 4) {
+        const int slot = (kk >> 2) & 1;
+        if (kk + 4 < BK) read_frag(slot ^ 1, kk + 4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[slot][a], bf[slot][b], acc[a][b], 0, 0, 0);
+        if (kk == 0) {  // tile k+1: registers -> the other buffer (nobody reads it during this step)
+          tile_store<TA>(As[cur ^ 1], tid, ra);
+          tile_store<!TB>(Bs[cur ^ 1], tid, rb);
+        }
+        if (kk == 4) load(k0 + 2 * BK);
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+      __syncthreads();
     }
-    __syncthreads();
-  }
-
+  };
+  if (a_in && b_in && (g.K % BK) == 0 && g.K <= a_k && g.K <= b_k) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
   // ---- epilogue.  f64 16x16 C/D map: col = lane&15, row = (lane>>4) + 4*reg.
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
