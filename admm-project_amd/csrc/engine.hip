@@ -303,7 +303,9 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
       if (p == X) p = nullptr;
     e->planSq = gemv_t_plan(nF, nF, ldM);
     ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
-    e->sy_half = std::getenv("ADMM_HIP_FULL_SYMV") == nullptr;
+    // lower-triangle form only where bandwidth matters: a 128x128 tile is 32 dependent panel steps of one
+    // wave, so for small n the latency of that chain exceeds the whole column-dot GEMV (n = 400: 18k -> 2xk it/s)
+    e->sy_half = std::getenv("ADMM_HIP_FULL_SYMV") == nullptr && nF >= 1536;
     if (e->sy_half) {
       ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
       ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));
@@ -1558,25 +1560,22 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
     if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
   }
-  // One iteration = a fixed sequence of launches with iteration-independent arguments (the
-  // iteration index lives in ctrl->iter), so a batch of iterations is captured ONCE into a
-  // hipGraph and replayed: launch-bound problems (SVM 6000x400, small lasso, the TRSV x-solve
-  // with its 2*n/64 launches) stop paying ~3.5 us of host launch time per kernel.  Iterations
-  // past a stop condition or past maxiters are no-ops on the device, so whole batches are replayed.
-  // Not used when collectives sit inside the iteration, for the CG x-solve (which polls the device
-  // between inner iterations), or with event timing on (hipEventElapsedTime rejects events that were
-  // recorded by graph nodes on ROCm 7.2: "invalid resource handle").
-  // Only worth it in the launch-bound regime (matrices up to 256 MB): capture + instantiate cost
-  // about a millisecond, which a GPU-bound loop (8 GB per pass) never earns back.
+  // One iteration = a fixed sequence of launches with iteration-independent arguments (the iteration
+  // index lives in ctrl->iter), and iterations past a stop condition or past maxiters are no-ops on the
+  // device, so a batch of iterations CAN be captured once into a hipGraph and replayed.  Measured on
+  // MI355X / ROCm 7.x (profiles/svm_bench.py, profiles/trsv_graph_bench.py) replay is never faster than
+  // eager launches on one stream -- SVM 6000x400: 23.0k vs 23.9k it/s; lasso 2000x512 with the 16-launch
+  // TRSV x-solve: 3.7k vs 4.9k -- so eager is the default and ADMM_HIP_GRAPH=1 opts in.  Never used when
+  // collectives or host callbacks sit inside the iteration, for the CG x-solve (which polls the device
+  // between inner iterations), with event timing on (hipEventElapsedTime rejects events recorded by graph
+  // nodes: "invalid resource handle"), or under rocprofv3 (which segfaults inside hipGraphLaunch).
   const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
-  // rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch when its tool library is preloaded:
-  // fall back to eager launches whenever a rocprofiler tool is attached to the process.
   const char* preload = std::getenv("LD_PRELOAD");
   const bool profiler_attached = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
                                  (preload && std::strstr(preload, "rocprof") != nullptr);
-  const bool use_graph = !sharded && e->profiling == 0 && e->xsolve != ADMM_XSOLVE_CG && !profiler_attached &&
-                         heavy <= (int64_t{32} << 20) && std::getenv("ADMM_HIP_NO_GRAPH") == nullptr &&
-                         !e->xcb && !e->zcb && !e->ocb;  // host callbacks cannot be captured
+  const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 &&
+                         e->xsolve != ADMM_XSOLVE_CG && !profiler_attached && heavy <= (int64_t{32} << 20) &&
+                         !e->xcb && !e->zcb && !e->ocb;
   auto enqueue_iteration = [&]() -> int {
     {
       const double* axsrc;

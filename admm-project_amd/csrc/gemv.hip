@@ -269,27 +269,37 @@ void launch_gemv_t(const GemvTPlan& p, const double* D, const double* v0, const 
 #undef ADMM_LAUNCH_GEMV_T
 }
 
+// g[r][j] = sum_c gpart[c][r][j].  Workgroup = 16 consecutive columns x 16 slots that split the chunk
+// index; the slots are combined through LDS in a fixed order (bitwise reproducible).  A serial loop over
+// the chunks per column (the first version) cost 30 us at 235 chunks -- a fifth of an SVM 60000x400 iteration.
 __global__ __launch_bounds__(kBlock) void sum_partials_t_kernel(const double* __restrict__ gpart, int32_t nchunk,
                                                                 int nrhs, int64_t ldg, int64_t n,
                                                                 double* __restrict__ g, int64_t ldg_out,
                                                                 const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
-  const int64_t total = n * nrhs;
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; t < total;
-       t += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int r = static_cast<int>(t / n);
-    const int64_t j = t - static_cast<int64_t>(r) * n;
-    double s = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) s += gpart[(static_cast<int64_t>(c) * nrhs + r) * ldg + j];
-    g[r * ldg_out + j] = s;
+  __shared__ double sacc[16][17];
+  const int jj = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int64_t tiles_per_rhs = (n + 15) / 16;
+  const int r = static_cast<int>(blockIdx.x / tiles_per_rhs);
+  const int64_t j = (blockIdx.x - static_cast<int64_t>(r) * tiles_per_rhs) * 16 + jj;
+  double s = 0.0;
+  if (j < n) {
+#pragma unroll 4
+    for (int32_t c = slot; c < nchunk; c += 16) s += gpart[(static_cast<int64_t>(c) * nrhs + r) * ldg + j];
+  }
+  sacc[slot][jj] = s;
+  __syncthreads();
+  if (slot == 0 && j < n) {
+    double t = sacc[0][jj];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sacc[k][jj];
+    g[r * ldg_out + j] = t;
   }
 }
 
 void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,
                            const Ctrl* ctrl, hipStream_t stream) {
-  int64_t blocks = ceil_div(p.n * nrhs, kBlock);
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
+  const int64_t blocks = ceil_div(p.n, 16) * nrhs;
   hipLaunchKernelGGL(sum_partials_t_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, gpart,
                      p.nchunk, nrhs, p.ldg, p.n, g, ldg_out, ctrl);
 }
