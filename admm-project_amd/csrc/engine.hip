@@ -323,9 +323,8 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 void solve_factor(admm_engine* e, const double* y, double* out) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
     launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream);
-  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    launch_gemv_t(e->planSq, e->Minv, y, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
-    launch_sum_partials(e->partSq, e->planSq.nchunk, e->planSq.ldg, e->nF, out, e->ctrl, e->stream);
+  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
+    launch_symv_small(e->Minv, e->nF, e->ldMinv, y, out, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
   }
@@ -1009,11 +1008,8 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
 static void factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
     launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
-  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // x = Minv*y, summed inside the prox kernel
-    launch_gemv_t(e->planSq, e->Minv, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
-    *axsrc = e->partSq;
-    *naxpart = e->planSq.nchunk;
-    *axld = e->planSq.ldg;
+  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
+    launch_symv_small(e->Minv, e->nF, e->ldMinv, e->rhs, e->x, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
   }

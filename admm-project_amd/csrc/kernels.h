@@ -46,6 +46,9 @@ struct SymvPlan {
   size_t tpart_elems() const { return static_cast<size_t>(ntile) * ldp; }
 };
 SymvPlan symv_plan(int64_t n);
+// y = M*x for a small symmetric M (full storage, ld even, 16-byte aligned; x 16-byte aligned): one wave per column
+void launch_symv_small(const double* M, int64_t n, int64_t ld, const double* x, double* y, const Ctrl* ctrl,
+                       hipStream_t stream);
 void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
                        double* y, const Ctrl* ctrl, hipStream_t stream);
 

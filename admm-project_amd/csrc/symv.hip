@@ -175,6 +175,37 @@ __global__ __launch_bounds__(kBlock) void symv_reduce_kernel(const double* __res
   }
 }
 
+// Small symmetric M (n < ~1500: cache-resident, latency-bound): y_j = column j of M dot x, one wave per
+// column, result written directly (no partials, no second kernel).  n = 400: 3 us against 12 + 4 us for the
+// chunked column-dot GEMV + its reduction.
+__global__ __launch_bounds__(kBlock) void symv_small_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
+                                                            const double* __restrict__ x, double* __restrict__ y,
+                                                            const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 4 + wid;
+  if (j >= n) return;
+  const double* __restrict__ col = M + j * ld;  // ld is even and M 16-byte aligned: pairs are aligned
+  const int64_t npairs = n >> 1;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t p = lane; p < npairs; p += 64) {
+    const double2_t m2 = *reinterpret_cast<const double2_t*>(col + 2 * p);
+    const double2_t x2 = *reinterpret_cast<const double2_t*>(x + 2 * p);
+    a0 = __builtin_fma(m2.x, x2.x, a0);
+    a1 = __builtin_fma(m2.y, x2.y, a1);
+  }
+  double s = a0 + a1;
+  if ((n & 1) && lane == 0) s = __builtin_fma(col[n - 1], x[n - 1], s);
+  s = wave_sum(s);
+  if (lane == 0) y[j] = s;
+}
+
+void launch_symv_small(const double* M, int64_t n, int64_t ld, const double* x, double* y, const Ctrl* ctrl,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(symv_small_kernel, dim3(static_cast<unsigned>(ceil_div(n, 4))), dim3(kBlock), 0, stream, M, n,
+                     ld, x, y, ctrl);
+}
+
 SymvPlan symv_plan(int64_t n) {
   SymvPlan p{};
   p.n = n;
