@@ -240,7 +240,7 @@ def main():
             tj = json.load(fh)
         try:
             traffic = sum(tj[k]["fetch_bytes_per_launch"] + tj[k]["write_bytes_per_launch"]
-                          for k in ("admm::symv_lower_kernel", "admm::symv_reduce_kernel"))
+                          for k in ("admm::symv_lower_kernel<true>", "admm::symv_reduce_kernel"))
         except KeyError:
             traffic = None
     xs_avg_ms = xs_ms / max(1, xs_cnt)
