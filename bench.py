@@ -173,6 +173,55 @@ def other_configs(ap, L, device, steps):
     return res
 
 
+def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out):
+    """The A-streaming legs (lad.m, matrix-free lasso) on the same D, s, and configs 3 / 5 at N = 1."""
+    # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
+    # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
+    # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
+    lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
+    k2 = max(5, a.steps // 8)
+    timed_run(lad, dist, 2)
+    lad.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
+    dt2, _ = timed_run(lad, dist, k2)
+    lad.set_profiling(False)
+    gn_ms, gn_cnt = lad.kernel_time(L.K_GEMV_N)
+    gt_ms, gt_cnt = lad.kernel_time(L.K_GEMV_T)
+    pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
+    rows_local = hi - lo
+    gbs = 16.0 * rows_local * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    out["a_streaming"] = {"workload": "lad.m on the same D,s: D*x + D'*[s+z-u, dz, u] per iteration (16mn B), "
+                                      "transpose reduction over the row shards",
+                          "iters_per_s": k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
+                          "AtAx_unit_ms": pair_ms, "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                          "gemv_n_avg_ms": gn_ms / max(1, gn_cnt), "gemv_t_avg_ms": gt_ms / max(1, gt_cnt),
+                          "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
+    lad.close()
+
+    # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
+    # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
+    mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
+                   comm=comm, cg_tol=1e-10)
+    k3 = max(3, a.steps // 40)
+    timed_run(mf, dist, 1, rho=rho)
+    mf.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
+    dt3, _ = timed_run(mf, dist, k3, rho=rho)
+    mf.set_profiling(False)
+    inner = float(mf.fetch(L.F_CG_ITERS, 1)[0])
+    gn_ms, gn_cnt = mf.kernel_time(L.K_GEMV_N)
+    gt_ms, gt_cnt = mf.kernel_time(L.K_GEMV_T)
+    pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
+    gbs = 16.0 * (hi - lo) * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    out["matrix_free"] = {"workload": "lasso, x-update by warm-started CG on (D'D + rho I), tol 1e-10",
+                          "iters_per_s": k3 / dt3, "ms_per_step": dt3 / k3 * 1e3,
+                          "inner_iters_per_step": inner / k3, "AtAx_unit_ms": pair_ms,
+                          "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                          "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
+    mf.close()
+
+    if world == 1:
+        out["other_configs"] = other_configs(ap, L, local, a.steps)
+
+
 def main():
     a = parse()
     rank, world, local, dist = dist_setup(a.one_gpu)
@@ -282,51 +331,10 @@ def main():
     eng.close()
 
     if not a.no_extras:
-        # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
-        # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
-        # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
-        lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
-        k2 = max(5, a.steps // 8)
-        timed_run(lad, dist, 2)
-        lad.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
-        dt2, _ = timed_run(lad, dist, k2)
-        lad.set_profiling(False)
-        gn_ms, gn_cnt = lad.kernel_time(L.K_GEMV_N)
-        gt_ms, gt_cnt = lad.kernel_time(L.K_GEMV_T)
-        pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
-        rows_local = hi - lo
-        gbs = 16.0 * rows_local * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
-        out["a_streaming"] = {"workload": "lad.m on the same D,s: D*x + D'*[s+z-u, dz, u] per iteration (16mn B), "
-                                          "transpose reduction over the row shards",
-                              "iters_per_s": k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
-                              "AtAx_unit_ms": pair_ms, "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
-                              "gemv_n_avg_ms": gn_ms / max(1, gn_cnt), "gemv_t_avg_ms": gt_ms / max(1, gt_cnt),
-                              "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
-        lad.close()
-
-        # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
-        # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
-        mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
-                       comm=comm, cg_tol=1e-10)
-        k3 = max(3, a.steps // 40)
-        timed_run(mf, dist, 1, rho=rho)
-        mf.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
-        dt3, _ = timed_run(mf, dist, k3, rho=rho)
-        mf.set_profiling(False)
-        inner = float(mf.fetch(L.F_CG_ITERS, 1)[0])
-        gn_ms, gn_cnt = mf.kernel_time(L.K_GEMV_N)
-        gt_ms, gt_cnt = mf.kernel_time(L.K_GEMV_T)
-        pair_ms = gn_ms / max(1, gn_cnt) + gt_ms / max(1, gt_cnt)
-        gbs = 16.0 * (hi - lo) * n / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
-        out["matrix_free"] = {"workload": "lasso, x-update by warm-started CG on (D'D + rho I), tol 1e-10",
-                              "iters_per_s": k3 / dt3, "ms_per_step": dt3 / k3 * 1e3,
-                              "inner_iters_per_step": inner / k3, "AtAx_unit_ms": pair_ms,
-                              "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
-                              "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
-        mf.close()
-
-    if not a.no_extras and world == 1:
-        out["other_configs"] = other_configs(ap, L, local, a.steps)
+        try:
+            side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
+        except Exception as exc:  # the side measurements must never cost the headline line
+            out["extras_error"] = repr(exc)
 
     if not a.no_cpu_baseline and world == 1 and rank == 0:
         out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
