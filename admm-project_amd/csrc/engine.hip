@@ -58,6 +58,7 @@ struct admm_comm;  // comm.hip
 namespace admm {
 int comm_allreduce_device(admm_comm* comm, double* buf, size_t count, hipStream_t stream);
 int comm_nranks(admm_comm* comm);
+int comm_rank(admm_comm* comm);
 }  // namespace admm
 
 struct admm_engine {
@@ -309,6 +310,9 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
     if (e->sy_half) {
       ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
       ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));
+      // zero once: with the tiles split over ranks, the slots of foreign tiles are never written
+      ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * e->planSy.npart_elems(), e->stream));
+      ADMM_HIP_TRY(hipMemsetAsync(e->syT, 0, sizeof(double) * e->planSy.tpart_elems(), e->stream));
     }
   } else {
     double* dv = e->dinv;
@@ -318,16 +322,29 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
   return ADMM_OK;
 }
 
+// x = Minv*y from the lower triangle; on a sharded engine every rank streams 1/N of the tiles and ONE
+// all-reduce of n doubles assembles x (the only per-iteration collective of the cached-factor lasso loop)
+static int symv_apply(admm_engine* e, const double* y, double* out) {
+  const int nr = e->comm ? comm_nranks(e->comm) : 1;
+  if (nr > 1) {
+    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
+    return comm_allreduce_device(e->comm, out, static_cast<size_t>(e->nF), e->stream);
+  }
+  launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream);
+  return ADMM_OK;
+}
+
 // out = F^-T F^-1 y  (out has nF elements).  For the INVERSE path the result is left as
 // chunk partials in partSq unless `materialize`.
-void solve_factor(admm_engine* e, const double* y, double* out) {
+int solve_factor(admm_engine* e, const double* y, double* out) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
-    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream);
+    return symv_apply(e, y, out);
   } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
     launch_symv_small(e->Minv, e->nF, e->ldMinv, y, out, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
   }
+  return ADMM_OK;
 }
 
 
@@ -950,7 +967,7 @@ static int cg_solve(admm_engine* e, const double* y) {
   return ADMM_OK;
 }
 
-static void factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld);
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld);
 
 // one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
 static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
@@ -970,12 +987,12 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
-        factor_x_update(e, axsrc, naxpart, axld);
+        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
       } else {
         // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
         launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
         launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, e->ctrl, e->stream);
-        solve_factor(e, e->tmpA, e->tmpB);
+        ADMM_TRY(solve_factor(e, e->tmpA, e->tmpB));
         launch_gemv_t(e->planDT, e->D, e->tmpB, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
         const double rho = e->last_opts.rho;
         launch_combine(e->partDT, e->planDT.nchunk, e->planDT.ldg, -1.0 / (rho * rho), e->rhs, 1.0 / rho, nullptr,
@@ -984,7 +1001,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       break;
     case ADMM_PROB_QP_BOUNDED:  // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
     case ADMM_PROB_MODEL:
-      factor_x_update(e, axsrc, naxpart, axld);
+      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
       break;
     case ADMM_PROB_LINEARPROGRAM:
     case ADMM_PROB_QP_STANDARD:  // x = K*y + k0: the KKT solve of getProxOps.m:1363 / 1410, reduced once
@@ -998,21 +1015,22 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
                      e->stream);
       break;
     default:  // LAD / Huber / SVM: rhs already holds D'*(c + z - u) (row 0 of g)
-      solve_factor(e, e->g, e->x);
+      ADMM_TRY(solve_factor(e, e->g, e->x));
       break;
   }
   return ADMM_OK;
 }
 
 // the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
-static void factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
-    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream);
+    return symv_apply(e, e->rhs, e->x);
   } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
     launch_symv_small(e->Minv, e->nF, e->ldMinv, e->rhs, e->x, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
   }
+  return ADMM_OK;
 }
 
 int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,

@@ -123,9 +123,16 @@ template <bool NT>
 __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
                                                            const double* __restrict__ x, double* __restrict__ npart,
                                                            double* __restrict__ tpart, int64_t ldp,
+                                                           int32_t part_rank, int32_t part_count,
                                                            const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
   if (blockIdx.x < blockIdx.y) return;  // tile strictly above the diagonal
+  // multi-GPU: the lower-triangle tiles are dealt round-robin to the ranks; the slots of the tiles a rank
+  // does not own stay at their initial zero and the partial results are summed by one all-reduce of n doubles
+  if (part_count > 1 &&
+      static_cast<int32_t>((blockIdx.x * (blockIdx.x + 1u) / 2u + blockIdx.y) % static_cast<unsigned>(part_count)) !=
+          part_rank)
+    return;
   const int lane = threadIdx.x & 63;
   const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyTile;  // wave's first row
   const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyTile;
@@ -216,12 +223,14 @@ SymvPlan symv_plan(int64_t n) {
 }
 
 void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
-                       double* y, const Ctrl* ctrl, hipStream_t stream) {
+                       double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank, int part_count) {
   dim3 grid(static_cast<unsigned>(p.ntile), static_cast<unsigned>(p.ntile));
   if (stream_hint(4 * p.npad * p.npad))
-    hipLaunchKernelGGL(symv_lower_kernel<true>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp, ctrl);
+    hipLaunchKernelGGL(symv_lower_kernel<true>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
+                       part_rank, part_count, ctrl);
   else
-    hipLaunchKernelGGL(symv_lower_kernel<false>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp, ctrl);
+    hipLaunchKernelGGL(symv_lower_kernel<false>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
+                       part_rank, part_count, ctrl);
   const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
                      p.ldp, p.n, p.ntile, y, ctrl);
