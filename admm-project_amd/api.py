@@ -321,7 +321,15 @@ def admm(xminf, zming, options):
         raise NotImplementedError("options.adaptive (experimental in the reference, admm.m:724-741) is not supported")
     par = _setopt(options, "parallel", "none")
     if par in ("xminf", "zming", "both"):
-        raise NotImplementedError("options.parallel in-prox slicing is replaced by row-sharded engines")
+        # admm.m:343-468 (parproxf / parproxg): the prox is evaluated slice by slice on the pool's workers and
+        # the pieces are concatenated.  For the separable z-prox of the linear SVM that is the computation the
+        # fused kernel already does over all rows at once (and the transpose reduction W = sum D_i'D_i of
+        # unwrappedadmm.m:96-141 is the engine's cached factor of D'D), so the option only has to be validated.
+        if prob.kind != "linearsvm":
+            raise NotImplementedError("options.parallel in-prox slicing is engine-native for the linear SVM / "
+                                      "unwrapped ADMM only; other problems shard rows with parallel.Comm")
+        from .errorcheck import slicemaker
+        slicemaker(options.get("slices", 0), int(options.get("workers", 1)), prob.expect["nB"])  # errorcheck.m:216-267
 
     quiet = _setopt(options, "quiet", 1)
     rho = float(_setopt(options, "rho", 1.0))

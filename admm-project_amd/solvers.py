@@ -128,7 +128,10 @@ def unwrappedadmm(zming, D, options=None):
     D = _matrix(D, "D")
     m, n = D.shape
     if options.get("parallel", "none") in ("xminf", "zming", "both"):
-        raise NotImplementedError("row-sharded unwrapped ADMM: use admm_project_amd.parallel")
+        # unwrappedadmm.m:45-74: the x-update becomes the transpose reduction (W = sum D_i'D_i, d = sum D_i'(z_i-u_i),
+        # x = W\d: the engine's cached factor of D'D does exactly that) and admm slices the z-prox ('zming').
+        options["slices"] = slicemaker(options.get("slices", 0), int(options.get("workers", 1)), m)
+        options["parallel"] = "zming" if options["parallel"] == "both" else "none"
     prob = zming.problem
     from .api import ProxOp
     xminf = ProxOp(prob, "x")
@@ -158,6 +161,10 @@ def linearsvm(D, ell, C, options=None):
         raise ValueError("Product ell*D is not possible; sizes incompatible!")
     loss = options.get("lossfunction", "hinge")  # linearsvm.m:154-158
     args = _engine_args(options, dict(D=D, Dt=None, ell=ell, C=C, lossfunction=loss))
+    if options.get("parallel", "none") in ("both", "zming", "xminf"):  # linearsvm.m:170-205
+        options["parallel"] = "both"
+        args["slices"] = options["slices"] = slicemaker(options.get("slices", 0), int(options.get("workers", 1)),
+                                                         D.shape[0])
     _, minz, _ = getproxops("LinearSVM", args)
     options["obj"] = _ENGINE_OBJ  # linearsvm.m:231-237
     results = unwrappedadmm(minz, D, options)

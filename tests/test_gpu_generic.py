@@ -229,3 +229,15 @@ def test_altproxg_handle(gpu):
     ref = S.linearprogram(p["b"], p["D"], p["s"], dict(o))
     got = gpu.linearprogram(p["b"], p["D"], p["s"], dict(o, altproxg=lambda x, z, u, rho: torch.clamp(x + u, min=0.0)))
     _compare(got, ref, tol=1e-7)
+
+
+def test_linearsvm_in_prox_slicing_options(gpu):
+    """linearsvm.m:170-205 / unwrappedadmm.m:45-141 with options.parallel: slices + transpose reduction give the
+    iterates of the unsliced run; the oracle executes the sliced closures literally (4 workers)."""
+    p = gpu.synth.svm_problem(0, 90, 111)
+    o = dict(objevals=1, x0=p["x0"], z0=p["z0"], u0=p["u0"], parallel="both")
+    got = gpu.linearsvm(p["D"], p["ell"], p["C"], dict(o, workers=4))
+    ref = S.linearsvm(p["D"], p["ell"], p["C"], dict(o), workers=4)
+    _compare(got, ref, tol=1e-7)
+    with pytest.raises(ValueError, match="slices does not match"):
+        gpu.linearsvm(p["D"], p["ell"], p["C"], dict(o, slices=[100, 100]))
