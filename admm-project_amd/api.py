@@ -8,7 +8,8 @@ x-/z-update and share one device-resident problem (data + cached factor).  When 
 receives a matching pair it runs the whole loop (admm.m:496-743) on the device through
 the C ABI.  ``options`` and ``results`` are dicts with the reference's field names.
 Caller-supplied prox handles (the reference's plain function handles, as in
-examples/convergencechecking.m) are supported for A = 1, B = -1: they are called with
+examples/convergencechecking.m, or the zming of unwrappedadmm) are supported for B = -1 with
+A = 1 or A = the library problem's data matrix: they are called with
 zero-copy CUDA tensors of the engine's state on the engine's HIP stream and must return
 CUDA tensors; the rest of the iteration stays in the fused kernels.  There is no CPU
 fallback: a handle that returns a host array is rejected loudly.
@@ -246,7 +247,8 @@ def _check_constraint(options, prob):
             raise ValueError(f"options.{key} does not match the problem size")
 
 
-_CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "linearprogram", "basispursuit")  # A = 1 problems
+_CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "linearprogram", "basispursuit",  # A = 1 problems
+                   "lad", "huberfit", "linearsvm")  # A = D problems
 
 
 def _generic_problem(options):

@@ -980,7 +980,11 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
     if (e->xcb(e->xuser, e->x, fastalg ? e->v : e->z, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
                static_cast<void*>(e->stream)) != 0)
       return fail(ADMM_E_INVALID, "the xminf callback reported a failure");
-    *axsrc = e->xext;  // the fused kernel stores it into x (guarded by the device stop flag)
+    if (e->a_identity) {
+      *axsrc = e->xext;  // the fused kernel stores it into x (guarded by the device stop flag)
+    } else {  // A = D: D*x follows; copy through a kernel that honours the stop flag
+      launch_combine(e->xext, 1, 0, 1.0, nullptr, 0.0, nullptr, e->x, e->nA, e->ctrl, e->stream);
+    }
     return ADMM_OK;
   }
   if (e->xsolve == ADMM_XSOLVE_CG) return cg_solve(e, e->a_identity ? e->rhs : e->g);
@@ -1036,17 +1040,19 @@ static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpar
 int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
                               void* zuser, admm_obj_callback obj, void* objuser) {
   if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
-  if ((xmin || zmin || obj) &&
-      !(e->problem == ADMM_PROB_MODEL || e->problem == ADMM_PROB_QP_BOUNDED || e->problem == ADMM_PROB_BASISPURSUIT ||
-        e->problem == ADMM_PROB_LINEARPROGRAM || e->problem == ADMM_PROB_QP_STANDARD ||
-        (e->problem == ADMM_PROB_LASSO && !e->fat && e->xsolve != ADMM_XSOLVE_CG)))
+  const bool a1 = e->problem == ADMM_PROB_MODEL || e->problem == ADMM_PROB_QP_BOUNDED ||
+                  e->problem == ADMM_PROB_BASISPURSUIT || e->problem == ADMM_PROB_LINEARPROGRAM ||
+                  e->problem == ADMM_PROB_QP_STANDARD || (e->problem == ADMM_PROB_LASSO && !e->fat);
+  const bool ad = e->problem == ADMM_PROB_LAD || e->problem == ADMM_PROB_HUBERFIT || e->problem == ADMM_PROB_LINEARSVM;
+  if ((xmin || zmin || obj) && !((a1 || ad) && e->xsolve != ADMM_XSOLVE_CG))
     return fail(ADMM_E_UNSUPPORTED,
-                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, QP, LP, basis pursuit)");
+                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, QP, LP, basis pursuit) "
+                "and the A = D problems (LAD, Huber, linear SVM / unwrapped ADMM) with a cached-factor x-solve");
   if ((xmin || zmin || obj) && e->comm && comm_nranks(e->comm) > 1)
     return fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines");
   ADMM_HIP_TRY(hipSetDevice(e->device));
   const int64_t n2 = round_up(e->len, 2);
-  if (!e->xext) ADMM_TRY(e->mem.alloc(&e->xext, n2));
+  if (!e->xext) ADMM_TRY(e->mem.alloc(&e->xext, round_up(e->nA, 2)));
   if (!e->zext) ADMM_TRY(e->mem.alloc(&e->zext, n2));
   if (!e->xh) ADMM_TRY(e->mem.alloc(&e->xh, n2));
   e->xcb = xmin;
@@ -1621,7 +1627,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         za.relax = o.relax;
         launch_prez(za, e->ctrl, e->stream);
         if (e->zcb) {
-          if (e->zcb(e->zuser, e->xh, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
+          // admm.m:521-530: zming is called with x itself, or with the relaxed Axhat when relax != 1; with A = 1
+          // the two have the same length (xh), with A = D the un-relaxed call passes the n-vector x
+          const double* zarg = (e->a_identity || o.relax != 1.0) ? e->xh : e->x;
+          if (e->zcb(e->zuser, zarg, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
             return fail(ADMM_E_INVALID, "the zming callback reported a failure");
         } else {  // zminModel: (QtQ + rho I) \ (Qts + rho*(x + u))   getProxOps.m:1012
           apply_slice_factor(e, e->zfac, e->rz, e->zext);

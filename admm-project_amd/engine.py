@@ -116,9 +116,13 @@ class Engine:
         self._lib = lib
         self.problem = problem
         self.m, self.n = int(d.m), int(d.n)
+        # lengths of x and of z, u (admm.m: nA, nB): the A = D problems constrain D*x - z = c
+        self.nA = self.n
+        self.nB = self.m if problem in (L.PROB_LAD, L.PROB_HUBERFIT, L.PROB_LINEARSVM) else self.n
         self.device = int(d.device)
         self._cb_keep = None
         self._cb_error = None
+        self._relax = 1.0
         del keep
 
     # ------------------------------------------------------------------ caller-supplied prox operators
@@ -137,7 +141,7 @@ class Engine:
         import torch  # device memory / stream plumbing only
 
         dev = torch.device("cuda", self.device)
-        n = self.n
+        nA, nB = self.nA, self.nB
 
         class _View:  # __cuda_array_interface__ carrier: torch.as_tensor makes a zero-copy tensor of it
             def __init__(self, ptr, count):
@@ -162,7 +166,9 @@ class Engine:
             def cb(_user, x, z, u, rho, out, nout, stream):
                 try:
                     with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
-                        res = fn(view(x, n), view(z, n), view(u, n), float(rho))
+                        # xminf gets x; zming gets x, or the relaxed Axhat (nB elements) when relax != 1 (admm.m:521-530)
+                        first = nA if (what == "xminf" or self._relax == 1.0) else nB
+                        res = fn(view(x, first), view(z, nB), view(u, nB), float(rho))
                         view(out, nout).copy_(as_result(res, nout, what))
                     return 0
                 except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
@@ -252,6 +258,7 @@ class Engine:
                 keep.append(a)
                 setattr(o, name, L.as_dp(a))
         s = L.RunSummary()
+        self._relax = float(relax)
         self._cb_error = None
         rc = self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s))
         if rc != L.OK and self._cb_error is not None:  # a Python prox callback raised: surface ITS exception

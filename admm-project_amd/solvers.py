@@ -132,8 +132,17 @@ def unwrappedadmm(zming, D, options=None):
         # x = W\d: the engine's cached factor of D'D does exactly that) and admm slices the z-prox ('zming').
         options["slices"] = slicemaker(options.get("slices", 0), int(options.get("workers", 1)), m)
         options["parallel"] = "zming" if options["parallel"] == "both" else "none"
-    prob = zming.problem
     from .api import ProxOp
+    if isinstance(zming, ProxOp):
+        prob = zming.problem
+    elif callable(zming):
+        # the reference's own use of this solver: the CALLER's z-prox handle (unwrappedadmm.m:1).  The x-update
+        # x = D^+ (z - u) is the linear-SVM engine's (same closure: getProxOps.m:1062-1068 == unwrappedadmm.m:78);
+        # the handle runs on device tensors between the two halves of the fused kernel.
+        args = _engine_args(options, dict(D=D, Dt=None, ell=np.ones(m), C=1.0, lossfunction="hinge"))
+        prob = getproxops("LinearSVM", args)[0].problem
+    else:
+        raise TypeError("Given zming is not a function handle!")
     xminf = ProxOp(prob, "x")
     options.update(A=D, At=D.T, B=-1, nB=m, c=0, m=m)
     rng = np.random.default_rng()

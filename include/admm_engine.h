@@ -81,7 +81,8 @@ typedef struct admm_engine admm_engine; /* opaque */
  * DEVICE pointers into the engine's state; the callback enqueues its work on `hip_stream` (a hipStream_t)
  * or synchronises before returning, and writes its result to `out` (never aliased with an input).
  *   xmin: out[nA] = xminf(x[nA], z[nB], u[nB], rho)   admm.m:502 (fast ADMM passes v, uhat: 506)
- *   zmin: out[nB] = zming(xh[nB], z[nB], u[nB], rho)  admm.m:521-530; xh is x, A*x or the relaxed Axhat
+ *   zmin: out[nB] = zming(xh, z[nB], u[nB], rho)      admm.m:521-530; xh is x (nA elements) or, when
+ *                                                      options.relax != 1, the relaxed Axhat (nB elements)
  *   obj : *out    = obj(x[nA], z[nB])                 admm.m:603-605
  * A non-zero return aborts the run with ADMM_E_INVALID.  Speculatively enqueued iterations after a stop
  * condition still invoke the callbacks; their outputs are discarded on the device.
@@ -207,8 +208,10 @@ int admm_device_info(int device, char* name, size_t cap, int64_t* hbm_bytes, int
 void admm_options_default(admm_options* opts);
 void admm_problem_desc_default(admm_problem_desc* desc);
 int admm_engine_create(const admm_problem_desc* desc, admm_engine** out);
-/* replace the x- and/or z-update (and the objective hook) of an A = 1 problem (lasso, bounded QP,
- * basis pursuit, model) by caller-supplied callbacks; NULL keeps the engine-native operator.
+/* replace the x- and/or z-update (and the objective hook) of an A = 1 problem (tall lasso, QP, LP, basis
+ * pursuit, model) or an A = D problem (LAD, Huber, linear SVM: the zming handle of
+ * unwrappedadmm(zming, D, options), unwrappedadmm.m:1) by caller-supplied callbacks; NULL keeps the
+ * engine-native operator.  x has nA = n elements; z, u and zmin's first argument have nB elements (n or m).
  * ADMM_PROB_MODEL created without Gram data REQUIRES the corresponding callback. */
 int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
                               void* zuser, admm_obj_callback obj, void* objuser);

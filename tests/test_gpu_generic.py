@@ -184,10 +184,10 @@ def test_host_handles_are_rejected(gpu):
         gpu.admm(lambda x, z, u, r: np.zeros(16), lambda x, z, u, r: np.zeros(16), o)
     with pytest.raises(NotImplementedError, match="A = 1, B = -1"):
         gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=np.eye(16)))
-    p = gpu.synth.lad_problem(0, 64, 8)
-    minx, _mz, _ = gpu.getproxops("lad", {"D": p["D"], "s": p["s"]})
+    p = gpu.synth.tv_problem(0, 64)
+    minx, _mz, _ = gpu.getproxops("totalvariation", {"s": p["s"], "lambda": 1.0})
     with pytest.raises(NotImplementedError, match="cannot be mixed"):
-        gpu.admm(minx, lambda x, z, u, r: z, dict(A=p["D"], B=-1, c=p["s"], m=64, nA=8, nB=64))
+        gpu.admm(minx, lambda x, z, u, r: z, dict(A=np.eye(64), B=-1, c=0, m=64, nA=64, nB=64))
 
 
 # ---------------------------------------------------------------------------- LP / standard-form QP
@@ -241,3 +241,57 @@ def test_linearsvm_in_prox_slicing_options(gpu):
     _compare(got, ref, tol=1e-7)
     with pytest.raises(ValueError, match="slices does not match"):
         gpu.linearsvm(p["D"], p["ell"], p["C"], dict(o, slices=[100, 100]))
+
+
+# ---------------------------------------------------------------------------- caller's handles with A = D
+def test_unwrappedadmm_with_callers_zprox(gpu):
+    """unwrappedadmm(zming, D, options) (unwrappedadmm.m:1) with the CALLER's z-prox: an epsilon-insensitive
+    shrinkage that is not one of the library's operators.  Un-relaxed, the handle receives x and applies D itself
+    (admm.m:528), exactly like zminLinearSVM (getProxOps.m:1088)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7)
+    m, n = 240, 12
+    D = np.asfortranarray(rng.standard_normal((m, n)))
+    b = rng.standard_normal(m)
+    x0, z0, u0 = rng.random(n), rng.random(m), rng.random(m)
+    tD, tb = torch.tensor(D, device=dev), torch.tensor(b, device=dev)
+
+    def zt(x, _z, u, rho):
+        v = tD @ x + u - tb
+        return tb + torch.sign(v) * torch.clamp(torch.abs(v) - 1.0 / rho, min=0.0)
+
+    def zn(x, _z, u, rho):
+        v = D @ x + u - b
+        return b + np.sign(v) * np.maximum(np.abs(v) - 1.0 / rho, 0.0)
+
+    o = dict(x0=x0, z0=z0, u0=u0, objevals=1)
+    og = dict(o, obj=lambda x, z: torch.sum(torch.abs(tD @ x - tb)))
+    orf = dict(o, obj=lambda x, z: float(np.sum(np.abs(D @ x - b))))
+    got, ref = gpu.unwrappedadmm(zt, D, og), S.unwrappedadmm(zn, D, orf)
+    _compare(got, ref, tol=1e-7)
+
+
+@pytest.mark.parametrize("relax", [1.0, 1.5])
+def test_lad_library_x_with_callers_z(gpu, relax):
+    """A = D, c = s: library x-update (cached factor of D'D) + the caller's z-prox.  With relax != 1 the handle
+    receives the relaxed Axhat (m elements) instead of x (admm.m:517-523)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    p = gpu.synth.lad_problem(1, 300, 20)
+    D, s_ = p["D"], p["s"]
+    m, n = D.shape
+    tD, ts = torch.tensor(D, device=dev), torch.tensor(s_, device=dev)
+    soft_t = lambda v, t: torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0.0)
+    soft_n = lambda v, t: np.sign(v) * np.maximum(np.abs(v) - t, 0.0)
+    if relax == 1.0:
+        zt = lambda x, _z, u, rho: soft_t(tD @ x + u - ts, 1.0 / rho)   # getProxOps.m:810
+        zn = lambda x, _z, u, rho: soft_n(D @ x + u - s_, 1.0 / rho)
+    else:
+        zt = lambda ax, _z, u, rho: soft_t(ax + u - ts, 1.0 / rho)       # getProxOps.m:808 (userelax)
+        zn = lambda ax, _z, u, rho: soft_n(ax + u - s_, 1.0 / rho)
+    minx, _mz, _ = gpu.getproxops("lad", {"D": D, "s": s_})
+    rminx, _rz, _ = PR.getproxops("lad", {"D": D, "Dt": D.T, "s": s_, "R": np.linalg.cholesky(D.T @ D),
+                                          "userelax": int(relax != 1.0)})
+    o = dict(A=D, At=D.T, B=-1, c=s_, m=m, nA=n, nB=m, relax=relax, maxiters=60)
+    _compare(gpu.admm(minx, zt, dict(o)), A.admm(rminx, zn, dict(o)), tol=1e-7)
