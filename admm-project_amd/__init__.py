@@ -8,6 +8,7 @@ from . import _lib, errorcheck, synth  # noqa: F401
 from ._lib import AdmmError  # noqa: F401
 from .api import ProxOp, admm, getproxops  # noqa: F401
 from .engine import Engine  # noqa: F401
+from . import testers  # noqa: F401,E402
 from .solvers import (basispursuit, huberfit, lad, lasso, linearprogram, linearsvm, model, quadraticprogram,  # noqa: F401
                       totalvariation, unwrappedadmm)
 

@@ -153,7 +153,8 @@ def getproxops(problem, args):
         loss = args.get("lossfunction", "hinge")
         m, n = D.shape
         eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
-                     loss=L.LOSS_01 if loss == "01" else L.LOSS_HINGE, xsolve=xs, device=dev, comm=comm, **cg)
+                     loss={"hinge": L.LOSS_HINGE, "01": L.LOSS_01}.get(loss, L.LOSS_HINGE_OBJ01), xsolve=xs,
+                     device=dev, comm=comm, **cg)
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
     elif kind == "linearprogram" or (kind == "quadraticprogram" and _get(args, "constraint") == "standard"):
         # getProxOps.m:1363 / 1410 solve [M D'; D 0] \ [rho*(z-u) - q; s] every iteration (M = rho*I for the

@@ -1172,7 +1172,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         fa.obj_scale_z = 0.5;
         break;
       case ADMM_PROB_LINEARSVM:
-        pa.objx = (e->loss == ADMM_LOSS_01) ? OBJX_ZEROONE : OBJX_HINGE;
+        pa.objx = (e->loss == ADMM_LOSS_HINGE) ? OBJX_HINGE : OBJX_ZEROONE;  // linearsvm.m:231-237
         fa.obj_scale_x = e->C;
         fa.obj_half_xnorm = 0.5;
         break;

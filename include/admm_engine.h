@@ -53,7 +53,9 @@ enum {
 };
 
 /* linear-SVM loss (getProxOps.m:1094: anything but '01' runs the hinge prox) */
-enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1 };
+enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1,
+       ADMM_LOSS_HINGE_OBJ01 = 2 /* any other lossfunction string (e.g. linearsvmtest.m:157 passes '0-1'): the hinge
+                                    prox runs, but linearsvm.m:231-237 installs the 0-1 objective */ };
 
 /* how the cached-factor x-update is applied every iteration */
 enum {

@@ -102,8 +102,26 @@ def model_fixtures():
         save(f"model_{tag}_200", inp, o, S.model(p["P"], p["Q"], p["r"], p["s"], o))
 
 
+def extra_fixtures():
+    """consensus lasso over 4 slices; plus the LP and the standard-form QP."""
+    p = ap.synth.lasso_problem(1, 256, 64)
+    o = dict(objevals=1, parallel="both", workers=4)
+    save("consensus_lasso_4x64", dict(D=p["D"], s=p["s"], lam=p["lam"]), o,
+         S.lasso(p["D"], p["s"], p["lam"], dict(objevals=1, parallel="both"), workers=4))
+    p = ap.synth.lp_problem(0, 32, 96)
+    o = dict(objevals=1, maxiters=400)
+    save("lp_32x96", dict(b=p["b"], D=p["D"], s=p["s"]), o, S.linearprogram(p["b"], p["D"], p["s"], o))
+    p = ap.synth.qp_standard_problem(0, 24, 80)
+    o = dict(objevals=1, maxiters=300)
+    save("qpstd_24x80", dict(P=p["P"], q=p["q"], r=p["r"], D=p["D"], s=p["s"]), o,
+         S.quadraticprogram_standard(p["P"], p["q"], p["r"], p["D"], p["s"], o))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["model"]:
         model_fixtures()  # add the model fixtures without touching the others
+    elif sys.argv[1:] == ["extra"]:
+        extra_fixtures()
     else:
         main()
+        extra_fixtures()

@@ -26,7 +26,8 @@ def test_fixture_inventory():
     for want in ("lasso_tall_256x64.npz", "lasso_fat_32x256.npz", "lad_512x64.npz", "lad_512x64_relax.npz",
                  "huber_512x64.npz", "svm_hinge_256x2.npz", "svm_01_256x2.npz", "qp_bounded_128.npz",
                  "lasso_fast_weak.npz", "lasso_fast_strong.npz", "lasso_tall_relax.npz", "basispursuit_32x96.npz",
-                 "model_plain_200.npz", "model_fast_weak_200.npz", "model_fast_strong_200.npz"):
+                 "model_plain_200.npz", "model_fast_weak_200.npz", "model_fast_strong_200.npz",
+                 "consensus_lasso_4x64.npz", "lp_32x96.npz", "qpstd_24x80.npz"):
         assert want in names
 
 
@@ -36,7 +37,14 @@ def test_oracle_reproduces_fixture(path):
     name = os.path.basename(path)
     o = _opts(z)
     inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
-    if name.startswith("lasso"):
+    if name.startswith("consensus"):
+        workers = int(o.pop("workers"))
+        r = S.lasso(inp["D"], inp["s"], float(inp["lam"]), o, workers=workers)
+    elif name.startswith("lp"):
+        r = S.linearprogram(inp["b"], inp["D"], inp["s"], o)
+    elif name.startswith("qpstd"):
+        r = S.quadraticprogram_standard(inp["P"], inp["q"], float(inp["r"]), inp["D"], inp["s"], o)
+    elif name.startswith("lasso"):
         r = S.lasso(inp["D"], inp["s"], float(inp["lam"]), o)
     elif name.startswith("lad"):
         r = S.lad(inp["D"], inp["s"], o)

@@ -377,7 +377,13 @@ def test_golden_fixture(gpu, path):
     name = os.path.basename(path)
     o = _opts(z)
     inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
-    if name.startswith("lasso"):
+    if name.startswith("consensus"):
+        got = gpu.lasso(inp["D"], inp["s"], float(inp["lam"]), o)
+    elif name.startswith("lp"):
+        got = gpu.linearprogram(inp["b"], inp["D"], inp["s"], o)
+    elif name.startswith("qpstd"):
+        got = gpu.quadraticprogram(inp["P"], inp["q"], float(inp["r"]), inp["D"], inp["s"], o)
+    elif name.startswith("lasso"):
         got = gpu.lasso(inp["D"], inp["s"], float(inp["lam"]), o)
     elif name.startswith("lad"):
         got = gpu.lad(inp["D"], inp["s"], o)
@@ -401,7 +407,7 @@ def test_golden_fixture(gpu, path):
             _close(k, got[k], ref[k], 1e-6, limit=20)
         return
     assert got["steps"] == int(z["steps"])
-    tol = 1e-7 if name.startswith("svm") else TOL
+    tol = 1e-7 if name.startswith(("svm", "lp", "qpstd")) else TOL
     for k in HIST:
         if k in ref:
             _close(k, got[k], ref[k], tol)
