@@ -326,7 +326,10 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 // all-reduce of n doubles assembles x (the only per-iteration collective of the cached-factor lasso loop)
 static int symv_apply(admm_engine* e, const double* y, double* out) {
   const int nr = e->comm ? comm_nranks(e->comm) : 1;
-  if (nr > 1) {
+  // splitting pays only when the streaming time it removes exceeds the latency of a small all-reduce
+  // (~25-30 us over xGMI): t = 4*npad^2 bytes at ~5.5 TB/s; n = 10^4 -> 73 us, so N >= 2 qualifies
+  const double t_us = 4.0 * static_cast<double>(e->planSy.npad) * static_cast<double>(e->planSy.npad) / 5.5e6;
+  if (nr > 1 && t_us * (1.0 - 1.0 / nr) > 30.0) {
     launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
     return comm_allreduce_device(e->comm, out, static_cast<size_t>(e->nF), e->stream);
   }

@@ -132,10 +132,22 @@ def cpu_baseline(p, factor, seconds, rho):
     per = (time.perf_counter() - t0) / 2
     k = int(max(3, min(500, seconds / max(per, 1e-6))))
     r = ref_admm(minx, minz, dict(base, maxiters=k))
-    return dict(value=k / r["runtime"], unit="iterations/s", cores=int(threads), kind="port",
-                sample=f"{k} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
-                       f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves, factor taken from the GPU setup); "
-                       f"loop only, as results.runtime")
+    out = dict(value=k / r["runtime"], unit="iterations/s", cores=int(threads), kind="port",
+               sample=f"{k} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
+                      f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves, factor taken from the GPU setup); "
+                      f"loop only, as results.runtime")
+    # MATLAB applies the factor it stored SPARSE (lasso.m:175-176) with single-threaded triangular solves:
+    # the same loop pinned to one BLAS thread is the closer stand-in for the reference's CPU path
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            k1 = int(max(2, min(60, 0.4 * seconds / max(per, 1e-6))))
+            r1 = ref_admm(minx, minz, dict(base, maxiters=k1))
+        out["single_thread"] = dict(value=k1 / r1["runtime"], unit="iterations/s", cores=1,
+                                    sample=f"{k1} iterations, BLAS limited to one thread")
+    except Exception as exc:  # threadpoolctl missing: report the multi-threaded number only
+        out["single_thread"] = dict(error=repr(exc))
+    return out
 
 
 def other_configs(ap, L, device, steps):
@@ -218,6 +230,19 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                           "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
     mf.close()
 
+    if world > 1:
+        # config 4: consensus lasso (getProxOps.m:383-442, 1217-1343), one row slice per GPU: own x_k, u_k and
+        # factor chol(D_k'D_k + rho I) per rank, ONE all-reduce of [sum x_k; sum u_k] (2n doubles) per iteration
+        cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local,
+                         comm=comm, slices=[hi - lo])
+        k4 = max(5, a.steps // 4)
+        timed_run(cons, dist, 2, rho=rho, stopcond="both")
+        dt4, _ = timed_run(cons, dist, k4, rho=rho, stopcond="both")
+        out["consensus_lasso"] = {"workload": f"consensus lasso, {world} row slices of {hi - lo} x {n}, one per GPU",
+                                  "iters_per_s": k4 / dt4, "ms_per_step": dt4 / k4 * 1e3,
+                                  "allreduce_doubles_per_iter": 2 * n + 2,
+                                  "setup_seconds": max_over_ranks(dist, cons.setup_seconds)}
+        cons.close()
     if world == 1:
         out["other_configs"] = other_configs(ap, L, local, a.steps)
 
