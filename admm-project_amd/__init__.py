@@ -10,6 +10,6 @@ from .api import ProxOp, admm, getproxops  # noqa: F401
 from .engine import Engine  # noqa: F401
 from . import testers  # noqa: F401,E402
 from .solvers import (basispursuit, huberfit, lad, lasso, linearprogram, linearsvm, model, quadraticprogram,  # noqa: F401
-                      totalvariation, unwrappedadmm)
+                      totalvariation, totalvariation2d, unwrappedadmm)
 
 __version__ = "0.1.0"

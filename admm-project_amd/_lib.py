@@ -19,7 +19,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -
 # problem kinds
 PROB_LASSO, PROB_LASSO_CONSENSUS, PROB_LAD, PROB_HUBERFIT = 1, 2, 3, 4
 PROB_LINEARSVM, PROB_TOTALVARIATION, PROB_QP_BOUNDED, PROB_BASISPURSUIT = 5, 6, 7, 8
-PROB_MODEL, PROB_LINEARPROGRAM, PROB_QP_STANDARD = 9, 10, 11
+PROB_MODEL, PROB_LINEARPROGRAM, PROB_QP_STANDARD, PROB_TV2D = 9, 10, 11, 12
 LOSS_HINGE, LOSS_01, LOSS_HINGE_OBJ01 = 0, 1, 2
 XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1

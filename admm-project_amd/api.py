@@ -26,7 +26,8 @@ from .engine import Engine
 __all__ = ["admm", "getproxops", "ProxOp"]
 
 _PROBLEMS = ("model", "basispursuit", "totalvariation", "linearsvm", "lasso", "linearprogram",
-             "quadraticprogram", "covarianceselection", "lad", "huberfit")
+             "quadraticprogram", "covarianceselection", "lad", "huberfit",
+             "totalvariation2d")  # engine-side extension, no reference counterpart
 
 
 class _Problem:
@@ -184,6 +185,14 @@ def getproxops(problem, args):
         n = sig.size
         eng = Engine(L.PROB_TOTALVARIATION, s=sig, lam=float(_get(args, "lambda")), nvec=n, device=dev)
         prob = _Problem("totalvariation", eng, dict(A="D", c=0.0, nA=n, nB=n))
+    elif kind == "totalvariation2d":
+        img = np.asarray(_get(args, "s"), dtype=np.float64)
+        if img.ndim != 2:
+            raise ValueError("Argument s is not an image (2-D array)!")
+        H, W = img.shape
+        eng = Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=float(_get(args, "lambda")),
+                     shape=(H, W), device=dev, **cg)
+        prob = _Problem("totalvariation2d", eng, dict(A="D", c=0.0, nA=H * W, nB=2 * H * W))
     elif kind == "basispursuit":
         P, q = _get(args, "P"), _get(args, "q")
         n = P.shape[0]

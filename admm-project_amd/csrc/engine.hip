@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "tv.h"
+#include "tv2d.h"
 #include "consensus.h"
 #include "cg.h"
 
@@ -120,6 +121,7 @@ struct admm_engine {
   double *v = nullptr, *uhat = nullptr, *zprev = nullptr, *uprev = nullptr;
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
+  int64_t tv2_H = 0, tv2_W = 0;  // 2-D TV image shape
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
@@ -503,7 +505,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, ~1 ms at n = 10^4);
   // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
   if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
-  if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
+  if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;  // the only x-update this problem has
+  if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
     return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg applies to problems whose x-update solves with D'D (+ rho I)"));
   e->xsolve = xs;
@@ -749,6 +752,27 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->xsolve = ADMM_XSOLVE_INVERSE;  // a GEMV by construction
       break;
     }
+    case ADMM_PROB_TV2D: {
+      // 2-D anisotropic TV of an m x n image (column-major): z, u have 2*m*n entries ([vertical; horizontal])
+      if (!desc->s || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "2-D total variation needs the m x n image in s"));
+      if (desc->lambda < 0) return bail(fail(ADMM_E_INVALID, "Given lambda parameter is not a nonnegative number!"));
+      const int64_t N = m * n;
+      e->tv2_H = m;
+      e->tv2_W = n;
+      e->m = 2 * N;
+      e->n = N;  // length of the CG vectors
+      e->a_identity = false;
+      e->nA = N;
+      e->len = 2 * N;
+      e->prox = PROX_SOFT;
+      e->rhs_kind = RHS_NONE;
+      if (desc->cg_tol <= 0 || desc->cg_tol == 1e-12) e->cg_tol = 1e-11;
+      if (desc->cg_maxit <= 0 || desc->cg_maxit == 200) e->cg_maxit = 500;
+      E_TRY(upload(e->mem, &e->s, desc->s, N, mk, e->stream));
+      E_TRY(e->mem.alloc(&e->tv_zB, round_up(2 * N, 2)));
+      E_TRY(e->mem.alloc(&e->tv_uB, round_up(2 * N, 2)));
+      break;
+    }
     case ADMM_PROB_TOTALVARIATION: {
       // totalvariation.m:122-157: s is the (column) signal, D = spdiags([1 -1],0:1,n,n) is implicit
       const int64_t nn = n > 0 ? n : m;
@@ -854,7 +878,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   E_TRY(e->mem.alloc(&e->uhat, L2));
   E_TRY(e->mem.alloc(&e->zprev, L2));
   E_TRY(e->mem.alloc(&e->uprev, L2));
-  if (!e->a_identity && e->problem != ADMM_PROB_TOTALVARIATION) {
+  if (!e->a_identity && e->problem != ADMM_PROB_TOTALVARIATION && e->problem != ADMM_PROB_TV2D) {
     E_TRY(e->mem.alloc(&e->dz, L2));
     e->ldg = N2;
     E_TRY(e->mem.alloc(&e->g, 3 * N2 + 16));  // + 16 reduction slots: one all-reduce payload
@@ -907,6 +931,14 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
 
 // q-source for CG: D'*(D*v) as gemv_t chunk partials (or, row-sharded, the all-reduced sum in cg_tmp)
 static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t* nchunk, int64_t* ldq) {
+  if (e->problem == ADMM_PROB_TV2D) {  // operator I + rho*D'D: the stencil part here, the identity via shift = 1
+    TimerScope ts(e, ADMM_K_GEMV_N);
+    launch_tv2d_laplace(e->tv2_H, e->tv2_W, e->last_opts.rho, v, e->cg_tmp, e->ctrl, e->stream);
+    *qin = e->cg_tmp;
+    *nchunk = 1;
+    *ldq = 0;
+    return ADMM_OK;
+  }
   {
     TimerScope ts(e, ADMM_K_GEMV_N);
     launch_gemv_n(e->planDN, e->D, v, e->partDN, e->ctrl, e->stream);
@@ -933,7 +965,7 @@ static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t
 static int cg_solve(admm_engine* e, const double* y) {
   CgArgs a{};
   a.n = e->n;
-  a.shift = e->cg_shift_is_rho ? e->last_opts.rho : 0.0;
+  a.shift = (e->problem == ADMM_PROB_TV2D) ? 1.0 : (e->cg_shift_is_rho ? e->last_opts.rho : 0.0);
   a.tol = e->cg_tol;
   a.maxit = e->cg_maxit;
   a.y = y;
@@ -1414,6 +1446,91 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (e->profiling) collect_timers(e);
     const int32_t steps = e->ctrl_host->steps;
+    e->last = admm_run_summary{};
+    e->last.steps = steps;
+    e->last.stopped_early = (steps < N) ? 1 : 0;
+    e->last.convtest_failed_at = e->ctrl_host->convfail;
+    e->last.runtime_s = rt;
+    e->last.objopt = NAN;
+    if (o.objevals && steps > 0) {
+      double v = NAN;
+      ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+      e->last.objopt = v;
+    }
+    e->has_run = true;
+    if (summary) *summary = e->last;
+    return ADMM_OK;
+  }
+
+  if (e->problem == ADMM_PROB_TV2D) {
+    if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for 2-D total variation");
+    if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for 2-D total variation");
+    const int64_t Npix = e->tv2_H * e->tv2_W;
+    if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+    }
+    Tv2Args ta{};
+    ta.H = e->tv2_H;
+    ta.W = e->tv2_W;
+    ta.rho = o.rho;
+    ta.thresh = e->lambda / o.rho;
+    ta.s = e->s;
+    ta.x = e->x;
+    ta.objevals = o.objevals;
+    ta.xhist = e->xhist;
+    ta.zhist = e->zhist;
+    ta.uhist = e->uhist;
+    ta.part = e->part;
+    fa.g = nullptr;
+    fa.x = nullptr;
+    fa.xhist = nullptr;
+    fa.dual_from_slots = 1;
+    if (o.objevals) {  // 1/2*||x - s||^2 + lambda*||D x||_1
+      fa.obj_scale_x = 0.5;
+      fa.obj_scale_z = e->lambda;
+    }
+    (void)Npix;
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t done = 0;
+    bool stop_seen = false;
+    while (done < N && !stop_seen) {
+      const bool a_cur = (done & 1) == 0;  // iteration k reads buffer A when k is even
+      ta.z = a_cur ? e->tv_zA : e->tv_zB;
+      ta.u = a_cur ? e->tv_uA : e->tv_uB;
+      ta.zo = a_cur ? e->tv_zB : e->tv_zA;
+      ta.uo = a_cur ? e->tv_uB : e->tv_uA;
+      {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
+      }
+      ADMM_TRY(cg_solve(e, e->rhs));  // (I + rho*D'D) x = s + rho*D'(z - u), warm-started, polls the device
+      int nblk = 1;
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        launch_tv2d_prox(ta, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+      done += 1;
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      if (e->ctrl_host->stop) stop_seen = true;
+    }
+    {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+    }
+    const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (e->profiling) collect_timers(e);
+    const int32_t steps = e->ctrl_host->steps;
+    e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
+    e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+    ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
+    e->cg_total_last = e->cg_st_host->total;
     e->last = admm_run_summary{};
     e->last.steps = steps;
     e->last.stopped_early = (steps < N) ? 1 : 0;

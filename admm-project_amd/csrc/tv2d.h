@@ -1,0 +1,36 @@
+// tv2d.h -- 2-D anisotropic total variation (BASELINE config 5 as literally written: an H x W image,
+// matrix-free x-update).  Engine-side extension: the reference's totalvariation.m is 1-D only.
+#pragma once
+#include "common.h"
+
+namespace admm {
+
+// Image x is H x W, column-major (row index i fastest), N = H*W.  D = [Dv; Dh] is 2N x N:
+//   (Dv x)[i,j] = x[i,j] - x[i+1,j]   (i < H-1, else 0)      first  N rows
+//   (Dh x)[i,j] = x[i,j] - x[i,j+1]   (j < W-1, else 0)      second N rows
+// so z, u have 2N elements and D'D is the 5-point Neumann Laplacian.
+struct Tv2Args {
+  int64_t H, W;
+  double rho, thresh;      // thresh = lambda/rho
+  const double* s;         // image (N)
+  const double* x;         // current x (N)
+  const double* z;         // current z, u (2N, read)
+  const double* u;
+  double* zo;              // next z, u (2N, written by the prox kernel; ping-pong)
+  double* uo;
+  int32_t objevals;
+  double* xhist;
+  double* zhist;
+  double* uhist;
+  double* part;            // [S_COUNT][kMaxPartBlocks]
+};
+
+// w = rho * D'D p   (the CG operator is I + rho*D'D: cg_q_kernel adds the identity part)
+void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, double* w, const Ctrl* ctrl,
+                         hipStream_t stream);
+// b = s + rho * D'(z - u)      right-hand side of the x-update
+void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t stream);
+// z/u update from x, residual sums, then the D' stencils of the dual residual / tolerance (second kernel)
+void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+
+}  // namespace admm

@@ -1,0 +1,172 @@
+// tv2d.hip -- 2-D anisotropic total-variation ADMM kernels (engine-side extension of totalvariation.m to the
+// "4096 x 4096 image, matrix-free x-update" of BASELINE config 5; the reference's solver is 1-D).
+//
+//   minimise 1/2*||x - s||^2 + lambda*||D x||_1,   D = [Dv; Dh]  (vertical / horizontal forward differences)
+//   x-update   (I + rho*D'D) x = s + rho*D'(z - u)      5-point Neumann Laplacian: warm-started CG (cg.hip),
+//                                                       the operator is the stencil below, nothing is stored
+//   z-update   z = soft(u + D x, lambda/rho);  u += D x - z       (getProxOps.m:199 / admm.m:548, c = 0)
+// Everything is a streaming stencil over the image; neighbour reads hit L2.
+#include "kernels.h"
+#include "loop_kernels.h"
+#include "tv2d.h"
+
+namespace admm {
+
+static int tv2_blocks(int64_t n) {
+  int64_t b = ceil_div(n, kBlock);
+  if (b > kMaxPartBlocks) b = kMaxPartBlocks;
+  if (b < 1) b = 1;
+  return static_cast<int>(b);
+}
+
+// w = rho * D'D p:  (D'D p)[i,j] = sum over the existing 4-neighbours of (p[i,j] - p[nb])
+__global__ __launch_bounds__(kBlock) void tv2d_laplace_kernel(int64_t H, int64_t W, double rho,
+                                                              const double* __restrict__ p, double* __restrict__ w,
+                                                              const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t N = H * W;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double c = p[idx];
+    double acc = 0.0;
+    if (i > 0) acc += c - p[idx - 1];
+    if (i < H - 1) acc += c - p[idx + 1];
+    if (j > 0) acc += c - p[idx - H];
+    if (j < W - 1) acc += c - p[idx + H];
+    w[idx] = rho * acc;
+  }
+}
+
+// (D'w)[i,j] for w = [wv; wh] given as two accessors; rows of D that do not exist (i = H-1 / j = W-1) are zero
+template <typename FV, typename FH>
+__device__ __forceinline__ double tv2_dt(int64_t i, int64_t j, int64_t H, int64_t W, int64_t idx, FV wv, FH wh) {
+  double acc = 0.0;
+  if (i < H - 1) acc += wv(idx);
+  if (i > 0) acc -= wv(idx - 1);
+  if (j < W - 1) acc += wh(idx);
+  if (j > 0) acc -= wh(idx - H);
+  return acc;
+}
+
+__global__ __launch_bounds__(kBlock) void tv2d_rhs_kernel(Tv2Args a, double* __restrict__ b,
+                                                          const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t H = a.H, W = a.W, N = H * W;
+  const double* __restrict__ z = a.z;
+  const double* __restrict__ u = a.u;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double dt = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return z[k] - u[k]; },
+                             [&](int64_t k) { return z[N + k] - u[N + k]; });
+    b[idx] = a.s[idx] + a.rho * dt;
+  }
+}
+
+__device__ __forceinline__ double tv2_soft(double v, double t) {
+  const double q = fabs(v) - t;
+  const double p = q > 0.0 ? q : 0.0;
+  return (v > 0.0) ? p : ((v < 0.0) ? -p : 0.0 * p);
+}
+
+__device__ __forceinline__ void tv2_block_partials(const double (&acc)[S_COUNT], double* part, int first, int last) {
+  __shared__ double sred[4][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) >= first && static_cast<int>(threadIdx.x) <= last) {
+    const int s = threadIdx.x;
+    part[s * kMaxPartBlocks + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void tv2d_prox_kernel(Tv2Args a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  const int64_t H = a.H, W = a.W, N = H * W;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double xi = a.x[idx];
+    const double d[2] = {(i < H - 1) ? xi - a.x[idx + 1] : 0.0, (j < W - 1) ? xi - a.x[idx + H] : 0.0};
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int64_t k = part * N + idx;
+      const double ax = d[part];
+      const double zp = a.z[k], uo = a.u[k];
+      const double zn = tv2_soft(uo + ax, a.thresh);
+      const double un = uo + (ax + (-zn));
+      const double r = ax + (-zn), dz = zn - zp, du = un - uo;
+      acc[S_R2] += r * r;
+      acc[S_AX2] += ax * ax;
+      acc[S_Z2] += zn * zn;
+      acc[S_DZ2] += dz * dz;
+      acc[S_U2] += un * un;
+      acc[S_DU2] += du * du;
+      if (a.objevals) acc[S_OBJZ] += fabs(ax);
+      a.zo[k] = zn;
+      a.uo[k] = un;
+      if (a.zhist) {
+        a.zhist[it * 2 * N + k] = zn;
+        a.uhist[it * 2 * N + k] = un;
+      }
+    }
+    if (a.objevals) {
+      const double e = xi - a.s[idx];
+      acc[S_OBJX] += e * e;
+    }
+    if (a.xhist) a.xhist[it * N + idx] = xi;
+  }
+  tv2_block_partials(acc, a.part, 0, S_OBJX);  // slots 0..7 (S_R2 .. S_OBJX)
+}
+
+// ||D'(z+ - z)||^2 (admm.m:624) and ||D'u+||^2 (admm.m:654): second pass, needs the neighbours' new values
+__global__ __launch_bounds__(kBlock) void tv2d_dual_kernel(Tv2Args a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t H = a.H, W = a.W, N = H * W;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double g2 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return a.zo[k] - a.z[k]; },
+                             [&](int64_t k) { return a.zo[N + k] - a.z[N + k]; });
+    const double g3 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return a.uo[k]; },
+                             [&](int64_t k) { return a.uo[N + k]; });
+    acc[S_G2] += g2 * g2;
+    acc[S_G3] += g3 * g3;
+  }
+  tv2_block_partials(acc, a.part, S_G2, S_G3);
+}
+
+void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, double* w, const Ctrl* ctrl,
+                         hipStream_t stream) {
+  int64_t blocks = ceil_div(H * W, kBlock);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tv2d_laplace_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, H, W, rho, p, w,
+                     ctrl);
+}
+
+void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.H * a.W, kBlock);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tv2d_rhs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, b, ctrl);
+}
+
+void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  const int nb = tv2_blocks(a.H * a.W);
+  *nblk_out = nb;
+  hipLaunchKernelGGL(tv2d_prox_kernel, dim3(nb), dim3(kBlock), 0, stream, a, ctrl);
+  hipLaunchKernelGGL(tv2d_dual_kernel, dim3(nb), dim3(kBlock), 0, stream, a, ctrl);
+}
+
+}  // namespace admm

@@ -20,7 +20,7 @@ class Engine:
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
                  device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
-                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None):
+                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -52,6 +52,8 @@ class Engine:
             if D is None:
                 d.m = int(nvec)
             d.n = int(nvec)
+        if shape is not None:  # 2-D total variation: the image is shape[0] x shape[1], column-major in s
+            d.m, d.n = int(shape[0]), int(shape[1])
         if Q is not None:  # model problem: QtQ, Qts and the optional objective data (getProxOps.m:83-89)
             Qm = _f64(Q)
             keep.append(Qm)
@@ -119,6 +121,8 @@ class Engine:
         # lengths of x and of z, u (admm.m: nA, nB): the A = D problems constrain D*x - z = c
         self.nA = self.n
         self.nB = self.m if problem in (L.PROB_LAD, L.PROB_HUBERFIT, L.PROB_LINEARSVM) else self.n
+        if problem == L.PROB_TV2D:
+            self.nA, self.nB = self.m * self.n, 2 * self.m * self.n
         self.device = int(d.device)
         self._cb_keep = None
         self._cb_error = None

@@ -16,7 +16,7 @@ from .api import admm, getproxops
 from .errorcheck import is_nonnegative_real, is_positive_real, slicemaker
 
 __all__ = ["lasso", "lad", "huberfit", "linearsvm", "unwrappedadmm", "quadraticprogram", "basispursuit",
-           "totalvariation", "model", "linearprogram"]
+           "totalvariation", "totalvariation2d", "model", "linearprogram"]
 
 _ENGINE_OBJ = "<engine-native objective>"
 
@@ -333,6 +333,40 @@ def totalvariation(s, lam, options=None):
     options.update(A=D, At=None, B=-1, mB=n, nB=n, c=0, m=n)  # totalvariation.m:151-157
     options["obj"] = _ENGINE_OBJ  # totalvariation.m:134-135
     results = admm(xmin, zmin, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def totalvariation2d(S, lam, options=None):
+    """results = totalvariation2d(S, lambda, options) -- engine-side extension (the reference's
+    totalvariation.m is 1-D): anisotropic TV denoising of an image,
+
+        minimise 1/2*||X - S||_F^2 + lambda*(sum|X[i+1,j] - X[i,j]| + sum|X[i,j+1] - X[i,j]|),
+
+    as ADMM on D*x - z = 0 with D = [Dv; Dh] (2N x N forward differences, x = X(:) column-major).  The
+    x-update (I + rho*D'D) x = s + rho*D'(z - u) is solved matrix-free by warm-started CG on the device
+    (``options['cg_tol']``, default 1e-11 relative); nothing is factored.  ``xopt`` is returned as an image.
+    """
+    if options is None:
+        options = {}
+    if not isinstance(options, dict):
+        raise TypeError("Given options is not a struct! At least pass empty struct!")
+    options = dict(options)
+    t0 = time.perf_counter()
+    if not np.isscalar(lam) or np.real(lam) < 0:
+        raise ValueError("Given lambda parameter is not a nonnegative number!")
+    img = np.asarray(S, dtype=np.float64)
+    if img.ndim != 2:
+        raise ValueError("Argument S is not an image (2-D array)!")
+    H, W = img.shape
+    N = H * W
+    args = _engine_args(options, dict(s=img))
+    args["lambda"] = float(np.real(lam))
+    xmin, zmin, _ = getproxops("TotalVariation2D", args)
+    options.update(A=_ShapeOnly((2 * N, N)), At=None, B=-1, nA=N, nB=2 * N, c=0, m=2 * N)
+    options["obj"] = _ENGINE_OBJ
+    results = admm(xmin, zmin, options)
+    results["xopt"] = results["xopt"].reshape((H, W), order="F")
     results["solverruntime"] = time.perf_counter() - t0
     return results
 

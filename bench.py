@@ -168,6 +168,30 @@ def other_configs(ap, L, device, steps):
                                       "achieved_GBs": passes * 8.0 * n * s.steps / dt / 1e9,
                                       "frac": passes * 8.0 * n * s.steps / dt / 1e9 / HBM_PEAK_GBS}
     tv.close()
+    # config 5 as literally written: anisotropic TV of a 4096 x 4096 IMAGE, matrix-free (CG) x-update -- an
+    # engine-side extension (the reference's solver is 1-D); own oracle, see tests/test_gpu_tv2d.py
+    hw = 4096
+    rng = np.random.default_rng(1)
+    img = np.zeros((hw, hw))
+    img[hw // 5:hw // 2, hw // 6:hw // 2] = 2.0
+    img[hw // 3:4 * hw // 5, hw // 3:5 * hw // 6] += 1.0
+    img += rng.standard_normal((hw, hw))
+    tv2 = ap.Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=1.0, shape=(hw, hw), device=device)
+    tv2.run(maxiters=2, domaxiters=1, record_history=0)
+    k2 = max(5, steps // 20)
+    t0 = time.perf_counter()
+    s2 = tv2.run(maxiters=k2, domaxiters=1, record_history=0)
+    dt2 = time.perf_counter() - t0
+    inner = float(tv2.fetch(L.F_CG_ITERS, 1)[0]) / s2.steps
+    npix = hw * hw
+    # doubles moved per ADMM iteration: rhs 6N + CG start 8N + prox 9N + dual 6N + 14N per inner CG iteration
+    # (stencil 2N, q 3N, x/r update 6N, direction 3N)
+    gb = (29.0 + 14.0 * inner) * 8.0 * npix / 1e9
+    res["totalvariation2d_4096x4096"] = {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3,
+                                         "cg_inner_iters_per_step": inner, "cg_tol": 1e-11,
+                                         "algorithmic_GB_per_iter": gb, "achieved_GBs": gb * s2.steps / dt2,
+                                         "frac": gb * s2.steps / dt2 / HBM_PEAK_GBS}
+    tv2.close()
     # config 3: linear SVM, hinge, MNIST-shaped synthetic pixels (image files are absent from the reference)
     for m in (6000, 60000):
         q = ap.synth.mnist_like_problem(seed=1, m=m, n=400, digit=0)

@@ -15,7 +15,7 @@ import scipy.linalg as sla
 import scipy.sparse as sp
 
 from .admm_ref import admm
-from .proxops_ref import getproxops
+from .proxops_ref import getproxops, soft_threshold
 
 
 def slicemaker(slices, workers, length):
@@ -143,6 +143,49 @@ def totalvariation(s, lam, options=None):
     options.update(A=D, At=Dt, B=-1, nB=n, c=0, m=n)  # 151-157
     options["obj"] = objective
     results = admm(xmin, zmin, options)
+    results["solverruntime"] = time.perf_counter() - t0
+    return results
+
+
+def tv2d_operator(H, W):
+    """D = [Dv; Dh] (2N x N, N = H*W, x = X(:) column-major): (Dv x)[i,j] = x[i,j] - x[i+1,j] for i < H-1,
+    (Dh x)[i,j] = x[i,j] - x[i,j+1] for j < W-1; the rows of the last image row / column are zero.
+    No reference counterpart (totalvariation.m is 1-D): this is the oracle of the engine's own extension."""
+    N = H * W
+    idx = np.arange(N).reshape((H, W), order="F")
+    rows, cols, vals = [], [], []
+    v = idx[:-1, :].reshape(-1)
+    rows += [v, v]
+    cols += [v, idx[1:, :].reshape(-1)]
+    vals += [np.ones(v.size), -np.ones(v.size)]
+    h = idx[:, :-1].reshape(-1)
+    rows += [N + h, N + h]
+    cols += [h, idx[:, 1:].reshape(-1)]
+    vals += [np.ones(h.size), -np.ones(h.size)]
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(2 * N, N))
+
+
+def totalvariation2d(S, lam, options=None):
+    """Anisotropic 2-D TV denoising by the same ADMM splitting as totalvariation.m (D*x - z = 0), with the
+    x-update solved directly (sparse LU) -- the device solves it by CG to 1e-11."""
+    import scipy.sparse.linalg as spla
+
+    options = dict(options or {})
+    t0 = time.perf_counter()
+    img = np.asarray(S, dtype=np.float64)
+    H, W = img.shape
+    N = H * W
+    s = img.reshape(-1, order="F")
+    D = tv2d_operator(H, W)
+    Dt = D.T.tocsr()
+    rho = float(options.get("rho", 1.0))
+    lu = spla.splu((sp.identity(N, format="csc") + rho * (Dt @ D)).tocsc())
+    xmin = lambda _x, z, u, r_: lu.solve(s + r_ * (Dt @ (z - u)))
+    zmin = lambda x, _z, u, r_: soft_threshold(u + D @ x, lam / r_)
+    options.update(A=D, At=Dt, B=-1, nA=N, nB=2 * N, c=0, m=2 * N)
+    options["obj"] = lambda x, z: 0.5 * float(np.sum((x - s) ** 2)) + lam * float(np.sum(np.abs(D @ x)))
+    results = admm(xmin, zmin, options)
+    results["xopt"] = results["xopt"].reshape((H, W), order="F")
     results["solverruntime"] = time.perf_counter() - t0
     return results
 

@@ -1,0 +1,25 @@
+"""BASELINE config 5 as literally written: anisotropic TV of a 4096 x 4096 image, matrix-free x-update."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import admm_project_amd as ap  # noqa: E402
+
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+rng = np.random.default_rng(1)
+img = np.zeros((H, W))
+img[H // 5:H // 2, W // 6:W // 2] = 2.0
+img[H // 3:4 * H // 5, W // 3:5 * W // 6] += 1.0
+img += rng.standard_normal((H, W))
+L = ap._lib
+e = ap.Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=1.0, shape=(H, W))
+for tag, k in (("warm", 3), ("timed", 20)):
+    t0 = time.perf_counter()
+    s = e.run(maxiters=k, domaxiters=1, record_history=0)
+    dt = time.perf_counter() - t0
+    inner = float(e.fetch(L.F_CG_ITERS, 1)[0])
+    print(tag, s.steps, "it/s %.1f" % (s.steps / dt), "ms/it %.3f" % (1e3 * dt / s.steps), "inner/it %.1f" % (inner / s.steps),
+          flush=True)

@@ -1,0 +1,58 @@
+"""2-D anisotropic total variation (engine-side extension; BASELINE config 5 as literally written): the device
+path (stencil kernels + matrix-free CG x-update) against the oracle's sparse-direct restatement.  No reference
+counterpart exists (totalvariation.m is 1-D), so this parity is pinned by the oracle alone."""
+import numpy as np
+import pytest
+
+from oracle import solvers_ref as S
+from tests.test_gpu_parity import _close
+
+pytestmark = pytest.mark.gpu
+
+
+def _image(seed, H, W):
+    rng = np.random.default_rng(seed)
+    img = np.zeros((H, W))
+    img[H // 5:H // 2, W // 6:W // 2] = 2.0
+    img[H // 3:4 * H // 5, W // 3:5 * W // 6] += 1.0
+    return img + 0.3 * rng.standard_normal((H, W))
+
+
+@pytest.mark.parametrize("H,W,opts", [
+    (24, 17, dict(objevals=1)), (33, 40, dict(objevals=1, rho=2.0)), (1, 50, dict(objevals=1)),
+    (40, 1, dict()), (64, 64, dict(objevals=1, convtest=1, stopcond="both", maxiters=60)),
+    (20, 30, dict(domaxiters=1, maxiters=25, nodualerror=1)),
+])
+def test_tv2d_matches_oracle(gpu, H, W, opts):
+    img = _image(H * 100 + W, H, W)
+    got = gpu.totalvariation2d(img, 0.5, dict(opts))
+    ref = S.totalvariation2d(img, 0.5, dict(opts))
+    assert got["steps"] == ref["steps"]
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq", "xopt", "zopt", "uopt"):
+        if k in ref:
+            _close(k, got[k], ref[k], 1e-7)
+    assert got["xopt"].shape == (H, W)
+    assert got["cg_iters_total"] >= got["steps"]
+
+
+def test_tv2d_denoises(gpu):
+    """The pass criterion of totalvariationtest.m:151 carried over: ADMM's objective beats the clean image's."""
+    H, W = 96, 80
+    rng = np.random.default_rng(3)
+    clean = np.zeros((H, W))
+    clean[20:60, 10:50] = 3.0
+    clean[40:90, 30:70] += 2.0
+    img = clean + rng.standard_normal((H, W))
+    lam = 1.0
+    tv = lambda X: np.sum(np.abs(np.diff(X, axis=0))) + np.sum(np.abs(np.diff(X, axis=1)))
+    obj = lambda X: 0.5 * np.sum((X - img) ** 2) + lam * tv(X)
+    r = gpu.totalvariation2d(img, lam, dict(objevals=1, maxiters=2000, record_history=0))
+    assert obj(r["xopt"]) < obj(clean)
+    assert r["objopt"] == pytest.approx(obj(r["xopt"]), rel=1e-9)
+
+
+def test_tv2d_argument_errors(gpu):
+    with pytest.raises(ValueError, match="not an image"):
+        gpu.totalvariation2d(np.zeros(10), 1.0, {})
+    with pytest.raises(ValueError, match="nonnegative"):
+        gpu.totalvariation2d(np.zeros((4, 4)), -1.0, {})
