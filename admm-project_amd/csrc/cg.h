@@ -33,5 +33,11 @@ void launch_cg_q(const CgArgs& a, const double* qin, int32_t nchunk, int64_t ldq
 void launch_cg_init(const CgArgs& a, hipStream_t stream);
 // alpha, x/r update, beta, p update, scalar state advance (after launch_cg_q(..., with_dot = true))
 void launch_cg_step_tail(const CgArgs& a, hipStream_t stream);
+// the pieces of the tail, for operators that fuse the direction update into their own apply kernel (tv2d.hip):
+// x += alpha p, r -= alpha q, partial r.r  |  rs <- r.r, iteration count, convergence flag
+void launch_cg_update(const CgArgs& a, hipStream_t stream);
+void launch_cg_advance(const CgArgs& a, hipStream_t stream);
+// number of workgroups (= partial sums) every CG kernel of a length-n solve uses
+int cg_num_blocks(int64_t n);
 
 }  // namespace admm

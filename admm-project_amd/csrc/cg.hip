@@ -144,4 +144,15 @@ void launch_cg_step_tail(const CgArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(kBlock), 0, stream, a, nb);
 }
 
+void launch_cg_update(const CgArgs& a, hipStream_t stream) {
+  const int nb = cg_blocks(a.n);
+  hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, stream, a, nb);
+}
+
+void launch_cg_advance(const CgArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(cg_advance_kernel, dim3(1), dim3(kBlock), 0, stream, a, cg_blocks(a.n));
+}
+
+int cg_num_blocks(int64_t n) { return cg_blocks(n); }
+
 }  // namespace admm

@@ -961,8 +961,55 @@ static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t
   return ADMM_OK;
 }
 
+// 2-D TV: the same CG with the direction update fused into the stencil apply (10 instead of 14 vector
+// passes and 3 instead of 5 launches per inner iteration); p ping-pongs between cg_p and cg_tmp
+static int cg_solve_tv2d(admm_engine* e, const double* y) {
+  CgArgs a{};
+  a.n = e->n;
+  a.shift = 1.0;
+  a.tol = e->cg_tol;
+  a.maxit = e->cg_maxit;
+  a.y = y;
+  a.x = e->x;
+  a.r = e->cg_r;
+  a.p = e->cg_p;
+  a.q = e->cg_q;
+  a.part = e->cg_part;
+  a.st = e->cg_st;
+  a.ctrl = e->ctrl;
+  const double rho = e->last_opts.rho;
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
+  // r = y - (I + rho*D'D) x, p = r, rs, ||y||
+  launch_tv2d_laplace(e->tv2_H, e->tv2_W, rho, e->x, e->cg_tmp, e->ctrl, e->stream);
+  CgArgs a0 = a;
+  a0.p = e->x;
+  launch_cg_q(a0, e->cg_tmp, 1, 0, false, e->stream);
+  launch_cg_init(a, e->stream);
+  double* pbuf[2] = {e->cg_p, e->cg_tmp};
+  int cur = 0;
+  launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[1], true, e->stream);  // q = A p, p.q (beta = 0)
+  cur = 1;
+  const int chunk = 8;
+  for (int done_it = 0; done_it < e->cg_maxit;) {
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
+    const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
+    for (int c = 0; c < k; ++c) {
+      a.p = pbuf[cur];
+      launch_cg_update(a, e->stream);   // alpha, x += alpha p, r -= alpha q, (r.r)_new partials
+      launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[cur ^ 1], false, e->stream);
+      cur ^= 1;
+      launch_cg_advance(a, e->stream);  // rs <- (r.r)_new, convergence flag
+    }
+    done_it += k;
+  }
+  return ADMM_OK;
+}
+
 // x <- argmin-free solve of (D'D + shift I) x = y by warm-started CG (cg.hip); polls the device flag
 static int cg_solve(admm_engine* e, const double* y) {
+  if (e->problem == ADMM_PROB_TV2D) return cg_solve_tv2d(e, y);
   CgArgs a{};
   a.n = e->n;
   a.shift = (e->problem == ADMM_PROB_TV2D) ? 1.0 : (e->cg_shift_is_rho ? e->last_opts.rho : 0.0);

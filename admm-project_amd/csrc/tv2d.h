@@ -1,6 +1,7 @@
 // tv2d.h -- 2-D anisotropic total variation (BASELINE config 5 as literally written: an H x W image,
 // matrix-free x-update).  Engine-side extension: the reference's totalvariation.m is 1-D only.
 #pragma once
+#include "cg.h"
 #include "common.h"
 
 namespace admm {
@@ -28,6 +29,12 @@ struct Tv2Args {
 // w = rho * D'D p   (the CG operator is I + rho*D'D: cg_q_kernel adds the identity part)
 void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, double* w, const Ctrl* ctrl,
                          hipStream_t stream);
+// One fused CG kernel per inner iteration: beta = (r.r)_new / (r.r)_old (0 when `first`), p_new = r + beta*p_old,
+// q = (I + rho*D'D) p_new, block partials of p_new.q -- the direction update and the operator in one pass
+// (p is ping-ponged because the stencil needs the neighbours' OLD p).  a.p = p_old, a.q = q; uses a.part as
+// launch_cg_update / launch_cg_advance do.
+void launch_tv2d_cg_pq(int64_t H, int64_t W, double rho, const CgArgs& a, double* p_new, bool first,
+                       hipStream_t stream);
 // b = s + rho * D'(z - u)      right-hand side of the x-update
 void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t stream);
 // z/u update from x, residual sums, then the D' stencils of the dual residual / tolerance (second kernel)

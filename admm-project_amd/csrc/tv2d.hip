@@ -38,6 +38,43 @@ __global__ __launch_bounds__(kBlock) void tv2d_laplace_kernel(int64_t H, int64_t
   }
 }
 
+__global__ __launch_bounds__(kBlock) void tv2d_cg_pq_kernel(int64_t H, int64_t W, double rho, CgArgs a,
+                                                            double* __restrict__ p_new, int nblk, int first) {
+  if (a.ctrl->stop || a.st->done) return;
+  __shared__ double scratch[4];
+  __shared__ double bc;
+  double beta = 0.0;
+  if (!first) {  // (r.r)_new from the update kernel's block partials, (r.r)_old still in the state block
+    double sacc = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) sacc += a.part[kMaxPartBlocks + b];
+    const double t = block_sum(sacc, scratch);
+    if (threadIdx.x == 0) bc = t / a.st->rs;
+    __syncthreads();
+    beta = bc;
+  }
+  const double* __restrict__ r = a.r;
+  const double* __restrict__ po = a.p;
+  const int64_t N = H * W;
+  double acc = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    auto pv = [&](int64_t k) { return first ? r[k] : __builtin_fma(beta, po[k], r[k]); };
+    const double c = pv(idx);
+    double lap = 0.0;
+    if (i > 0) lap += c - pv(idx - 1);
+    if (i < H - 1) lap += c - pv(idx + 1);
+    if (j > 0) lap += c - pv(idx - H);
+    if (j < W - 1) lap += c - pv(idx + H);
+    const double qv = c + rho * lap;
+    p_new[idx] = c;
+    a.q[idx] = qv;
+    acc += c * qv;
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) a.part[blockIdx.x] = t;
+}
+
 // (D'w)[i,j] for w = [wv; wh] given as two accessors; rows of D that do not exist (i = H-1 / j = W-1) are zero
 template <typename FV, typename FH>
 __device__ __forceinline__ double tv2_dt(int64_t i, int64_t j, int64_t H, int64_t W, int64_t idx, FV wv, FH wh) {
@@ -154,6 +191,12 @@ void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, doub
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(tv2d_laplace_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, H, W, rho, p, w,
                      ctrl);
+}
+
+void launch_tv2d_cg_pq(int64_t H, int64_t W, double rho, const CgArgs& a, double* p_new, bool first,
+                       hipStream_t stream) {
+  const int nb = cg_num_blocks(a.n);  // the partial-sum count launch_cg_update / launch_cg_advance expect
+  hipLaunchKernelGGL(tv2d_cg_pq_kernel, dim3(nb), dim3(kBlock), 0, stream, H, W, rho, a, p_new, nb, first ? 1 : 0);
 }
 
 void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t stream) {

@@ -184,9 +184,9 @@ def other_configs(ap, L, device, steps):
     dt2 = time.perf_counter() - t0
     inner = float(tv2.fetch(L.F_CG_ITERS, 1)[0]) / s2.steps
     npix = hw * hw
-    # doubles moved per ADMM iteration: rhs 6N + CG start 8N + prox 9N + dual 6N + 14N per inner CG iteration
-    # (stencil 2N, q 3N, x/r update 6N, direction 3N)
-    gb = (29.0 + 14.0 * inner) * 8.0 * npix / 1e9
+    # doubles moved per ADMM iteration: rhs 6N + CG start 12N + prox 9N + dual 6N + 10N per inner CG iteration
+    # (fused direction + stencil: reads r, p, writes p, q; update: reads x, p, r, q, writes x, r)
+    gb = (33.0 + 10.0 * inner) * 8.0 * npix / 1e9
     res["totalvariation2d_4096x4096"] = {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3,
                                          "cg_inner_iters_per_step": inner, "cg_tol": 1e-11,
                                          "algorithmic_GB_per_iter": gb, "achieved_GBs": gb * s2.steps / dt2,
