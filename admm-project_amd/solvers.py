@@ -201,14 +201,17 @@ def quadraticprogram(P, q, r, cons1, cons2, options=None):
     c1, c2 = np.asarray(cons1, dtype=np.float64), np.asarray(cons2, dtype=np.float64)
     vec1, vec2 = (c1.ndim <= 1 or 1 in c1.shape), (c2.ndim <= 1 or 1 in c2.shape)
     if not vec1 and not vec2:
-        raise ValueError("Constraint inputs do not specify a bounded or a standard-form problem!")
+        raise ValueError("It appears that both constraint inputs are matrices! If trying to use standard "
+                         "constraint form, only one can be a matrix.")  # quadraticprogram.m:361-363
     if not (vec1 and vec2):  # 'standard': D*x = s, x >= 0   (quadraticprogram.m:319-345)
         Dm, sv = (c2, c1) if vec1 else (c1, c2)
         sv = sv.reshape(-1)
         if Dm.shape[1] != P.shape[0]:
-            raise ValueError("The number of columns of constraint matrix D does not match the size of P!")
+            raise ValueError("Number of columns in constraint matrix in standard form do not match lengths of "
+                             "P and q!")  # quadraticprogram.m:348-349
         if Dm.shape[0] != sv.size:
-            raise ValueError("The number of rows in matrix D must match the length of vector s!")
+            raise ValueError("Number of rows in constraint matrix in standard form does not match length of "
+                             "constraint vector! (D and s in standard form)")  # quadraticprogram.m:351-353
         n = P.shape[0]
         rho = float(options.get("rho", 1.0))
         args = _engine_args(options, dict(P=P, q=q, D=Dm, s=sv, rho=rho, n=n, constraint="standard", r=float(r)))
@@ -260,9 +263,9 @@ def linearprogram(b, D, s, options=None):
     s = _colvec(s, "s")
     m, n = D.shape
     if b.size != n:
-        raise ValueError("The length of cost vector b must match the number of columns of D!")
+        raise ValueError("Number of columns in D do not match length of vector b!")  # linearprogram.m:241-244
     if s.size != m:
-        raise ValueError("The number of rows in matrix D must match the length of vector s!")
+        raise ValueError("Number of rows in D does not match length of vector s!")
     rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
     args = _engine_args(options, dict(D=D, Dt=D.T, b=b, s=s, n=n, rho=rho))
     minx, minz, _ = getproxops("LinearProgram", args)
@@ -396,10 +399,14 @@ def model(P, Q, r, s, options=None):
     Q = _matrix(Q, "Q")
     r = _colvec(r, "r")
     s = _colvec(s, "s")
+    if P.shape[0] != Q.shape[0]:  # model.m:204-211
+        raise ValueError("Number of rows in P do not match number of rows in Q!")
     if P.shape[1] != Q.shape[1]:
-        raise ValueError("Matrices P and Q must have the same number of columns!")
-    if r.size != P.shape[0] or s.size != Q.shape[0]:
-        raise ValueError("Vectors r and s must match the rows of P and Q!")
+        raise ValueError("Number of columns in P do not match number of columns in Q!")
+    if P.shape[0] != r.size:
+        raise ValueError("Number of rows in P does not match length of vector r!")
+    if Q.shape[0] != s.size:
+        raise ValueError("Number of rows in Q does not match length of vector s!")
     n = P.shape[1]
     rho = is_positive_real(options["rho"], "options.rho") if "rho" in options else 1.0
     args = dict(PtP=P.T @ P, Ptr=P.T @ r, QtQ=Q.T @ Q, Qts=Q.T @ s, n=n, rho=rho, P=P, Q=Q, r=r, s=s)

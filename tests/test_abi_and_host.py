@@ -175,3 +175,31 @@ def test_mnist_label_reader(ap, tmp_path):
     bad.write_bytes(struct.pack(">ii", 1234, 1) + b"\0")
     with pytest.raises(ValueError):
         ap.synth.read_idx1_labels(str(bad))
+
+
+def test_solver_argument_errors_mirror_the_reference(ap):
+    """Validation happens on the host before any device work: the reference's error() texts (model.m:204-211,
+    linearprogram.m:241-244, quadraticprogram.m:348-363, lasso.m / lad.m size checks)."""
+    z = np.zeros
+    with pytest.raises(ValueError, match="rows in P do not match number of rows in Q"):
+        ap.model(z((5, 3)), z((4, 3)), z(5), z(4), {})
+    with pytest.raises(ValueError, match="columns in P do not match number of columns in Q"):
+        ap.model(z((5, 3)), z((5, 2)), z(5), z(5), {})
+    with pytest.raises(ValueError, match="rows in P does not match length of vector r"):
+        ap.model(z((5, 3)), z((5, 3)), z(4), z(5), {})
+    with pytest.raises(ValueError, match="rows in Q does not match length of vector s"):
+        ap.model(z((5, 3)), z((5, 3)), z(5), z(6), {})
+    with pytest.raises(ValueError, match="columns in D do not match length of vector b"):
+        ap.linearprogram(z(4), z((2, 3)), z(2), {})
+    with pytest.raises(ValueError, match="rows in D does not match length of vector s"):
+        ap.linearprogram(z(3), z((2, 3)), z(5), {})
+    with pytest.raises(ValueError, match="both constraint inputs are matrices"):
+        ap.quadraticprogram(np.eye(3), z(3), 0.0, z((2, 3)), z((2, 3)), {})
+    with pytest.raises(ValueError, match="do not match lengths of P and q"):
+        ap.quadraticprogram(np.eye(3), z(3), 0.0, z((2, 4)), z(2), {})
+    with pytest.raises(ValueError, match="do not match size of s"):
+        ap.lasso(z((5, 3)), z(4), 0.1, {})
+    with pytest.raises(ValueError, match="not an image"):
+        ap.totalvariation2d(z(7), 1.0, {})
+    with pytest.raises(TypeError, match="not a struct"):
+        ap.linearprogram(z(3), z((2, 3)), z(2), "options")
