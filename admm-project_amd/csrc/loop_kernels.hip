@@ -39,129 +39,142 @@ __device__ __forceinline__ void block_reduce_slots(double (&acc)[S_COUNT], doubl
   }
 }
 
+// Everything the loop does with element i once Ax_i is known (admm.m:515-569, 608-654): relaxation, z-prox,
+// u-update, fast-ADMM extrapolation, histories, the residual / objective partial sums and the next rhs.
+__device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, double ax, int64_t it, double kcoef,
+                                             double (&acc)[S_COUNT]) {
+  if (a.a_identity) {
+    if (a.x_out) a.x_out[i] = ax;
+    if (a.xhist) a.xhist[it * a.len + i] = ax;
+  }
+  const double zp = a.z[i];
+  const double u_old = a.u[i];
+  const double uo = (a.alg == 0) ? u_old : a.uhat[i];
+  const double ci = a.c ? a.c[i] : 0.0;
+  // admm.m:517  Axhat = relax*A(x) - (1-relax)*(B(zprev) - c),  B = -1
+  const double axh = (a.relax != 1.0) ? a.relax * ax - (1.0 - a.relax) * ((-zp) - ci) : ax;
+  const double v = (axh + uo) - ci;
+  double zn;
+  switch (a.prox) {
+    case PROX_SOFT:
+      zn = soft(v, a.t);
+      break;
+    case PROX_HUBER:
+      zn = 1.0 / (1.0 + a.rho) * (a.rho * v + soft(v, 1.0 + 1.0 / a.rho));
+      break;
+    case PROX_HINGE: {
+      const double l = a.ell[i];
+      const double lv = l * v;
+      zn = v + l * fmax(fmin(1.0 - lv, a.t), 0.0);
+      break;
+    }
+    case PROX_01: {
+      const double l = a.ell[i];
+      const double s = l * v;
+      const double y = ((s >= 1.0) || (s < (1.0 - sqrt(2.0 / a.t)))) ? s : 1.0;
+      zn = l * y;
+      break;
+    }
+    case PROX_GIVEN:
+      zn = a.zgiven[i];
+      break;
+    case PROX_POS:
+      zn = fmax(v, 0.0);
+      break;
+    default:  // PROX_BOX
+      zn = fmin(a.ub[i], fmax(a.lb[i], v));
+      break;
+  }
+  const double Bz = -zn;
+  const double un = uo + ((axh + Bz) - ci);  // admm.m:542-550
+  const double r = (ax + Bz) - ci;           // admm.m:621 uses Ax, not Axhat
+  const double dzv = zn - zp;
+  acc[S_R2] += r * r;
+  acc[S_AX2] += ax * ax;
+  acc[S_Z2] += zn * zn;
+  acc[S_DZ2] += dzv * dzv;
+  acc[S_U2] += un * un;
+  const double du = un - u_old;
+  acc[S_DU2] += du * du;
+  if (a.objz == OBJZ_ABS) acc[S_OBJZ] += fabs(zn);
+  else if (a.objz == OBJZ_HUBER) acc[S_OBJZ] += huber_cvx(zn);
+  if (a.objx == OBJX_HINGE) acc[S_OBJX] += fmax(1.0 - a.ell[i] * ax, 0.0);
+  else if (a.objx == OBJX_ZEROONE) {
+    const double q = 1.0 - a.ell[i] * ax;
+    acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
+  } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
+  else if (a.objx == OBJX_DOT) acc[S_OBJX] += a.ell[i] * ax;
+
+  a.z[i] = zn;
+  a.u[i] = un;
+  if (a.dz) a.dz[i] = dzv;
+  if (a.zhist) a.zhist[it * a.len + i] = zn;
+  if (a.uhist) a.uhist[it * a.len + i] = un;
+
+  double zx = zn, ux = un;
+  if (a.alg == 1) {  // admm.m:568-569
+    zx = zn + kcoef * (zn - zp);
+    ux = un + kcoef * (un - u_old);
+    a.v[i] = zx;
+    a.uhat[i] = ux;
+    if (a.vhist) a.vhist[it * a.len + i] = zx;
+    if (a.uhathist) a.uhathist[it * a.len + i] = ux;
+  } else if (a.alg == 2) {  // decision needs d first: keep what the extrapolation kernel needs
+    const double vo = a.v[i];
+    const double duh = un - uo, dzv2 = zn - vo;
+    acc[S_DUH2] += duh * duh;
+    acc[S_DZV2] += dzv2 * dzv2;
+    a.zprev[i] = zp;
+    a.uprev[i] = u_old;
+  }
+  if (a.alg != 2 && a.rhs) {
+    switch (a.rhs_kind) {
+      case RHS_RHO_DTS:
+        a.rhs[i] = a.rho * (zx - ux) + a.rhs_add[i];
+        break;
+      case RHS_RHO_MINUS_Q:
+        a.rhs[i] = a.rho * (zx - ux) - a.rhs_add[i];
+        break;
+      case RHS_DIFF:
+        a.rhs[i] = zx - ux;
+        break;
+      case RHS_T1:
+        a.rhs[i] = (ci + zx) - ux;
+        break;
+      default:
+        break;
+    }
+  }
+}
+
+__device__ __forceinline__ double prox_kcoef(const ProxArgs& a, const Ctrl* ctrl) {
+  if (a.alg != 1) return 0.0;
+  // admm.m:504, 567: aprev = acurr; acurr = (1+sqrt(1+4 aprev^2))/2
+  const double aprev = ctrl->acurr;
+  const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+  return (aprev - 1.0) / acn;
+}
+
 __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   const int64_t it = ctrl->iter;
   double acc[S_COUNT];
 #pragma unroll
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-
-  double kcoef = 0.0;
-  if (a.alg == 1) {  // admm.m:504, 567: aprev = acurr; acurr = (1+sqrt(1+4 aprev^2))/2
-    const double aprev = ctrl->acurr;
-    const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
-    kcoef = (aprev - 1.0) / acn;
-  }
-
+  const double kcoef = prox_kcoef(a, ctrl);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
     double ax = 0.0;
     for (int32_t cidx = 0; cidx < a.naxpart; ++cidx) ax += a.axsrc[static_cast<int64_t>(cidx) * a.axld + i];
-    if (a.a_identity) {
-      if (a.x_out) a.x_out[i] = ax;
-      if (a.xhist) a.xhist[it * a.len + i] = ax;
-    }
-    const double zp = a.z[i];
-    const double u_old = a.u[i];
-    const double uo = (a.alg == 0) ? u_old : a.uhat[i];
-    const double ci = a.c ? a.c[i] : 0.0;
-    // admm.m:517  Axhat = relax*A(x) - (1-relax)*(B(zprev) - c),  B = -1
-    const double axh = (a.relax != 1.0) ? a.relax * ax - (1.0 - a.relax) * ((-zp) - ci) : ax;
-    const double v = (axh + uo) - ci;
-    double zn;
-    switch (a.prox) {
-      case PROX_SOFT:
-        zn = soft(v, a.t);
-        break;
-      case PROX_HUBER:
-        zn = 1.0 / (1.0 + a.rho) * (a.rho * v + soft(v, 1.0 + 1.0 / a.rho));
-        break;
-      case PROX_HINGE: {
-        const double l = a.ell[i];
-        const double lv = l * v;
-        zn = v + l * fmax(fmin(1.0 - lv, a.t), 0.0);
-        break;
-      }
-      case PROX_01: {
-        const double l = a.ell[i];
-        const double s = l * v;
-        const double y = ((s >= 1.0) || (s < (1.0 - sqrt(2.0 / a.t)))) ? s : 1.0;
-        zn = l * y;
-        break;
-      }
-      case PROX_GIVEN:
-        zn = a.zgiven[i];
-        break;
-      case PROX_POS:
-        zn = fmax(v, 0.0);
-        break;
-      default:  // PROX_BOX
-        zn = fmin(a.ub[i], fmax(a.lb[i], v));
-        break;
-    }
-    const double Bz = -zn;
-    const double un = uo + ((axh + Bz) - ci);  // admm.m:542-550
-    const double r = (ax + Bz) - ci;           // admm.m:621 uses Ax, not Axhat
-    const double dzv = zn - zp;
-    acc[S_R2] += r * r;
-    acc[S_AX2] += ax * ax;
-    acc[S_Z2] += zn * zn;
-    acc[S_DZ2] += dzv * dzv;
-    acc[S_U2] += un * un;
-    const double du = un - u_old;
-    acc[S_DU2] += du * du;
-    if (a.objz == OBJZ_ABS) acc[S_OBJZ] += fabs(zn);
-    else if (a.objz == OBJZ_HUBER) acc[S_OBJZ] += huber_cvx(zn);
-    if (a.objx == OBJX_HINGE) acc[S_OBJX] += fmax(1.0 - a.ell[i] * ax, 0.0);
-    else if (a.objx == OBJX_ZEROONE) {
-      const double q = 1.0 - a.ell[i] * ax;
-      acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
-    } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
-    else if (a.objx == OBJX_DOT) acc[S_OBJX] += a.ell[i] * ax;
-
-    a.z[i] = zn;
-    a.u[i] = un;
-    if (a.dz) a.dz[i] = dzv;
-    if (a.zhist) a.zhist[it * a.len + i] = zn;
-    if (a.uhist) a.uhist[it * a.len + i] = un;
-
-    double zx = zn, ux = un;
-    if (a.alg == 1) {  // admm.m:568-569
-      zx = zn + kcoef * (zn - zp);
-      ux = un + kcoef * (un - u_old);
-      a.v[i] = zx;
-      a.uhat[i] = ux;
-      if (a.vhist) a.vhist[it * a.len + i] = zx;
-      if (a.uhathist) a.uhathist[it * a.len + i] = ux;
-    } else if (a.alg == 2) {  // decision needs d first: keep what the extrapolation kernel needs
-      const double vo = a.v[i];
-      const double duh = un - uo, dzv2 = zn - vo;
-      acc[S_DUH2] += duh * duh;
-      acc[S_DZV2] += dzv2 * dzv2;
-      a.zprev[i] = zp;
-      a.uprev[i] = u_old;
-    }
-    if (a.alg != 2 && a.rhs) {
-      switch (a.rhs_kind) {
-        case RHS_RHO_DTS:
-          a.rhs[i] = a.rho * (zx - ux) + a.rhs_add[i];
-          break;
-        case RHS_RHO_MINUS_Q:
-          a.rhs[i] = a.rho * (zx - ux) - a.rhs_add[i];
-          break;
-        case RHS_DIFF:
-          a.rhs[i] = zx - ux;
-          break;
-        case RHS_T1:
-          a.rhs[i] = (ci + zx) - ux;
-          break;
-        default:
-          break;
-      }
-    }
+    prox_element(a, i, ax, it, kcoef, acc);
   }
   block_reduce_slots(acc, a.part);
 }
+
+// (A variant of this kernel that gathered x_i straight from symv_lower_kernel's partial sums -- 16 elements x 16
+// slots per workgroup, saving the symv_reduce launch -- was measured SLOWER on the headline loop: 10.29k vs
+// 11.55k it/s.  625 workgroups instead of 40 make the 12-slot block reductions and the finalize kernel's
+// partial sums cost more than the launch they save.)
 
 __global__ __launch_bounds__(kBlock) void prez_kernel(PreZArgs a, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
