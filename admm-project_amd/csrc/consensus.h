@@ -11,7 +11,9 @@ struct SliceFactor {
   double* F = nullptr;      // lower Cholesky factor of D_k'D_k + rho*I   (getProxOps.m:424-435)
   int64_t n = 0, ld = 0;
   double* dinv = nullptr;   // inverted 64x64 diagonal blocks
-  double* Minv = nullptr;   // explicit inverse (xsolve = inverse)
+  double* Minv = nullptr;   // explicit inverse (xsolve = inverse), tile-padded like the engine's own (symv.hip)
+  int64_t ldM = 0;
+  SymvPlan planSy{};        // lower-triangle application for n >= 1536, one wave per column below
   TrsvPlan trsv{};
   double* work = nullptr;
   GemvTPlan plan{};

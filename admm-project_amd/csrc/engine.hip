@@ -373,16 +373,21 @@ int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int
     double* X = nullptr;
     ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
     int rc = trtri_lower_from_diag(W, n, ld, f.dinv, X, ld, e->stream);
-    if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(ld) * n);
+    f.planSy = symv_plan(n);
+    f.ldM = f.planSy.npad;
+    if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM);
     if (rc == ADMM_OK) {
-      launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, ld, true, e->stream);
-      launch_symmetrize_lower(f.Minv, n, ld, e->stream);
+      (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream);
+      launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, f.ldM, true, e->stream);
+      launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
     }
     (void)hipStreamSynchronize(e->stream);
     (void)hipFree(X);
     ADMM_TRY(rc);
-    f.plan = gemv_t_plan(n, n, ld);
-    ADMM_TRY(e->mem.alloc(&f.part, f.plan.part_elems(1)));
+    if (n >= 1536 && !e->syN) {  // partial-sum buffers of the lower-triangle kernel, shared by all slices (same n)
+      ADMM_TRY(e->mem.alloc(&e->syN, f.planSy.npart_elems()));
+      ADMM_TRY(e->mem.alloc(&e->syT, f.planSy.tpart_elems()));
+    }
   } else {
     double* dv = f.dinv;
     ADMM_TRY(trsv_build(W, n, ld, &dv, &f.trsv, e->stream));
@@ -393,8 +398,8 @@ int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int
 
 void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, double* out) {
   if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    launch_gemv_t(f.plan, f.Minv, y, nullptr, nullptr, 1, f.part, e->ctrl, e->stream);
-    launch_sum_partials(f.part, f.plan.nchunk, f.plan.ldg, f.n, out, e->ctrl, e->stream);
+    if (f.n >= 1536) launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream);
+    else launch_symv_small(f.Minv, f.n, f.ldM, y, out, e->ctrl, e->stream);
   } else {
     launch_trsv_pair(f.trsv, y, out, f.work, e->ctrl, e->stream);
   }

@@ -295,3 +295,21 @@ def test_lad_library_x_with_callers_z(gpu, relax):
                                           "userelax": int(relax != 1.0)})
     o = dict(A=D, At=D.T, B=-1, c=s_, m=m, nA=n, nB=m, relax=relax, maxiters=60)
     _compare(gpu.admm(minx, zt, dict(o)), A.admm(rminx, zn, dict(o)), tol=1e-7)
+
+
+# ---------------------------------------------------------------------------- large-n slice / second factors
+def test_consensus_lasso_large_n_uses_the_lower_triangle_kernel(gpu):
+    """n = 1600: the per-slice cached inverses are applied from their lower triangles (same kernel as the
+    headline x-solve); parity with the 2-slice oracle."""
+    p = gpu.synth.lasso_problem(4, 3400, 1600)
+    o = dict(objevals=1, parallel="both", maxiters=8)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, workers=2, xsolve="inverse"))
+    ref = S.lasso(p["D"], p["s"], p["lam"], o, workers=2)
+    _compare(got, ref, tol=1e-7)
+
+
+def test_model_large_n_both_factors(gpu):
+    """n = 1600: x- and z-update of the model problem both run the lower-triangle kernel on shared partial buffers."""
+    P, Q, r, s = _model_data(gpu, 5, 1700, 1600)
+    o = dict(objevals=1, maxiters=6, domaxiters=1)
+    _compare(gpu.model(P, Q, r, s, dict(o, xsolve="inverse")), S.model(P, Q, r, s, o), tol=1e-7)
