@@ -113,6 +113,7 @@ struct admm_engine {
   SymvPlan planSy{};    // Minv applied from its lower triangle only (half the bytes)
   double *syN = nullptr, *syT = nullptr;
   bool sy_half = false;
+  bool sy_split = false;  // multi-GPU: split the tiles of the x-solve over the ranks (decided by measurement at create)
   double *partDN = nullptr, *partDT = nullptr, *partSq = nullptr;
 
   // iterates
@@ -315,6 +316,29 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
       // zero once: with the tiles split over ranks, the slots of foreign tiles are never written
       ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * e->planSy.npart_elems(), e->stream));
       ADMM_HIP_TRY(hipMemsetAsync(e->syT, 0, sizeof(double) * e->planSy.tpart_elems(), e->stream));
+      // Multi-GPU: splitting the tiles over the ranks removes t*(1 - 1/N) of streaming time per x-solve and adds
+      // one all-reduce of n doubles.  Decide with the latency this communicator actually has (measured here, the
+      // mean over the ranks so that every rank takes the same decision): t = 4*npad^2 bytes at ~5.5 TB/s.
+      const int nr = e->comm ? comm_nranks(e->comm) : 1;
+      if (nr > 1) {
+        double* probe = e->syN;  // any device buffer of >= nF + 1 doubles
+        for (int k = 0; k < 3; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(nF), e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        const auto c0 = std::chrono::steady_clock::now();
+        const int reps = 10;
+        for (int k = 0; k < reps; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(nF), e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        double lat_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e6 / reps;
+        ADMM_HIP_TRY(hipMemcpyAsync(probe, &lat_us, sizeof(double), hipMemcpyHostToDevice, e->stream));
+        ADMM_TRY(comm_allreduce_device(e->comm, probe, 1, e->stream));
+        ADMM_HIP_TRY(hipMemcpyAsync(&lat_us, probe, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        lat_us /= nr;
+        const double t_us = 4.0 * static_cast<double>(e->planSy.npad) * static_cast<double>(e->planSy.npad) / 5.5e6;
+        e->sy_split = t_us * (1.0 - 1.0 / nr) > 1.15 * lat_us;
+        if (const char* f = std::getenv("ADMM_HIP_XSPLIT")) e->sy_split = f[0] == '1';  // tests force either form
+        ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * e->planSy.npart_elems(), e->stream));
+      }
     }
   } else {
     double* dv = e->dinv;
@@ -328,10 +352,7 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
 // all-reduce of n doubles assembles x (the only per-iteration collective of the cached-factor lasso loop)
 static int symv_apply(admm_engine* e, const double* y, double* out) {
   const int nr = e->comm ? comm_nranks(e->comm) : 1;
-  // splitting pays only when the streaming time it removes exceeds the latency of a small all-reduce
-  // (~25-30 us over xGMI): t = 4*npad^2 bytes at ~5.5 TB/s; n = 10^4 -> 73 us, so N >= 2 qualifies
-  const double t_us = 4.0 * static_cast<double>(e->planSy.npad) * static_cast<double>(e->planSy.npad) / 5.5e6;
-  if (nr > 1 && t_us * (1.0 - 1.0 / nr) > 30.0) {
+  if (nr > 1 && e->sy_split) {
     launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
     return comm_allreduce_device(e->comm, out, static_cast<size_t>(e->nF), e->stream);
   }
