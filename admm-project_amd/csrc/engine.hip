@@ -1621,7 +1621,6 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   }
 
   if (e->problem == ADMM_PROB_TOTALVARIATION) {
-    if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for total variation");
     if (o.relax != 1.0)
       return fail(ADMM_E_UNSUPPORTED,
                   "relaxation with total variation applies D twice in the reference (getProxOps.m:199); not implemented");
@@ -1683,6 +1682,89 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       fa.obj_scale_z = e->lambda;
     }
     const int check_tv = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+    if (alg != 0) {
+      // Fast / accelerated ADMM (admm.m:267-298, 563-600): the x-update takes (v, uhat), the generic fused prox
+      // kernel does the z/u update, extrapolation, histories and partial sums on the vector D*x, and the D'
+      // stencils of the dual residual come from dz = z - zprev and u.  z, u are updated in place here.
+      if (!e->dz) ADMM_TRY(e->mem.alloc(&e->dz, round_up(len, 2)));
+      if (!e->tmpA) ADMM_TRY(e->mem.alloc(&e->tmpA, round_up(len, 2)));
+      pa.dz = e->dz;
+      pa.t = e->lambda / o.rho;  // getProxOps.m:199
+      pa.objz = OBJZ_NONE;
+      pa.objx = OBJX_NONE;
+      pa.x_out = nullptr;
+      fa.obj_scale_x = 0.0;
+      fa.obj_scale_z = 0.0;
+      fa.obj_scale_part = o.objevals ? 1.0 : 0.0;
+      ta.part = e->part;
+      const auto t0f = std::chrono::steady_clock::now();
+      int32_t donef = 0;
+      bool stopf = false;
+      while (donef < N && !stopf) {
+        const int32_t batch = (N - donef < check_tv) ? N - donef : check_tv;
+        for (int32_t b = 0; b < batch; ++b) {
+          ta.z = e->v;  // x = xminf(x, v, uhat, rho)   admm.m:506
+          ta.u = e->uhat;
+          ta.y = e->tv_y;
+          {
+            TimerScope ts(e, ADMM_K_XSOLVE);
+            launch_tv_sweep(ta, false, e->ctrl, e->stream);
+            launch_tv_sweep(ta, true, e->ctrl, e->stream);
+          }
+          int nob = 0, nblk = 1;
+          launch_tv_dx(e->x, e->s, e->n, e->lambda, o.objevals, e->tmpA, e->objpart, &nob, e->ctrl, e->stream);
+          {
+            TimerScope ts(e, ADMM_K_PROX);
+            pa.axsrc = e->tmpA;
+            pa.naxpart = 1;
+            pa.axld = 0;
+            launch_prox(pa, e->ctrl, &nblk, e->stream);
+          }
+          fa.nblk = nblk;
+          fa.slots_reduced = nullptr;
+          fa.objp_reduced = nullptr;
+          if (alg == 2) {
+            launch_fast_decide(fa, e->stream);
+            launch_extrapolate(xa, e->ctrl, e->stream);
+          }
+          launch_tv_dual(e->dz, e->u, e->n, e->part, nblk, e->ctrl, e->stream);
+          fa.objpart = o.objevals ? e->objpart : nullptr;
+          fa.nobjpart = o.objevals ? nob : 0;
+          {
+            TimerScope ts(e, ADMM_K_FINALIZE);
+            launch_finalize(fa, e->stream);
+          }
+        }
+        donef += batch;
+        if (!o.domaxiters || donef >= N) {
+          ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+          ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+          if (e->ctrl_host->stop) stopf = true;
+        }
+      }
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      {
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+      }
+      if (e->profiling) collect_timers(e);
+      const int32_t stepsf = e->ctrl_host->steps;
+      e->last = admm_run_summary{};
+      e->last.steps = stepsf;
+      e->last.stopped_early = (stepsf < N) ? 1 : 0;
+      e->last.convtest_failed_at = e->ctrl_host->convfail;
+      e->last.runtime_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0f).count();
+      e->last.objopt = NAN;
+      if (o.objevals && stepsf > 0) {
+        double v = NAN;
+        ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (stepsf - 1), sizeof(double), hipMemcpyDeviceToHost));
+        e->last.objopt = v;
+      }
+      e->has_run = true;
+      if (summary) *summary = e->last;
+      return ADMM_OK;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     int32_t done = 0;
     bool stop_seen = false;

@@ -38,6 +38,13 @@ void launch_tv_sweep(const TvArgs& a, bool backward, const Ctrl* ctrl, hipStream
 void launch_tv_prox(const TvArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 // One launch per iteration: backward sweep (x) + z/u update + residual sums + the NEXT iteration's forward
 // sweep, 8 vector passes instead of 11.  Available when tv_fused_ok(a) (small halo: elems == 8).
+// Unfused building blocks for the fast / accelerated ADMM variants (the generic prox_kernel does the z/u/v/uhat
+// work): ax = D*x as a vector plus the objective 1/2||x-s||^2 + lambda*sum|x_{i+1}-x_i| in block partials, and the
+// D' stencils of the dual residual / tolerance from dz = z - zprev and u.
+void launch_tv_dx(const double* x, const double* s, int64_t n, double lambda, int objevals, double* ax,
+                  double* objpart, int* nobj_out, const Ctrl* ctrl, hipStream_t stream);
+void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, int nblk, const Ctrl* ctrl,
+                    hipStream_t stream);
 bool tv_fused_ok(const TvArgs& a);
 // slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced)
 void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream);

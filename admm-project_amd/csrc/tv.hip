@@ -536,6 +536,64 @@ __global__ __launch_bounds__(kBlock) void tv_pack_kernel(const double* __restric
   if (threadIdx.x == 0) out16[s] = t;
 }
 
+__global__ __launch_bounds__(kBlock) void tv_dx_kernel(const double* __restrict__ x, const double* __restrict__ s,
+                                                       int64_t n, double lambda, int objevals,
+                                                       double* __restrict__ ax, double* __restrict__ objpart,
+                                                       const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double xi = x[i];
+    const bool inner = i + 1 < n;
+    const double xn = inner ? x[i + 1] : 0.0;
+    ax[i] = inner ? xi - xn : xi;  // D = spdiags([1 -1], 0:1, n, n): the last row is x_n (totalvariation.m:127)
+    if (objevals) {                // totalvariation.m:134-135
+      const double e = xi - s[i];
+      acc += 0.5 * e * e + (inner ? lambda * fabs(xn - xi) : 0.0);
+    }
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) objpart[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void tv_dual_kernel(const double* __restrict__ dz, const double* __restrict__ u,
+                                                         int64_t n, double* __restrict__ part,
+                                                         const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  double a2 = 0.0, a3 = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double g2 = (i > 0) ? dz[i] - dz[i - 1] : dz[i];  // (D'w)_i = w_i - w_{i-1}
+    const double g3 = (i > 0) ? u[i] - u[i - 1] : u[i];
+    a2 += g2 * g2;
+    a3 += g3 * g3;
+  }
+  const double t2 = block_sum(a2, scratch);
+  const double t3 = block_sum(a3, scratch);
+  if (threadIdx.x == 0) {
+    part[S_G2 * kMaxPartBlocks + blockIdx.x] = t2;
+    part[S_G3 * kMaxPartBlocks + blockIdx.x] = t3;
+  }
+}
+
+void launch_tv_dx(const double* x, const double* s, int64_t n, double lambda, int objevals, double* ax,
+                  double* objpart, int* nobj_out, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(n, kBlock);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  if (blocks < 1) blocks = 1;
+  *nobj_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(tv_dx_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, x, s, n, lambda,
+                     objevals, ax, objpart, ctrl);
+}
+
+void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, int nblk, const Ctrl* ctrl,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(tv_dual_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, stream, dz, u, n, part, ctrl);
+}
+
 bool tv_fused_ok(const TvArgs& a) { return a.elems == 8 && a.ftile >= 512; }
 
 void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream) {

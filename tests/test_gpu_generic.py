@@ -313,3 +313,15 @@ def test_model_large_n_both_factors(gpu):
     P, Q, r, s = _model_data(gpu, 5, 1700, 1600)
     o = dict(objevals=1, maxiters=6, domaxiters=1)
     _compare(gpu.model(P, Q, r, s, dict(o, xsolve="inverse")), S.model(P, Q, r, s, o), tol=1e-7)
+
+
+# ---------------------------------------------------------------------------- 1-D TV with fast / accelerated ADMM
+@pytest.mark.parametrize("opts", [dict(fast=1, fasttype="strong", maxiters=80, objevals=1),
+                                  dict(fast=1, fasttype="weak", maxiters=80, objevals=1),
+                                  dict(fast=1, fasttype="strong", stopcond="both", convtest=0, rho=2.0, maxiters=60)])
+@pytest.mark.parametrize("n", [257, 5000])
+def test_totalvariation_fast_admm(gpu, opts, n):
+    p = gpu.synth.tv_problem(2, n)
+    got = gpu.totalvariation(p["s"], p["lam"], dict(opts))
+    ref = S.totalvariation(p["s"], p["lam"], dict(opts))
+    _compare(got, ref, tol=1e-7)
