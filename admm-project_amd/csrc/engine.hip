@@ -309,7 +309,7 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
     ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
     // lower-triangle form only where bandwidth matters: a 128x128 tile is 32 dependent panel steps of one
     // wave, so for small n the latency of that chain exceeds the whole column-dot GEMV (n = 400: 18k -> 2xk it/s)
-    e->sy_half = std::getenv("ADMM_HIP_FULL_SYMV") == nullptr && nF >= 1536;
+    e->sy_half = nF >= 1536;
     if (e->sy_half) {
       ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
       ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));

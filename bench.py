@@ -320,12 +320,8 @@ def main():
     # the same K steps without the HIP event records of the roofline leg in the stream
     dt_plain, _ = timed_run(eng, dist, a.steps, rho=rho)
     if a.xsolve == "inverse":
-        if os.environ.get("ADMM_HIP_FULL_SYMV"):
-            alg_bytes = 8.0 * n * n  # one pass over the full symmetric n x n inverse
-            kname = "gemv_t_kernel<1> (x = inv(D'D+rho I) * y as column dots of the symmetric inverse)"
-        else:
-            alg_bytes = 8.0 * n * (n + 1) / 2  # lower triangle of the symmetric inverse, read once
-            kname = "symv_lower_kernel (+ symv_reduce): x = inv(D'D+rho I) * y from the lower triangle only"
+        alg_bytes = 8.0 * n * (n + 1) / 2  # lower triangle of the symmetric inverse, read once
+        kname = "symv_lower_kernel (+ symv_reduce): x = inv(D'D+rho I) * y from the lower triangle only"
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "trsv_fwd/bwd_step kernels (x = L'\\(L\\y))"
@@ -333,7 +329,7 @@ def main():
     # run rocprofv3 on itself): valid for the default problem size and the symmetric-half kernel only
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if a.xsolve == "inverse" and n == 10000 and not os.environ.get("ADMM_HIP_FULL_SYMV") and os.path.exists(tfile):
+    if a.xsolve == "inverse" and n == 10000 and os.path.exists(tfile):
         with open(tfile) as fh:
             tj = json.load(fh)
         try:
