@@ -63,13 +63,21 @@ void run_n(const double* D, int64_t m, int64_t n, int64_t ld, const double* x, d
 // thread all land within 2 % of the product kernel; the pure-read pattern ceiling is ~6 % above it.
 // experimental variants of gemv_n: MODE 0 = product structure, 1 = no x loads (constant), 2 = x chunk staged
 // in LDS, 3 = product structure with RPT double2 per thread per column (512*RPT rows per block)
-template <int U, int RPT, int MODE, int NACC = U>
+template <int U, int RPT, int MODE, int NACC = U, int MAP = 0>
 __global__ __launch_bounds__(kBlock) void gemv_n_exp(const double* __restrict__ D, int64_t m, int64_t n, int64_t ld,
                                                      const double* __restrict__ x, double* __restrict__ ypart,
                                                      int64_t ldy, int64_t cols_per_chunk) {
   extern __shared__ double sx[];
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * (512 * RPT) + 2 * threadIdx.x;
-  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * cols_per_chunk;
+  int rb = blockIdx.x, cc = blockIdx.y;
+  if (MAP == 1) {  // the 8 XCDs take workgroups round-robin: give each XCD a contiguous range of row blocks
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, k = lin >> 3;
+    const int per = (gridDim.x + 7) / 8;
+    rb = xcd * per + (k % per);
+    cc = k / per;
+    if (rb >= static_cast<int>(gridDim.x) || cc >= static_cast<int>(gridDim.y)) return;
+  }
+  const int64_t row = static_cast<int64_t>(rb) * (512 * RPT) + 2 * threadIdx.x;
+  const int64_t j0 = static_cast<int64_t>(cc) * cols_per_chunk;
   const int64_t j1 = (j0 + cols_per_chunk < n) ? j0 + cols_per_chunk : n;
   if (MODE == 2) {
     for (int64_t j = j0 + threadIdx.x; j < j1; j += kBlock) sx[j - j0] = x[j];
@@ -108,21 +116,21 @@ __global__ __launch_bounds__(kBlock) void gemv_n_exp(const double* __restrict__ 
       s.x += acc[k][q].x;
       s.y += acc[k][q].y;
     }
-    *reinterpret_cast<double2_t*>(ypart + static_cast<int64_t>(blockIdx.y) * ldy + row + q * 512) = s;
+    *reinterpret_cast<double2_t*>(ypart + static_cast<int64_t>(cc) * ldy + row + q * 512) = s;
   }
 }
 
-template <int U, int RPT, int MODE, int NACC = U>
+template <int U, int RPT, int MODE, int NACC = U, int MAP = 0>
 void run_exp(const double* D, int64_t m, int64_t n, int64_t ld, const double* x, double* ypart, int chunks) {
   const int64_t cpc = ceil_div(n, chunks);
   const int nch = static_cast<int>(ceil_div(n, cpc));
   dim3 grid(static_cast<unsigned>(ceil_div(m, 512 * RPT)), static_cast<unsigned>(nch));
   char name[128];
-  snprintf(name, sizeof name, "gemv_n EXP U=%d RPT=%d mode=%d nacc=%d chunks=%3d grid=%u", U, RPT, MODE, NACC, nch, grid.x * grid.y);
+  snprintf(name, sizeof name, "gemv_n EXP U=%d RPT=%d mode=%d nacc=%d map=%d chunks=%3d grid=%u", U, RPT, MODE, NACC, MAP, nch, grid.x * grid.y);
   const size_t lds = MODE == 2 ? static_cast<size_t>(cpc) * 8 : 0;
   timeit(name,
          [&] {
-           hipLaunchKernelGGL((gemv_n_exp<U, RPT, MODE, NACC>), grid, dim3(kBlock), lds, 0, D, m, n, ld, x, ypart,
+           hipLaunchKernelGGL((gemv_n_exp<U, RPT, MODE, NACC, MAP>), grid, dim3(kBlock), lds, 0, D, m, n, ld, x, ypart,
                               round_up(m, 2), cpc);
          },
          8.0 * m * n);
@@ -168,12 +176,10 @@ int main(int argc, char** argv) {
     printf("default gemv_t plan: rows/chunk=%d chunks=%d\n", q.rows_per_chunk, q.nchunk);
   }
   for (int chunks : {21, 32}) run_n<8>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {60, 80, 100, 125, 160, 200}) run_exp<16, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {80, 125, 160}) run_exp<16, 1, 0, 4>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {80, 125, 160}) run_exp<16, 1, 0, 1>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {80, 125, 160}) run_exp<8, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {80, 125}) run_exp<24, 1, 0, 2>(D, m, n, ld, x, ypart, chunks);
-  for (int chunks : {80, 125}) run_exp<8, 2, 0, 2>(D, m, n, ld, x, ypart, chunks);
+  // cols_per_chunk multiples of 8 so that the tail-less EXP kernel streams everything: 10000/25 = 400, /50 = 200, /125 = 80
+  for (int chunks : {25, 50, 125}) run_exp<8, 1, 0, 8, 0>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {25, 50, 125}) run_exp<8, 1, 0, 8, 1>(D, m, n, ld, x, ypart, chunks);
+  for (int chunks : {25, 50, 125}) run_exp<8, 1, 0, 2, 1>(D, m, n, ld, x, ypart, chunks);
   for (int rc : {2048, 4096}) run_t<1>(D, m, n, ld, v, gpart, rc);
   for (int rc : {1024, 2048}) run_t<3>(D, m, n, ld, v, gpart, rc);
   return 0;
