@@ -33,11 +33,16 @@ _PROBLEMS = ("model", "basispursuit", "totalvariation", "linearsvm", "lasso", "l
 class _Problem:
     """Shared state behind a (minx, minz) pair: what getproxops' closure captured."""
 
-    def __init__(self, kind, engine, expect, extra=None):
+    def __init__(self, kind, engine, expect, extra=None, rebuild=None, rho=1.0):
         self.kind = kind
         self.engine = engine
         self.expect = expect  # constraint the solver must pass to admm: dict(A=..., c=..., nA, nB)
         self.extra = extra or {}
+        # closures of the reference that re-derive their cached data when admm passes a different rho
+        # (rhoprev logic: getProxOps.m:968-975, 1005-1008, 1441-1453; KKT systems 1363/1410 use the current rho):
+        # rebuild(rho) returns a fresh engine for that rho
+        self.rebuild = rebuild
+        self.rho = float(rho)
 
 
 class ProxOp:
@@ -168,18 +173,22 @@ def getproxops(problem, args):
         lp = kind == "linearprogram"
         q = np.asarray(_get(args, "b" if lp else "q"), dtype=np.float64).reshape(-1)
         P = None if lp else np.asarray(_get(args, "P"), dtype=np.float64)
-        K, k0 = _reduce_kkt(P, D, s, rho)
-        if lp:
-            eng = Engine(L.PROB_LINEARPROGRAM, q=q, K=K, k0=k0, rho=rho, device=dev)
-        else:
-            eng = Engine(L.PROB_QP_STANDARD, P=P, q=q, K=K, k0=k0, rho=rho, r=float(args.get("r", 0.0)), device=dev)
-        prob = _Problem(kind, eng, dict(A=1, c=0.0, nA=n, nB=n))
+        r0 = float(args.get("r", 0.0))
+
+        def build(rho_):
+            K, k0 = _reduce_kkt(P, D, s, rho_)
+            if lp:
+                return Engine(L.PROB_LINEARPROGRAM, q=q, K=K, k0=k0, rho=rho_, device=dev)
+            return Engine(L.PROB_QP_STANDARD, P=P, q=q, K=K, k0=k0, rho=rho_, r=r0, device=dev)
+
+        prob = _Problem(kind, build(rho), dict(A=1, c=0.0, nA=n, nB=n), rebuild=build, rho=rho)
     elif kind == "quadraticprogram":
         P, q = _get(args, "P"), _get(args, "q")
         n = P.shape[0]
-        eng = Engine(L.PROB_QP_BOUNDED, P=P, q=q, lb=_get(args, "lb"), ub=_get(args, "ub"),
-                     rho=float(_get(args, "rho")), r=float(args.get("r", 0.0)), xsolve=xs, device=dev)
-        prob = _Problem("quadraticprogram", eng, dict(A=1, c=0.0, nA=n, nB=n))
+        lb, ub, r0 = _get(args, "lb"), _get(args, "ub"), float(args.get("r", 0.0))
+        build = lambda rho_: Engine(L.PROB_QP_BOUNDED, P=P, q=q, lb=lb, ub=ub, rho=rho_, r=r0, xsolve=xs, device=dev)
+        rho = float(_get(args, "rho"))
+        prob = _Problem("quadraticprogram", build(rho), dict(A=1, c=0.0, nA=n, nB=n), rebuild=build, rho=rho)
     elif kind == "totalvariation":
         sig = np.asarray(_get(args, "s"), dtype=np.float64).reshape(-1)
         n = sig.size
@@ -207,9 +216,10 @@ def getproxops(problem, args):
         objdata = {}
         if all(k in args for k in ("P", "Q", "r", "s")):
             objdata = dict(D=args["P"], s=args["r"], D2=args["Q"], s2=args["s"])
-        eng = Engine(L.PROB_MODEL, P=PtP, q=Ptr, Q=QtQ, qz=Qts, nvec=n, rho=float(args.get("rho", 1.0)),
-                     xsolve=xs, device=dev, **objdata)
-        prob = _Problem("model", eng, dict(A=1, c=0.0, nA=n, nB=n))
+        build = lambda rho_: Engine(L.PROB_MODEL, P=PtP, q=Ptr, Q=QtQ, qz=Qts, nvec=n, rho=rho_, xsolve=xs, device=dev,
+                                    **objdata)
+        rho = float(args.get("rho", 1.0))
+        prob = _Problem("model", build(rho), dict(A=1, c=0.0, nA=n, nB=n), rebuild=build, rho=rho)
     else:
         raise NotImplementedError(f"problem '{kind}' is outside the engine's hot-path scope (SURVEY.md section 8)")
     return ProxOp(prob, "x"), ProxOp(prob, "z"), extra
@@ -313,6 +323,11 @@ def admm(xminf, zming, options):
                                       "(supported: " + ", ".join(_CALLBACK_KINDS) + ")")
     else:
         prob = _generic_problem(options)  # both handles are the caller's: admm.m:24 as is (A = 1, B = -1)
+    rho_run = float(_setopt(options, "rho", 1.0))
+    if prob.rebuild is not None and rho_run != prob.rho and rho_run > 0:
+        prob.engine.close()  # the closure's "rho ~= rhoprev" branch: new cached factor / KKT reduction
+        prob.engine = prob.rebuild(rho_run)
+        prob.rho = rho_run
     eng = prob.engine
     _check_constraint(options, prob)
     user_obj = options.get("obj") if callable(options.get("obj")) else None

@@ -325,3 +325,15 @@ def test_totalvariation_fast_admm(gpu, opts, n):
     got = gpu.totalvariation(p["s"], p["lam"], dict(opts))
     ref = S.totalvariation(p["s"], p["lam"], dict(opts))
     _compare(got, ref, tol=1e-7)
+
+
+def test_rho_given_to_admm_differs_from_getproxops(gpu):
+    """getProxOps.m:968-975, 1005-1008 (rhoprev logic): the model closures follow the rho admm passes, whatever
+    getproxops was called with; the device engine is rebuilt for the new rho."""
+    P, Q, r, s = _model_data(gpu, 2, 90, 70)
+    args = dict(PtP=P.T @ P, Ptr=P.T @ r, QtQ=Q.T @ Q, Qts=Q.T @ s, n=70)
+    minx, minz, _ = gpu.getproxops("model", args)          # built for rho = 1
+    rminx, rminz, _ = PR.getproxops("model", args)
+    for rho in (2.5, 0.4, 2.5):
+        o = _constraint(70, rho=rho, maxiters=40)
+        _compare(gpu.admm(minx, minz, dict(o)), A.admm(rminx, rminz, dict(o)), tol=TOL)
