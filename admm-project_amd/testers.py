@@ -13,7 +13,7 @@ import numpy as np
 from . import solvers, synth
 
 __all__ = ["lassotest", "ladtest", "huberfittest", "totalvariationtest", "linearsvmtest", "basispursuittest",
-           "linearprogramtest", "modeltest"]
+           "linearprogramtest", "modeltest", "solvertester"]
 
 
 def _opts(options, **forced):
@@ -151,3 +151,66 @@ def modeltest(seed=0, rows=2 ** 7, cols=2 ** 7, errtol=1e-3, quiet=1, options=No
                 failed=int(not (abs(1.0 - obj(xopt) / obj(xt)) <= errtol and np.linalg.norm(xt - xopt) <= errtol)),
                 steps=results["steps"])
     return results, test
+
+
+def _sizes(solver, scale, options):
+    """Default scalers of testers/solvertester.m (343-361, 396-408, 480-492, 583-595): problem size per scale."""
+    scaler = options.get("scaler")
+    if callable(scaler):
+        m, n = scaler(scale)
+        return int(m), int(n)
+    ttype = options.get("testtype", "default")
+    if solver == "model":
+        if ttype == "fat":
+            return 2 ** (scale - 1), 2 ** scale
+        if ttype == "skinny":
+            return 2 ** scale, 2 ** (scale - 1)
+        return 2 ** scale, 2 ** scale
+    if solver in ("basispursuit", "linearprogram"):
+        n = 2 ** scale
+        return -(-n // 5), n
+    if solver == "totalvariation":
+        return 2 ** scale, 1
+    # lasso, lad, huberfit: skinny (8x more rows) unless asked otherwise
+    if ttype == "fat":
+        return max(1, 2 ** (scale - 3)), 2 ** scale
+    if ttype == "square":
+        return 2 ** scale, 2 ** scale
+    return 2 ** scale, max(1, 2 ** (scale - 3))
+
+
+def solvertester(solver="model", minscale=2, maxscale=8, trials=10, showplots=0, options=None):
+    """results = solvertester(solver, minscale, maxscale, trials, showplots, options)
+    (testers/solvertester.m:29-275): run the solver's tester `trials` times at every scale from minscale to
+    maxscale (problem sizes 2^scale by the reference's default scalers) and collect runtimes and failures.
+    ``showplots`` is accepted and ignored (plots are not part of the engine)."""
+    options = dict(options or {})
+    tests = {"model": modeltest, "basispursuit": basispursuittest, "linearprogram": linearprogramtest,
+             "lasso": lassotest, "totalvariation": totalvariationtest, "lad": ladtest, "huberfit": huberfittest}
+    if solver not in tests:
+        raise ValueError("Given solver is not a supported solver to test!")
+    if not (int(minscale) >= 1 and int(maxscale) >= int(minscale) and int(trials) >= 1):
+        raise ValueError("minscale, maxscale and trials must be positive integers with maxscale >= minscale!")
+    if "errtol" not in options:  # solvertester.m:93-101
+        options["errtol"] = 1e-10 if solver in ("basispursuit", "linearprogram") else 1e-3
+    seed_rng = np.random.default_rng(options.get("seed"))
+    passthrough = {k: v for k, v in options.items() if k not in ("errtol", "testtype", "scaler", "seed")}
+    nscale = int(maxscale) - int(minscale) + 1
+    runtimes = np.zeros((nscale, int(trials)))
+    failed = np.zeros((nscale, int(trials)), dtype=int)
+    steps = np.zeros((nscale, int(trials)), dtype=int)
+    seeds = np.zeros((nscale, int(trials)), dtype=np.int64)
+    for r, scale in enumerate(range(int(minscale), int(maxscale) + 1)):
+        m, n = _sizes(solver, scale, options)
+        for c in range(int(trials)):
+            seed = int(seed_rng.integers(0, 2 ** 31 - 1))
+            if solver == "totalvariation":
+                res, test = tests[solver](seed, m, options["errtol"], 1, passthrough)
+            else:
+                res, test = tests[solver](seed, m, n, options["errtol"], 1, passthrough)
+            seeds[r, c] = seed
+            runtimes[r, c] = res["solverruntime"]
+            failed[r, c] = test["failed"]
+            steps[r, c] = res["steps"]
+    return dict(solver=solver, scales=list(range(int(minscale), int(maxscale) + 1)), runtimes=runtimes, failed=failed,
+                steps=steps, seeds=seeds, avetimes=runtimes.mean(axis=1), failure=int(failed.any()), errtol=options["errtol"])

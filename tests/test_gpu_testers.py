@@ -1,4 +1,5 @@
 """The reference's testers (testers/*.m) run on the device solvers: each one's own pass criterion holds."""
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -30,3 +31,30 @@ def test_linearprogramtest_reports_the_reference_quantities(gpu):
     results, test = gpu.testers.linearprogramtest(1)
     assert test["relerror"] <= 1e-3
     assert test["objopt"] <= test["trueobjopt"] * (1 + 1e-3)
+
+
+def test_solvertester_demo_session(gpu):
+    """solvertester.m's no-argument demo: the model solver, scales 2..8 (kept to 2..6 and 2 trials here)."""
+    res = gpu.testers.solvertester("model", 2, 6, 2, 0, dict(seed=3))
+    assert res["runtimes"].shape == (5, 2) and res["failed"].shape == (5, 2)
+    assert res["avetimes"].shape == (5,) and np.all(res["runtimes"] > 0) and np.all(res["steps"] >= 1)
+    assert res["failure"] == int(res["failed"].any())
+    # tiny random systems need not meet the 1e-3 criterion; what must hold is that the device run takes the same
+    # number of steps and gets the same verdict as the oracle on the same problem
+    from oracle import solvers_ref as S
+    for r, scale in enumerate(res["scales"]):
+        for c in range(2):
+            p = gpu.synth.model_problem(int(res["seeds"][r, c]), 2 ** scale, 2 ** scale)
+            P, Q, rr, ss = p["P"], p["Q"], p["r"], p["s"]
+            ref = S.model(P, Q, rr, ss, dict(objevals=1, maxiters=10000, convtest=1, stopcond="both"))
+            xt = np.linalg.solve(P.T @ P + Q.T @ Q, P.T @ rr + Q.T @ ss)
+            obj = lambda x: 0.5 * np.sum((P @ x - rr) ** 2) + 0.5 * np.sum((Q @ x - ss) ** 2)
+            if "steps" not in ref:  # the oracle's convergence test aborted (q4): nothing to compare
+                continue
+            ref_failed = int(not (abs(1.0 - obj(ref["xopt"]) / obj(xt)) <= 1e-3
+                                  and np.linalg.norm(xt - ref["xopt"]) <= 1e-3))
+            assert res["steps"][r, c] == ref["steps"] and res["failed"][r, c] == ref_failed, (scale, c)
+    res = gpu.testers.solvertester("lasso", 5, 8, 2, 0, dict(seed=4))
+    assert res["failed"].sum() == 0
+    with pytest.raises(ValueError, match="not a supported solver"):
+        gpu.testers.solvertester("nope", 2, 3, 1)
