@@ -25,6 +25,8 @@ struct CgArgs {
   double* part;      // [2][kMaxPartBlocks]
   CgState* st;
   const Ctrl* ctrl;
+  int32_t* skip;     // nullable: mirrors (done || ctrl->stop) into the first word of a Ctrl-shaped block, so that the
+                     // operator's own kernels (gemv_n / gemv_t, which only know `ctrl->stop`) become no-ops too
 };
 
 // q = sum of the gemv_t chunk partials + shift*p (and the block partials of p.q when with_dot)

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void cg_start_kernel(CgArgs a, int nblk) {
     a.st->ynorm = sqrt(yy);
     a.st->iters = 0;
     a.st->done = (sqrt(rs) <= a.tol * sqrt(yy)) ? 1 : 0;
+    if (a.skip) *a.skip = a.st->done;
   }
 }
 
@@ -116,7 +117,10 @@ __global__ void cg_advance_kernel(CgArgs a, int nblk) {
     a.st->rs = rsn;
     a.st->iters += 1;
     a.st->total += 1;
-    if (sqrt(rsn) <= a.tol * a.st->ynorm || a.st->iters >= a.maxit) a.st->done = 1;
+    if (sqrt(rsn) <= a.tol * a.st->ynorm || a.st->iters >= a.maxit) {
+      a.st->done = 1;
+      if (a.skip) *a.skip = 1;
+    }
   }
 }
 

@@ -133,6 +133,8 @@ struct admm_engine {
   bool cg_shift_is_rho = false;
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_tmp = nullptr, *cg_part = nullptr;
   CgState* cg_st = nullptr;
+  Ctrl* cg_skip = nullptr;  // Ctrl-shaped block whose .stop mirrors (CG converged || ctrl->stop): skips the operator kernels
+  int cg_chunk = 8;         // inner iterations enqueued between polls: follows the last solve's count
   CgState* cg_st_host = nullptr;  // pinned
   int64_t cg_total_last = 0;
   // consensus lasso (getProxOps.m:383-442, 1217-1343)
@@ -921,6 +923,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     e->cg_st = reinterpret_cast<CgState*>(st);
     E_HIP(hipMemsetAsync(e->cg_st, 0, sizeof(CgState), e->stream));
     E_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->cg_st_host), sizeof(CgState), hipHostMallocDefault));
+    double* sk = nullptr;
+    E_TRY(e->mem.alloc(&sk, (sizeof(Ctrl) + 7) / 8));
+    e->cg_skip = reinterpret_cast<Ctrl*>(sk);
+    E_HIP(hipMemsetAsync(e->cg_skip, 0, sizeof(Ctrl), e->stream));
   }
   e->tv_zA = e->z;
   e->tv_uA = e->u;
@@ -965,14 +971,15 @@ static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t
     *ldq = 0;
     return ADMM_OK;
   }
+  const Ctrl* sk = e->cg_skip;  // no-ops once this solve has converged (or the run has stopped)
   {
     TimerScope ts(e, ADMM_K_GEMV_N);
-    launch_gemv_n(e->planDN, e->D, v, e->partDN, e->ctrl, e->stream);
+    launch_gemv_n(e->planDN, e->D, v, e->partDN, sk, e->stream);
   }
-  launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, e->ctrl, e->stream);
+  launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, sk, e->stream);
   {
     TimerScope ts(e, ADMM_K_GEMV_T);
-    launch_gemv_t(e->planDT, e->D, e->tmpA, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+    launch_gemv_t(e->planDT, e->D, e->tmpA, nullptr, nullptr, 1, e->partDT, sk, e->stream);
   }
   *qin = e->partDT;
   *nchunk = e->planDT.nchunk;
@@ -1015,11 +1022,8 @@ static int cg_solve_tv2d(admm_engine* e, const double* y) {
   int cur = 0;
   launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[1], true, e->stream);  // q = A p, p.q (beta = 0)
   cur = 1;
-  const int chunk = 8;
+  const int chunk = e->cg_chunk;  // as long as the previous solve: launches after convergence are no-ops
   for (int done_it = 0; done_it < e->cg_maxit;) {
-    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
-    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->cg_st_host->done || e->ctrl_host->stop) break;
     const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
     for (int c = 0; c < k; ++c) {
       a.p = pbuf[cur];
@@ -1029,7 +1033,11 @@ static int cg_solve_tv2d(admm_engine* e, const double* y) {
       launch_cg_advance(a, e->stream);  // rs <- (r.r)_new, convergence flag
     }
     done_it += k;
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
   }
+  e->cg_chunk = std::min(64, std::max(4, static_cast<int>(e->cg_st_host->iters) + 2));
   return ADMM_OK;
 }
 
@@ -1049,8 +1057,10 @@ static int cg_solve(admm_engine* e, const double* y) {
   a.part = e->cg_part;
   a.st = e->cg_st;
   a.ctrl = e->ctrl;
-  // clear iters/done of the previous solve (total keeps counting)
+  a.skip = &e->cg_skip->stop;
+  // clear iters/done of the previous solve (total keeps counting) and re-arm the operator kernels
   ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_skip->stop, 0, sizeof(int32_t), e->stream));
   const double* qin;
   int32_t nchunk;
   int64_t ldq;
@@ -1059,11 +1069,10 @@ static int cg_solve(admm_engine* e, const double* y) {
   a0.p = e->x;  // q = D'D x + shift*x
   launch_cg_q(a0, qin, nchunk, ldq, false, e->stream);
   launch_cg_init(a, e->stream);
-  const int chunk = 4;
+  // everything enqueued after convergence is a no-op (operator kernels included), so a chunk can be as long as
+  // the previous solve was: one or two polls of the device per solve instead of one per 4 iterations
+  const int chunk = e->cg_chunk;
   for (int done_it = 0; done_it < e->cg_maxit;) {
-    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
-    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->cg_st_host->done || e->ctrl_host->stop) break;
     const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
     for (int c = 0; c < k; ++c) {
       ADMM_TRY(cg_apply(e, e->cg_p, &qin, &nchunk, &ldq));
@@ -1071,7 +1080,11 @@ static int cg_solve(admm_engine* e, const double* y) {
       launch_cg_step_tail(a, e->stream);
     }
     done_it += k;
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
   }
+  e->cg_chunk = std::min(64, std::max(4, static_cast<int>(e->cg_st_host->iters) + 2));
   return ADMM_OK;
 }
 
