@@ -69,6 +69,7 @@ class Options(C.Structure):
         ("stopcond", C.c_int32), ("nodualerror", C.c_int32), ("record_history", C.c_int32),
         ("check_every", C.c_int32),
         ("x0", _dp), ("z0", _dp), ("u0", _dp),
+        ("stale_factor_ok", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

@@ -300,6 +300,102 @@ def _generic_problem(options):
     return _Problem("generic", eng, dict(A=1, c=0.0, nA=n, nB=n))
 
 
+_ADAPTIVE_KINDS = ("lasso", "lad", "huberfit", "totalvariation", "linearsvm", "quadraticprogram", "basispursuit",
+                   "linearprogram", "generic")  # B = -1: ||B dz|| of the H-norm is ||dz||
+
+
+def _admm_adaptive(xminf, zming, options, prob):
+    """options.adaptive (experimental, admm.m:724-741): rho changes after every iteration i > 2, so the loop is
+    stepped from the host -- one device iteration per step, warm-started from the previous (x, z, u), with the
+    closures' "rho ~= rhoprev" re-factorisation (prob.rebuild) in between.  The H-norm keeps the rho it was
+    created with (MATLAB anonymous functions capture by value, admm.m:305-309) while w = [x; z; rho*u] uses the
+    current one (admm.m:678)."""
+    if _setopt(options, "fast", 0):
+        raise NotImplementedError("options.adaptive together with fast ADMM is not supported")
+    if prob.kind not in _ADAPTIVE_KINDS:
+        raise NotImplementedError(f"options.adaptive is not supported for the '{prob.kind}' operators")
+    rho = float(_setopt(options, "rho", 1.0))
+    rho_H = rho
+    N = _setopt(options, "maxiters", 1000)
+    N = int(math.ceil(float(np.real(N)))) if N > 0 else 1000
+    domaxiters = _setopt(options, "domaxiters", 0)
+    nodualerror = _setopt(options, "nodualerror", 0)
+    objevals = bool(_setopt(options, "objevals", 0))
+    convtol = _setopt(options, "convtol", 1e-10)
+    Hnormtol = _setopt(options, "Hnormtol", 1e-6)
+    stopcond = _setopt(options, "stopcond", "standard")
+    nA, nB = prob.expect["nA"], prob.expect["nB"]
+    state = {k: (np.zeros(n) if options.get(k) is None else np.array(options[k], dtype=np.float64).reshape(-1))
+             for k, n in (("x0", nA), ("z0", nB), ("u0", nB))}
+    results = dict(state)
+    results["Hnormtol"] = Hnormtol
+    hist = {k: [] for k in ("xvals", "zvals", "uvals", "wvals", "pnorm", "dnorm", "perr", "derr", "objevals",
+                            "Hnormsq")}
+    x, z, u = state["x0"], state["z0"], state["u0"]
+    w = np.concatenate([x, z, rho * u])
+    runtime, step, failed, i = 0.0, None, 0, 0
+
+    def pack():
+        for k in ("xvals", "zvals", "uvals", "wvals"):
+            results[k] = np.asfortranarray(np.stack(hist[k], axis=1))
+        for k in ("pnorm", "dnorm", "perr", "derr", "Hnormsq") + (("objevals",) if objevals else ()):
+            results[k] = np.array(hist[k])
+
+    for i in range(1, N + 1):
+        # closures without a "rho ~= rhoprev" branch keep their factor (xminLASSO, getProxOps.m:1192-1206)
+        o = dict(options, adaptive=0, convtest=0, stopcond="standard", maxiters=1, domaxiters=1, quiet=1, rho=rho,
+                 x0=x, z0=z, u0=u, record_history=0, stale_factor_ok=int(prob.rebuild is None))
+        step = admm(xminf, zming, o)
+        runtime += step["runtime"]
+        x, z, u = step["xopt"], step["zopt"], step["uopt"]
+        for k, v in (("xvals", x), ("zvals", z), ("uvals", u)):
+            hist[k].append(v)
+        for k in ("pnorm", "dnorm", "perr", "derr"):
+            hist[k].append(float(step[k][0]))
+        if objevals:
+            hist["objevals"].append(float(step["objevals"][0]))
+        wprev, w = w, np.concatenate([x, z, rho * u])  # admm.m:677-682
+        hist["wvals"].append(w)
+        dw = wprev - w
+        hist["Hnormsq"].append(rho_H * float(dw[nA:nA + nB] @ dw[nA:nA + nB]) + rho_H * float(dw[nA + nB:] @ dw[nA + nB:]))
+        H1 = H2 = None
+        if i >= 2:
+            H2, H1 = hist["Hnormsq"][-1], hist["Hnormsq"][-2]
+            if H1 > np.finfo(float).eps and H2 > H1 and not ((H2 - H1) <= H1 * convtol):  # q4: early return
+                failed = i
+                break
+        if stopcond in ("standard", "both") and not domaxiters and hist["pnorm"][-1] < hist["perr"][-1] and (
+                nodualerror or hist["dnorm"][-1] < hist["derr"][-1]):
+            break
+        if stopcond in ("hnorm", "both") and not domaxiters and i > 2 and hist["Hnormsq"][-1] <= Hnormtol:
+            break
+        if i > 2:  # admm.m:724-741 (wdiff is the scalar H1 - H2)
+            growthtol = 5
+            wdiff = np.float64(H1 - H2)  # MATLAB arithmetic: 0/0 is NaN, not an exception
+            rhoprev = rho
+            rho = rho * (wdiff * rhoprev) / (wdiff * wdiff)
+            rhodiff = abs(rho - rhoprev)
+            if rhodiff >= rhoprev * growthtol:
+                rho = rho / growthtol
+            elif rhodiff <= rhoprev / growthtol:
+                rho = rho * growthtol
+    pack()
+    if failed:
+        print(f"Iteration {failed}: H norms not converging to given relative tolerance: "
+              f"{(H2 - H1) / (H1 + np.finfo(float).eps):g} is not less or equal to tol. {convtol:g}")
+        print("ADMM seems to not be converging! Please check that your proximal operators are correct!")
+        results["convtest_failed_at"] = failed
+        return results
+    results["steps"] = i
+    results["xopt"], results["zopt"], results["uopt"] = x, z, u
+    if objevals:
+        results["objopt"] = float(step["objopt"])
+    results["runtime"] = runtime
+    results["rho_final"] = rho  # extension: the step size the next iteration would have used
+    results["options"] = options
+    return results
+
+
 def admm(xminf, zming, options):
     """Run ADMM on the device (admm.m:24).  See the module docstring."""
     if not isinstance(options, dict):
@@ -344,8 +440,8 @@ def admm(xminf, zming, options):
     if prob.kind == "lasso-consensus" and not ("altu" in options and "specialnorms" in options):
         raise ValueError("consensus lasso needs options.altu and options.specialnorms from getproxops' extra "
                          "(lasso.m:222-223)")
-    if _setopt(options, "adaptive", 0):
-        raise NotImplementedError("options.adaptive (experimental in the reference, admm.m:724-741) is not supported")
+    if _setopt(options, "adaptive", 0) and _setopt(options, "convtest", 0):  # admm.m:724: only with convtest
+        return _admm_adaptive(xminf, zming, options, prob)
     par = _setopt(options, "parallel", "none")
     if par in ("xminf", "zming", "both"):
         # admm.m:343-468 (parproxf / parproxg): the prox is evaluated slice by slice on the pool's workers and
@@ -393,7 +489,7 @@ def admm(xminf, zming, options):
                        reltol=_setopt(options, "reltol", 1e-3), Hnormtol=_setopt(options, "Hnormtol", 1e-6),
                        restart=_setopt(options, "restart", 0.999), dvaltol=_setopt(options, "dvaltol", 1e-8),
                        record_history=record_history, check_every=int(options.get("check_every", 0)),
-                       x0=x0, z0=z0, u0=u0)
+                       x0=x0, z0=z0, u0=u0, stale_factor_ok=options.get("stale_factor_ok", 0))
     finally:
         if use_callbacks:
             eng.set_callbacks()  # the library operators are the engine's default again

@@ -1196,7 +1196,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   if (o.restart <= 0.0 || o.restart >= 1.0) o.restart = 0.999;  // admm.m:285-287
   if (o.fast != ADMM_FAST_OFF && o.fast != ADMM_FAST_WEAK && o.fast != ADMM_FAST_STRONG)
     return fail(ADMM_E_INVALID, "bad options.fast");
-  if (o.rho != e->rho_factor && (e->F || e->has_zfac || e->Kmat) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
+  if (o.rho != e->rho_factor && !o.stale_factor_ok && (e->F || e->has_zfac || e->Kmat) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
       e->problem != ADMM_PROB_LINEARSVM)
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)

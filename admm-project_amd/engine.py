@@ -241,7 +241,8 @@ class Engine:
     # ------------------------------------------------------------------ run / fetch
     def run(self, *, rho=1.0, maxiters=1000, domaxiters=0, relax=1.0, fast=L.FAST_OFF, objevals=0, convtest=0,
             convtol=1e-10, stopcond="standard", nodualerror=0, abstol=1e-5, reltol=1e-3, Hnormtol=1e-6,
-            restart=0.999, dvaltol=1e-8, record_history=1, check_every=0, x0=None, z0=None, u0=None):
+            restart=0.999, dvaltol=1e-8, record_history=1, check_every=0, x0=None, z0=None, u0=None,
+            stale_factor_ok=0):
         o = L.Options()
         self._lib.admm_options_default(C.byref(o))
         o.rho, o.relax, o.abstol, o.reltol = float(rho), float(relax), float(abstol), float(reltol)
@@ -255,6 +256,7 @@ class Engine:
         o.nodualerror = int(bool(nodualerror))
         o.record_history = int(bool(record_history))
         o.check_every = int(check_every)
+        o.stale_factor_ok = int(bool(stale_factor_ok))
         keep = []
         for name, val in (("x0", x0), ("z0", z0), ("u0", u0)):
             if val is not None:

@@ -173,6 +173,10 @@ typedef struct admm_options {
   const double* x0;     /* optional warm start, HOST pointers (admm.m:252-254) */
   const double* z0;
   const double* u0;
+  int32_t stale_factor_ok; /* 1 = run with options.rho != the rho the cached factor was built with, as xminLASSO does
+                              (getProxOps.m:1192-1206 never re-factors; needed by options.adaptive, admm.m:724-741);
+                              0 = refuse the mismatch (default: it is almost always a caller's mistake) */
+  int32_t reserved1;
 } admm_options;
 
 typedef struct admm_run_summary {

@@ -327,7 +327,7 @@ def admm(xminf, zming, options):
         # experimental adaptive rho (admm.m:724-741)
         if adaptive and convtest and i > 2:
             growthtol = 5
-            wdiff = H1 - H2
+            wdiff = np.float64(H1 - H2)  # MATLAB arithmetic: 0/0 is NaN, not an exception
             rhoprev = rho
             rho = rho * (wdiff * rhoprev) / (wdiff * wdiff)
             rhodiff = abs(rho - rhoprev)

@@ -337,3 +337,26 @@ def test_rho_given_to_admm_differs_from_getproxops(gpu):
     for rho in (2.5, 0.4, 2.5):
         o = _constraint(70, rho=rho, maxiters=40)
         _compare(gpu.admm(minx, minz, dict(o)), A.admm(rminx, rminz, dict(o)), tol=TOL)
+
+
+@pytest.mark.parametrize("solver", ["lasso", "quadraticprogram"])
+def test_adaptive_rho(gpu, solver):
+    """a14 (admm.m:724-741): rho changes after every iteration i > 2 -- host-stepped device iterations, with the
+    closures' re-factorisation on rho changes, against the oracle's loop."""
+    # the reference's update rho <- rho^2/(H1 - H2) is unstable: with xminLASSO's never-refreshed factor
+    # (getProxOps.m:1192-1206) the H-norm jumps at the first change and rho turns negative one iteration later
+    # (the engine refuses rho <= 0), so the lasso case stops after the first adapted iteration; LAD from zero
+    # starts has H1 == H2 (rho = NaN).  The QP re-factors (getProxOps.m:1441-1456) and stays tame.
+    o = dict(adaptive=1, convtest=1, convtol=1e9, objevals=1, maxiters=4 if solver == "lasso" else 6, domaxiters=1)
+    if solver == "lasso":
+        p = gpu.synth.lasso_problem(3, 120, 40)
+        got, ref = gpu.lasso(p["D"], p["s"], p["lam"], dict(o)), S.lasso(p["D"], p["s"], p["lam"], dict(o))
+    else:
+        rng = np.random.default_rng(5)
+        M = rng.standard_normal((24, 24))
+        P, q = M @ M.T + np.eye(24), rng.standard_normal(24)
+        lb, ub = -np.ones(24), np.ones(24)
+        got = gpu.quadraticprogram(P, q, 0.0, lb, ub, dict(o))
+        ref = S.quadraticprogram_bounded(P, q, 0.0, lb, ub, dict(o))
+    _compare(got, ref, tol=1e-6)
+    assert got["steps"] == o["maxiters"] and got["rho_final"] != 1.0
