@@ -200,7 +200,7 @@ def getproxops(problem, args):
             raise ValueError("Argument s is not an image (2-D array)!")
         H, W = img.shape
         eng = Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=float(_get(args, "lambda")),
-                     shape=(H, W), device=dev, **cg)
+                     shape=(H, W), xsolve=xs, device=dev, **cg)
         prob = _Problem("totalvariation2d", eng, dict(A="D", c=0.0, nA=H * W, nB=2 * H * W))
     elif kind == "basispursuit":
         P, q = _get(args, "P"), _get(args, "q")

@@ -1,0 +1,35 @@
+// dct.h -- direct x-update of 2-D total variation: (I + rho*D'D) is diagonalised by the 2-D DCT-II (D'D is the
+// 5-point Laplacian with Neumann boundaries), so x = C' diag(1/(1 + rho*(lam_i + lam_j))) C b in five streaming
+// passes instead of ~35 CG iterations.  Engine-side extension (the reference has no 2-D solver; tv2d.h).
+#pragma once
+#include "common.h"
+
+namespace admm {
+
+struct DctTables {        // device tables of one transform length n = 2^log2n
+  int32_t n, log2n;
+  const admm_double2* tw;   // e^{-2 pi i k / n},     k < n/2        (FFT twiddles)
+  const admm_double2* c4;   // e^{-i pi k / (2n)},    k <= n/2       (FFT -> DCT-II rotation)
+  const double* lam;        // 4 sin^2(pi k / (2n)),  k < n          (eigenvalues of the 1-D Neumann Laplacian)
+};
+
+// host side of the tables (long double trigonometry); buffers have n/2, n/2 + 1 and n entries
+void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam);
+// n is a power of two the LDS-resident transform supports
+bool dct_length_ok(int64_t n);
+
+// img (H x W, column-major, ld = H), in place: every column -> its DCT-II (unnormalised), two columns per workgroup
+void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
+                             hipStream_t stream);
+// inverse of the above (DCT-III with the 1/H factor): src -> dst (may alias)
+void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
+                             const Ctrl* ctrl, hipStream_t stream);
+// t (W x H, column-major: the transposed, column-transformed image), in place: every column (one image row
+// frequency i) -> DCT-II along W, divide by 1 + rho*(lamH[i] + lamW[k]), DCT-III back
+void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const DctTables& th, const DctTables& tw,
+                           const Ctrl* ctrl, hipStream_t stream);
+// dst (cols x rows, column-major) = src (rows x cols, column-major) transposed
+void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
+                      hipStream_t stream);
+
+}  // namespace admm

@@ -1,0 +1,306 @@
+// dct.hip -- LDS-resident fp64 DCT-II / DCT-III (length 2^p <= 4096) and the spectral x-update of 2-D total
+// variation (dct.h).  One workgroup transforms TWO real sequences at once as one complex FFT (z = a + i*b):
+//   Makhoul's permutation   v[n] = x[2n], v[N-1-n] = x[2n+1]        turns the DCT-II into an N-point FFT of v,
+//   X_k = Re(e^{-i pi k/(2N)} V_k),  X_{N-k} = -Im(e^{-i pi k/(2N)} V_k),
+// and V_a, V_b come out of the joint spectrum by the usual even/odd split.  The FFT is an in-place radix-2
+// decimation-in-frequency network, four stages fused per pass in registers (16 points per thread: three LDS round
+// trips for 4096 points), natural order in -> bit-reversed order out; the inverse runs the same network backwards
+// (decimation in time, conjugate twiddles), bit-reversed in -> natural out, so nothing is ever reordered: the
+// spectral step addresses position bitrev(k) directly.
+#include <cmath>
+
+#include "dct.h"
+#include "kernels.h"
+
+namespace admm {
+
+using c64 = admm_double2;  // (re, im)
+
+__device__ __forceinline__ c64 cmul(c64 a, c64 b) {
+  return c64{__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x)};
+}
+__device__ __forceinline__ c64 cmulc(c64 a, c64 b) {  // a * conj(b)
+  return c64{__builtin_fma(a.x, b.x, a.y * b.y), __builtin_fma(a.y, b.x, -(a.x * b.y))};
+}
+__device__ __forceinline__ int bitrev(int k, int log2n) { return static_cast<int>(__brev(static_cast<unsigned>(k)) >> (32 - log2n)); }
+
+// LDS position of element a: the low four index bits are XORed with bits 4-7 and 8-11, which makes every access
+// pattern of this file conflict-free per 16-lane group: consecutive a, a = 16*lane + e (the last pass of a
+// 4096-point transform), and a = 256*c + const (bit-reversed order seen from consecutive k).
+__device__ __forceinline__ int swz(int a) { return a ^ ((a >> 4) & 15) ^ ((a >> 8) & 15); }
+
+template <int R>
+__device__ __forceinline__ c64 unit_root(int x) {  // e^{-2 pi i x / R}, x < R/2 (compile-time after unrolling)
+  constexpr double kC16[8] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+                              0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613};
+  constexpr double kS16[8] = {0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
+                              -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173};
+  const int i = x * (16 / R);
+  return c64{kC16[i], kS16[i]};
+}
+
+// log2(R) fused radix-2 stages on blocks of B points: thread q owns the R points base + e*B/R.  DIF (forward) pairs
+// (e, e + half) with twiddle w_n^{(j + el*B/R) * (n/B) * 2^s} = tw[j*(n/B) << s] * e^{-2 pi i (el << s) / R};
+// INV runs the stages backwards with conjugate twiddles (the exact inverse network, times R).
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(c64* zs, int n, int B, const c64* __restrict__ tw) {
+  constexpr int LR = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
+  const int Bq = B / R;
+  const int T = n / B;
+  const int lg = 31 - __clz(Bq);
+  for (int q = threadIdx.x; q < n / R; q += blockDim.x) {
+    const int j = q & (Bq - 1);
+    const int base = (q >> lg) * B + j;
+    c64 v[R];
+#pragma unroll
+    for (int e = 0; e < R; ++e) v[e] = zs[swz(base + e * Bq)];
+#pragma unroll
+    for (int ss = 0; ss < LR; ++ss) {
+      const int s = INV ? LR - 1 - ss : ss;
+      const int half = R >> (s + 1);
+      const c64 wj = tw[(j * T) << s];
+#pragma unroll
+      for (int e = 0; e < R; ++e) {
+        if (e & half) continue;
+        const int el = e & (half - 1);
+        const c64 w = (el == 0) ? wj : cmul(wj, unit_root<R>(el << s));
+        const c64 a = v[e], b = v[e + half];
+        if (!INV) {
+          v[e] = a + b;
+          v[e + half] = cmul(a - b, w);
+        } else {
+          const c64 t = cmulc(b, w);
+          v[e] = a + t;
+          v[e + half] = a - t;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < R; ++e) zs[swz(base + e * Bq)] = v[e];
+  }
+}
+
+// callers synchronise before; every pass ends with a barrier.  Radix plan: 16 while four or more stages remain, then
+// one pass of 8 / 4 / 2 on the smallest blocks; the inverse replays the same passes in reverse.
+template <bool INV>
+__device__ __forceinline__ void fft_network(c64* zs, int n, int log2n, const c64* __restrict__ tw) {
+  const int rem = log2n & 3;        // stages of the odd pass (blocks of 2^rem points)
+  if (!INV) {
+    int B = n;
+    for (; B >= 16; B >>= 4) {
+      fft_pass<16, false>(zs, n, B, tw);
+      __syncthreads();
+    }
+    if (rem == 3) fft_pass<8, false>(zs, n, 8, tw);
+    else if (rem == 2) fft_pass<4, false>(zs, n, 4, tw);
+    else if (rem == 1) fft_pass<2, false>(zs, n, 2, tw);
+    if (rem) __syncthreads();
+  } else {
+    if (rem == 3) fft_pass<8, true>(zs, n, 8, tw);
+    else if (rem == 2) fft_pass<4, true>(zs, n, 4, tw);
+    else if (rem == 1) fft_pass<2, true>(zs, n, 2, tw);
+    if (rem) __syncthreads();
+    for (int B = 16 << rem; B <= n; B <<= 4) {
+      fft_pass<16, true>(zs, n, B, tw);
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int makhoul(int i, int n) { return (i & 1) ? n - 1 - (i >> 1) : (i >> 1); }
+
+// (a, b) -> LDS in Makhoul order
+__device__ __forceinline__ void load_pair(c64* zs, const double* __restrict__ a, const double* __restrict__ b, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) zs[swz(makhoul(i, n))] = c64{a[i], b[i]};
+}
+// LDS (after the inverse network) -> (a, b), scaled
+__device__ __forceinline__ void store_pair(const c64* zs, double* __restrict__ a, double* __restrict__ b, int n,
+                                           double scale) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const c64 v = zs[swz(makhoul(i, n))];
+    a[i] = v.x * scale;
+    b[i] = v.y * scale;
+  }
+}
+
+// joint bit-reversed spectrum -> the four DCT coefficients of a pair (k, n-k), 0 < k < n/2
+__device__ __forceinline__ void spectrum_to_dct(c64 zk, c64 zn, c64 ck, double& xak, double& xan, double& xbk,
+                                                double& xbn) {
+  const c64 va = c64{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};
+  const c64 vb = c64{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};
+  const c64 pa = cmul(ck, va), pb = cmul(ck, vb);
+  xak = pa.x;
+  xan = -pa.y;
+  xbk = pb.x;
+  xbn = -pb.y;
+}
+__device__ __forceinline__ void dct_to_spectrum(double xak, double xan, double xbk, double xbn, c64 ck, c64& zk,
+                                                c64& zn) {
+  const c64 va = cmulc(c64{xak, -xan}, ck), vb = cmulc(c64{xbk, -xbn}, ck);
+  zk = c64{va.x - vb.y, va.y + vb.x};
+  zn = c64{va.x + vb.y, vb.x - va.y};
+}
+
+constexpr double kSqrtHalf = 0.70710678118654752440;
+constexpr double kSqrt2 = 1.41421356237309504880;
+
+__global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __restrict__ img, int64_t H, DctTables t,
+                                                                  const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int n = t.n, p = t.log2n;
+  double* a = img + static_cast<int64_t>(2 * blockIdx.x) * H;
+  double* b = a + H;
+  load_pair(zs, a, b, n);
+  __syncthreads();
+  fft_network<false>(zs, n, p, t.tw);
+  for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
+    if (k == 0) {
+      a[0] = zs[0].x;
+      b[0] = zs[0].y;
+    } else if (k == (n >> 1)) {
+      const c64 h = zs[1];  // bitrev(n/2) = 1
+      a[k] = kSqrtHalf * h.x;
+      b[k] = kSqrtHalf * h.y;
+    } else {
+      double xak, xan, xbk, xbn;
+      spectrum_to_dct(zs[swz(bitrev(k, p))], zs[swz(bitrev(n - k, p))], t.c4[k], xak, xan, xbk, xbn);
+      a[k] = xak;
+      a[n - k] = xan;
+      b[k] = xbk;
+      b[n - k] = xbn;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* __restrict__ src,
+                                                                  double* __restrict__ dst, int64_t H, DctTables t,
+                                                                  const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int n = t.n, p = t.log2n;
+  const double* a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
+  const double* b = a + H;
+  for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
+    if (k == 0) {
+      zs[0] = c64{a[0], b[0]};
+    } else if (k == (n >> 1)) {
+      zs[1] = c64{kSqrt2 * a[k], kSqrt2 * b[k]};
+    } else {
+      c64 zk, zn;
+      dct_to_spectrum(a[k], a[n - k], b[k], b[n - k], t.c4[k], zk, zn);
+      zs[swz(bitrev(k, p))] = zk;
+      zs[swz(bitrev(n - k, p))] = zn;
+    }
+  }
+  __syncthreads();
+  fft_network<true>(zs, n, p, t.tw);
+  double* oa = dst + static_cast<int64_t>(2 * blockIdx.x) * H;
+  store_pair(zs, oa, oa + H, n, 1.0 / static_cast<double>(n));
+}
+
+// columns of t have length W (= tw.n) and belong to the row frequencies i = 2*blockIdx.x, +1 of the image
+__global__ __launch_bounds__(kBlock) void dct_rows_solve_kernel(double* __restrict__ tm, int64_t W, double rho,
+                                                                const double* __restrict__ lamH, DctTables t,
+                                                                const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int n = t.n, p = t.log2n;
+  double* a = tm + static_cast<int64_t>(2 * blockIdx.x) * W;
+  double* b = a + W;
+  load_pair(zs, a, b, n);
+  __syncthreads();
+  fft_network<false>(zs, n, p, t.tw);
+  const double la = lamH[2 * blockIdx.x], lb = lamH[2 * blockIdx.x + 1];
+  const double* __restrict__ lam = t.lam;
+  for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
+    if (k == 0) {
+      const c64 z0 = zs[0];
+      zs[0] = c64{z0.x / (1.0 + rho * la), z0.y / (1.0 + rho * lb)};  // lam[0] = 0
+    } else if (k == (n >> 1)) {
+      const c64 h = zs[1];  // X = sqrt(1/2) V and V' = sqrt(2) X': the rotation cancels
+      zs[1] = c64{h.x / (1.0 + rho * (la + lam[k])), h.y / (1.0 + rho * (lb + lam[k]))};
+    } else {
+      const int rk = swz(bitrev(k, p)), rn = swz(bitrev(n - k, p));
+      const c64 ck = t.c4[k];
+      double xak, xan, xbk, xbn;
+      spectrum_to_dct(zs[rk], zs[rn], ck, xak, xan, xbk, xbn);
+      const double lk = lam[k], ln = lam[n - k];
+      xak /= 1.0 + rho * (la + lk);
+      xan /= 1.0 + rho * (la + ln);
+      xbk /= 1.0 + rho * (lb + lk);
+      xbn /= 1.0 + rho * (lb + ln);
+      c64 zk, zn;
+      dct_to_spectrum(xak, xan, xbk, xbn, ck, zk, zn);
+      zs[rk] = zk;
+      zs[rn] = zn;
+    }
+  }
+  __syncthreads();
+  fft_network<true>(zs, n, p, t.tw);
+  store_pair(zs, a, b, n, 1.0 / static_cast<double>(n));
+}
+
+// 64 x 64 tiles through LDS (65-double pitch: conflict-free both ways); fully coalesced on both sides
+__global__ __launch_bounds__(kBlock) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                           int64_t rows, int64_t cols, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double tile[64][65];
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    const int64_t r = r0 + tx, cc = c0 + c;
+    if (r < rows && cc < cols) tile[c][tx] = src[r + cc * rows];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t cc = c0 + tx, rr = r0 + r;
+    if (cc < cols && rr < rows) dst[cc + rr * cols] = tile[tx][r];
+  }
+}
+
+bool dct_length_ok(int64_t n) { return n >= 8 && n <= 4096 && (n & (n - 1)) == 0; }
+
+void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam) {
+  const long double pi = 3.141592653589793238462643383279502884L;
+  for (int32_t k = 0; k < n / 2; ++k) {
+    const long double ang = -2.0L * pi * k / n;
+    tw[k] = admm_double2{static_cast<double>(cosl(ang)), static_cast<double>(sinl(ang))};
+  }
+  for (int32_t k = 0; k <= n / 2; ++k) {
+    const long double ang = -pi * k / (2.0L * n);
+    c4[k] = admm_double2{static_cast<double>(cosl(ang)), static_cast<double>(sinl(ang))};
+  }
+  for (int32_t k = 0; k < n; ++k) {
+    const long double sv = sinl(pi * k / (2.0L * n));
+    lam[k] = static_cast<double>(4.0L * sv * sv);
+  }
+}
+
+static size_t dct_lds_bytes(int n) { return sizeof(c64) * static_cast<size_t>(n); }
+
+void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
+                     stream, img, H, th, ctrl);
+}
+
+void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
+                             const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
+                     stream, src, dst, H, th, ctrl);
+}
+
+void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const DctTables& th, const DctTables& tw,
+                           const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(dct_rows_solve_kernel, dim3(static_cast<unsigned>(H / 2)), dim3(kBlock), dct_lds_bytes(tw.n),
+                     stream, t, W, rho, th.lam, tw, ctrl);
+}
+
+void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
+                      hipStream_t stream) {
+  const dim3 grid(static_cast<unsigned>(ceil_div(rows, 64)), static_cast<unsigned>(ceil_div(cols, 64)));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(kBlock), 0, stream, src, dst, rows, cols, ctrl);
+}
+
+}  // namespace admm

@@ -13,6 +13,7 @@
 #include "loop_kernels.h"
 #include "tv.h"
 #include "tv2d.h"
+#include "dct.h"
 #include "consensus.h"
 #include "cg.h"
 
@@ -123,6 +124,8 @@ struct admm_engine {
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
   int64_t tv2_H = 0, tv2_W = 0;  // 2-D TV image shape
+  bool tv2_dct = false;          // spectral (DCT) x-update instead of CG: both sides a power of two (dct.h)
+  DctTables dctH{}, dctW{};
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
@@ -533,7 +536,11 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, ~1 ms at n = 10^4);
   // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
   if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
-  if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;  // the only x-update this problem has
+  // 2-D TV: AUTO = the direct spectral solve when both sides are powers of two, else (or on request) warm-started
+  // CG; the CG vectors are allocated either way (one of them is the transposition scratch of the spectral solve)
+  const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
+                            dct_length_ok(desc->m) && dct_length_ok(desc->n);
+  if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
     return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg applies to problems whose x-update solves with D'D (+ rho I)"));
@@ -799,6 +806,29 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(upload(e->mem, &e->s, desc->s, N, mk, e->stream));
       E_TRY(e->mem.alloc(&e->tv_zB, round_up(2 * N, 2)));
       E_TRY(e->mem.alloc(&e->tv_uB, round_up(2 * N, 2)));
+      if (tv2_want_dct) {
+        auto tables = [&](int64_t len, DctTables* t) -> int {
+          const int32_t L = static_cast<int32_t>(len);
+          std::vector<admm_double2> tw(static_cast<size_t>(L / 2)), c4(static_cast<size_t>(L / 2 + 1));
+          std::vector<double> lam(static_cast<size_t>(L));
+          dct_fill_tables(L, tw.data(), c4.data(), lam.data());
+          double *dtw = nullptr, *dc4 = nullptr, *dlam = nullptr;
+          ADMM_TRY(upload(e->mem, &dtw, reinterpret_cast<const double*>(tw.data()), L, ADMM_MEM_HOST, e->stream));
+          ADMM_TRY(upload(e->mem, &dc4, reinterpret_cast<const double*>(c4.data()), L + 2, ADMM_MEM_HOST, e->stream));
+          ADMM_TRY(upload(e->mem, &dlam, lam.data(), L, ADMM_MEM_HOST, e->stream));
+          ADMM_HIP_TRY(hipStreamSynchronize(e->stream));  // the host vectors go out of scope
+          t->n = L;
+          t->log2n = 0;
+          while ((1 << t->log2n) < L) ++t->log2n;
+          t->tw = reinterpret_cast<const admm_double2*>(dtw);
+          t->c4 = reinterpret_cast<const admm_double2*>(dc4);
+          t->lam = dlam;
+          return ADMM_OK;
+        };
+        E_TRY(tables(m, &e->dctH));
+        E_TRY(tables(n, &e->dctW));
+        e->tv2_dct = true;
+      }
       break;
     }
     case ADMM_PROB_TOTALVARIATION: {
@@ -1042,6 +1072,19 @@ static int cg_solve_tv2d(admm_engine* e, const double* y) {
 }
 
 // x <- argmin-free solve of (D'D + shift I) x = y by warm-started CG (cg.hip); polls the device flag
+// 2-D TV x-update, direct: x = C2' diag(1/(1 + rho*(lamH_i + lamW_j))) C2 y with the 2-D DCT-II C2 (dct.h).
+// Five streaming passes (10 N doubles of traffic); y is overwritten, e->cg_r is the transposition scratch.
+static int dct_solve_tv2d(admm_engine* e, double* y) {
+  TimerScope ts(e, ADMM_K_XSOLVE);
+  const int64_t H = e->tv2_H, W = e->tv2_W;
+  launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);                 // along i, in place
+  launch_transpose(y, e->cg_r, H, W, e->ctrl, e->stream);                        // -> W x H
+  launch_dct_rows_solve(e->cg_r, H, W, e->last_opts.rho, e->dctH, e->dctW, e->ctrl, e->stream);
+  launch_transpose(e->cg_r, y, W, H, e->ctrl, e->stream);                        // -> H x W
+  launch_dct_cols_inverse(y, e->x, H, W, e->dctH, e->ctrl, e->stream);
+  return ADMM_OK;
+}
+
 static int cg_solve(admm_engine* e, const double* y) {
   if (e->problem == ADMM_PROB_TV2D) return cg_solve_tv2d(e, y);
   CgArgs a{};
@@ -1577,6 +1620,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       fa.obj_scale_z = e->lambda;
     }
     (void)Npix;
+    const int check_tv2 = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
     const auto t0 = std::chrono::steady_clock::now();
     int32_t done = 0;
     bool stop_seen = false;
@@ -1586,15 +1630,17 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       ta.u = a_cur ? e->tv_uA : e->tv_uB;
       ta.zo = a_cur ? e->tv_zB : e->tv_zA;
       ta.uo = a_cur ? e->tv_uB : e->tv_uA;
-      {
+      if (done == 0) {  // later right-hand sides come out of the fused z/u pass of the previous iteration
         TimerScope ts(e, ADMM_K_XSOLVE);
         launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
       }
-      ADMM_TRY(cg_solve(e, e->rhs));  // (I + rho*D'D) x = s + rho*D'(z - u), warm-started, polls the device
+      // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
+      if (e->tv2_dct) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+      else ADMM_TRY(cg_solve(e, e->rhs));
       int nblk = 1;
       {
         TimerScope ts(e, ADMM_K_PROX);
-        launch_tv2d_prox(ta, e->ctrl, &nblk, e->stream);
+        launch_tv2d_fused(ta, e->rhs, e->ctrl, &nblk, e->stream);
       }
       fa.nblk = nblk;
       {
@@ -1602,9 +1648,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_finalize(fa, e->stream);
       }
       done += 1;
-      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
-      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-      if (e->ctrl_host->stop) stop_seen = true;
+      // the CG path synchronises inside every solve anyway; the spectral path runs check_tv2 iterations ahead
+      // (everything enqueued after the stop flag is a no-op)
+      if (!e->tv2_dct || done % check_tv2 == 0 || done == N) {
+        ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->ctrl_host->stop) stop_seen = true;
+      }
     }
     {
       hipError_t le = hipGetLastError();

@@ -324,8 +324,10 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
     static_assert(S_COUNT <= 16, "slot layout");
     const int slot = threadIdx.x >> 4, sub = threadIdx.x & 15;
     double v = 0.0;
-    if (slot < S_COUNT)
+    if (slot < S_COUNT) {
+#pragma unroll 8
       for (int b = sub; b < a.nblk; b += 16) v += a.part[slot * kMaxPartBlocks + b];
+    }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (sub == 0) S[slot] = v;

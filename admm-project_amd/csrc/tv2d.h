@@ -40,4 +40,8 @@ void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t 
 // z/u update from x, residual sums, then the D' stencils of the dual residual / tolerance (second kernel)
 void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 
+// prox + dual stencils + the NEXT x-update's right-hand side in one pass (replaces launch_tv2d_prox and the
+// following launch_tv2d_rhs; launch_tv2d_rhs is still needed once, for the first iteration)
+void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+
 }  // namespace admm

@@ -185,6 +185,109 @@ __global__ __launch_bounds__(kBlock) void tv2d_dual_kernel(Tv2Args a, const Ctrl
   tv2_block_partials(acc, a.part, S_G2, S_G3);
 }
 
+// One pass per iteration instead of three: the z/u update, the D' stencils of the dual residual / tolerance AND the
+// next x-update's right-hand side b = s + rho*D'(z+ - u+).  The stencils need the NEW values of the rows i-1 (of Dv)
+// and j-1 (of Dh): each thread recomputes those two neighbour updates from the old iterates (same formula, same
+// inputs -> bit-identical to what the neighbour stores); the extra reads are cache hits (row i-1 sits in the same
+// line, column j-1 was streamed 16 workgroups earlier on the same XCD).  HBM traffic: 6N read + 5N written
+// instead of 9N + 6N + 6N for prox, dual and rhs kernels.
+__global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* __restrict__ bnext,
+                                                            const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  const int64_t H = a.H, W = a.W, N = H * W;
+  const double* __restrict__ x = a.x;
+  const double* __restrict__ z = a.z;
+  const double* __restrict__ u = a.u;
+  const double t = a.thresh;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const bool hasv = i < H - 1, hash = j < W - 1, up = i > 0, left = j > 0;
+    const double xi = x[idx];
+    const double d[2] = {hasv ? xi - x[idx + 1] : 0.0, hash ? xi - x[idx + H] : 0.0};
+    double zn[2], un[2], zp[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int64_t k = part * N + idx;
+      const double ax = d[part];
+      const double uo = u[k];
+      zp[part] = z[k];
+      zn[part] = tv2_soft(uo + ax, t);
+      un[part] = uo + (ax + (-zn[part]));
+      const double r = ax + (-zn[part]), dz = zn[part] - zp[part], du = un[part] - uo;
+      acc[S_R2] += r * r;
+      acc[S_AX2] += ax * ax;
+      acc[S_Z2] += zn[part] * zn[part];
+      acc[S_DZ2] += dz * dz;
+      acc[S_U2] += un[part] * un[part];
+      acc[S_DU2] += du * du;
+      if (a.objevals) acc[S_OBJZ] += fabs(ax);
+      a.zo[k] = zn[part];
+      a.uo[k] = un[part];
+      if (a.zhist) {
+        a.zhist[it * 2 * N + k] = zn[part];
+        a.uhist[it * 2 * N + k] = un[part];
+      }
+    }
+    const double si = a.s[idx];
+    if (a.objevals) {
+      const double e = xi - si;
+      acc[S_OBJX] += e * e;
+    }
+    if (a.xhist) a.xhist[it * N + idx] = xi;
+    // the rows above / to the left: new z, u of (i-1, j) in the vertical part and of (i, j-1) in the horizontal one
+    double znu = 0.0, unu = 0.0, zpu = 0.0, znl = 0.0, unl = 0.0, zpl = 0.0;
+    if (up) {
+      const double ax = x[idx - 1] - xi, uo = u[idx - 1];
+      zpu = z[idx - 1];
+      znu = tv2_soft(uo + ax, t);
+      unu = uo + (ax + (-znu));
+    }
+    if (left) {
+      const double ax = x[idx - H] - xi, uo = u[N + idx - H];
+      zpl = z[N + idx - H];
+      znl = tv2_soft(uo + ax, t);
+      unl = uo + (ax + (-znl));
+    }
+    // D'w at (i, j), in tv2_dt's order of operations
+    double g2 = 0.0, g3 = 0.0, gb = 0.0;
+    if (hasv) {
+      g2 += zn[0] - zp[0];
+      g3 += un[0];
+      gb += zn[0] - un[0];
+    }
+    if (up) {
+      g2 -= znu - zpu;
+      g3 -= unu;
+      gb -= znu - unu;
+    }
+    if (hash) {
+      g2 += zn[1] - zp[1];
+      g3 += un[1];
+      gb += zn[1] - un[1];
+    }
+    if (left) {
+      g2 -= znl - zpl;
+      g3 -= unl;
+      gb -= znl - unl;
+    }
+    acc[S_G2] += g2 * g2;
+    acc[S_G3] += g3 * g3;
+    bnext[idx] = si + a.rho * gb;
+  }
+  tv2_block_partials(acc, a.part, 0, S_COUNT - 1);
+}
+
+void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  const int nb = tv2_blocks(a.H * a.W);
+  *nblk_out = nb;
+  hipLaunchKernelGGL(tv2d_fused_kernel, dim3(nb), dim3(kBlock), 0, stream, a, bnext, ctrl);
+}
+
 void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, double* w, const Ctrl* ctrl,
                          hipStream_t stream) {
   int64_t blocks = ceil_div(H * W, kBlock);

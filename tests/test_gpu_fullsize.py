@@ -112,15 +112,17 @@ def test_tv_4096sq_identities(gpu):
     assert r["objopt"] == pytest.approx(0.5 * np.sum((x - s) ** 2) + lam * np.sum(np.abs(np.diff(x))), rel=1e-10)
 
 
-def test_tv2d_4096x4096_identities(gpu):
-    """Config 5 as literally written (image, matrix-free x-update): the CG solve meets its tolerance."""
+@pytest.mark.parametrize("xsolve", ["auto", "cg"])
+def test_tv2d_4096x4096_identities(gpu, xsolve):
+    """Config 5 as literally written (image, matrix-free x-update): the spectral solve / the CG solve meet the
+    x-update's defining equation."""
     H = W = 4096
     rng = np.random.default_rng(1)
     img = np.zeros((H, W))
     img[H // 5:H // 2, W // 6:W // 2] = 2.0
     img += rng.standard_normal((H, W))
     lam, rho = 1.0, 1.0
-    run = lambda o: gpu.totalvariation2d(img, lam, o)
+    run = lambda o: gpu.totalvariation2d(img, lam, dict(o, xsolve=xsolve))
     st = run(dict(maxiters=3, domaxiters=1, record_history=0))
     r = run(dict(maxiters=1, domaxiters=1, record_history=0, objevals=1, x0=st["xopt"].reshape(-1, order="F"),
                  z0=st["zopt"], u0=st["uopt"]))

@@ -32,7 +32,24 @@ def test_tv2d_matches_oracle(gpu, H, W, opts):
         if k in ref:
             _close(k, got[k], ref[k], 1e-7)
     assert got["xopt"].shape == (H, W)
-    assert got["cg_iters_total"] >= got["steps"]
+    pow2 = all(v >= 8 and v & (v - 1) == 0 for v in (H, W))
+    assert (got["cg_iters_total"] == 0) if pow2 else (got["cg_iters_total"] >= got["steps"])  # spectral x-update
+
+
+@pytest.mark.parametrize("H,W,rho", [(8, 8, 1.0), (16, 64, 1.0), (64, 32, 2.5), (128, 256, 0.7), (32, 8, 1.0),
+                                     (512, 8, 1.0), (8, 1024, 1.3), (2048, 16, 1.0), (16, 4096, 0.5)])  # every radix plan
+def test_tv2d_spectral_x_update(gpu, H, W, rho):
+    """Power-of-two sides: (I + rho*D'D) is inverted through the 2-D DCT-II (dct.hip) -- against the oracle's
+    sparse-direct solve, and against the engine's own CG path."""
+    img = _image(H * 1000 + W, H, W)
+    o = dict(objevals=1, rho=rho, maxiters=30, domaxiters=1)
+    got = gpu.totalvariation2d(img, 0.4, dict(o))
+    ref = S.totalvariation2d(img, 0.4, dict(o))
+    cg = gpu.totalvariation2d(img, 0.4, dict(o, xsolve="cg"))
+    assert got["cg_iters_total"] == 0 and cg["cg_iters_total"] >= 30
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, got[k], ref[k], 1e-9)
+        _close(k, cg[k], ref[k], 1e-7)
 
 
 def test_tv2d_denoises(gpu):
