@@ -168,30 +168,38 @@ def other_configs(ap, L, device, steps):
                                       "achieved_GBs": passes * 8.0 * n * s.steps / dt / 1e9,
                                       "frac": passes * 8.0 * n * s.steps / dt / 1e9 / HBM_PEAK_GBS}
     tv.close()
-    # config 5 as literally written: anisotropic TV of a 4096 x 4096 IMAGE, matrix-free (CG) x-update -- an
-    # engine-side extension (the reference's solver is 1-D); own oracle, see tests/test_gpu_tv2d.py
+    # config 5 as literally written: anisotropic TV of a 4096 x 4096 IMAGE, no cached factor -- an engine-side
+    # extension (the reference's solver is 1-D); own oracle, see tests/test_gpu_tv2d.py.  Two x-updates:
+    # the direct spectral solve (2-D DCT, dct.hip; the default for power-of-two sides) and warm-started CG.
     hw = 4096
     rng = np.random.default_rng(1)
     img = np.zeros((hw, hw))
     img[hw // 5:hw // 2, hw // 6:hw // 2] = 2.0
     img[hw // 3:4 * hw // 5, hw // 3:5 * hw // 6] += 1.0
     img += rng.standard_normal((hw, hw))
-    tv2 = ap.Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=1.0, shape=(hw, hw), device=device)
-    tv2.run(maxiters=2, domaxiters=1, record_history=0)
-    k2 = max(5, steps // 20)
-    t0 = time.perf_counter()
-    s2 = tv2.run(maxiters=k2, domaxiters=1, record_history=0)
-    dt2 = time.perf_counter() - t0
-    inner = float(tv2.fetch(L.F_CG_ITERS, 1)[0]) / s2.steps
     npix = hw * hw
-    # doubles moved per ADMM iteration: rhs 6N + CG start 12N + prox 9N + dual 6N + 10N per inner CG iteration
-    # (fused direction + stencil: reads r, p, writes p, q; update: reads x, p, r, q, writes x, r)
-    gb = (33.0 + 10.0 * inner) * 8.0 * npix / 1e9
-    res["totalvariation2d_4096x4096"] = {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3,
-                                         "cg_inner_iters_per_step": inner, "cg_tol": 1e-11,
-                                         "algorithmic_GB_per_iter": gb, "achieved_GBs": gb * s2.steps / dt2,
-                                         "frac": gb * s2.steps / dt2 / HBM_PEAK_GBS}
-    tv2.close()
+    flat = np.asfortranarray(img).reshape(-1, order="F")
+    for tag, xs, k2 in (("", L.XSOLVE_AUTO, max(50, steps)), ("_cg", L.XSOLVE_CG, max(5, steps // 20))):
+        tv2 = ap.Engine(L.PROB_TV2D, s=flat, lam=1.0, shape=(hw, hw), xsolve=xs, device=device)
+        tv2.run(maxiters=2, domaxiters=1, record_history=0)
+        t0 = time.perf_counter()
+        s2 = tv2.run(maxiters=k2, domaxiters=1, record_history=0)
+        dt2 = time.perf_counter() - t0
+        inner = float(tv2.fetch(L.F_CG_ITERS, 1)[0]) / s2.steps
+        if xs == L.XSOLVE_CG:
+            # doubles per ADMM iteration: CG start 12N + fused z/u/dual/rhs pass 11N + 10N per inner iteration
+            # (fused direction + stencil: reads r, p, writes p, q; update: reads x, p, r, q, writes x, r)
+            gb = (23.0 + 10.0 * inner) * 8.0 * npix / 1e9
+            extra = {"x_update": "cg", "cg_inner_iters_per_step": inner, "cg_tol": 1e-11}
+        else:
+            # fused z/u/dual/rhs pass 6N read + 5N written; spectral solve: five in-place passes (column DCT,
+            # transpose, row DCT + scale + inverse, transpose, column inverse) = 10N
+            gb = 21.0 * 8.0 * npix / 1e9
+            extra = {"x_update": "dct"}
+        res["totalvariation2d_4096x4096" + tag] = dict(
+            {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3, "algorithmic_GB_per_iter": gb,
+             "achieved_GBs": gb * s2.steps / dt2, "frac": gb * s2.steps / dt2 / HBM_PEAK_GBS}, **extra)
+        tv2.close()
     # config 3: linear SVM, hinge, MNIST-shaped synthetic pixels (image files are absent from the reference)
     for m in (6000, 60000):
         q = ap.synth.mnist_like_problem(seed=1, m=m, n=400, digit=0)
