@@ -231,8 +231,8 @@ def test_total_variation_second_run_and_errors(gpu):
     np.testing.assert_array_equal(a["uopt"], a["uvals"][:, -1])
     with pytest.raises(gpu.AdmmError):
         gpu.admm(minx, minz, dict(base, relax=1.5))
-    with pytest.raises(gpu.AdmmError):
-        gpu.admm(minx, minz, dict(base, fast=1))
+    c = gpu.admm(minx, minz, dict(base, fast=1, maxiters=7, domaxiters=1))  # fast ADMM: the unfused TV path
+    assert c["steps"] == 7 and "avals" in c
 
 
 @pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
