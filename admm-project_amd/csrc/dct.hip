@@ -107,19 +107,23 @@ __device__ __forceinline__ void fft_network(c64* zs, int n, int log2n, const c64
   }
 }
 
-__device__ __forceinline__ int makhoul(int i, int n) { return (i & 1) ? n - 1 - (i >> 1) : (i >> 1); }
 
-// (a, b) -> LDS in Makhoul order
-__device__ __forceinline__ void load_pair(c64* zs, const double* __restrict__ a, const double* __restrict__ b, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) zs[swz(makhoul(i, n))] = c64{a[i], b[i]};
+// (a, b) -> LDS in Makhoul order: x[2i] -> v[i], x[2i+1] -> v[n-1-i], one 16-byte load per column and thread
+__device__ __forceinline__ void load_pair(c64* zs, const double* a, const double* b, int n) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+    const admm_double2 va = load2<false>(a + 2 * i), vb = load2<false>(b + 2 * i);
+    zs[swz(i)] = c64{va.x, vb.x};
+    zs[swz(n - 1 - i)] = c64{va.y, vb.y};
+  }
 }
 // LDS (after the inverse network) -> (a, b), scaled
-__device__ __forceinline__ void store_pair(const c64* zs, double* __restrict__ a, double* __restrict__ b, int n,
-                                           double scale) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const c64 v = zs[swz(makhoul(i, n))];
-    a[i] = v.x * scale;
-    b[i] = v.y * scale;
+__device__ __forceinline__ void store_pair(const c64* zs, double* a, double* b, int n, double scale) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
+    const c64 v0 = zs[swz(i)], v1 = zs[swz(n - 1 - i)];
+    store2<false>(a + 2 * i, admm_double2{v0.x * scale, v1.x * scale});
+    store2<false>(b + 2 * i, admm_double2{v0.y * scale, v1.y * scale});
   }
 }
 
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __rest
   load_pair(zs, a, b, n);
   __syncthreads();
   fft_network<false>(zs, n, p, t.tw);
+#pragma unroll 2
   for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
     if (k == 0) {
       a[0] = zs[0].x;
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   const int n = t.n, p = t.log2n;
   const double* a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
   const double* b = a + H;
+#pragma unroll 2
   for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
     if (k == 0) {
       zs[0] = c64{a[0], b[0]};
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(kBlock) void dct_rows_solve_kernel(double* __restri
   fft_network<false>(zs, n, p, t.tw);
   const double la = lamH[2 * blockIdx.x], lb = lamH[2 * blockIdx.x + 1];
   const double* __restrict__ lam = t.lam;
+#pragma unroll 2
   for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
     if (k == 0) {
       const c64 z0 = zs[0];
