@@ -124,6 +124,7 @@ struct admm_engine {
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
   int64_t tv2_H = 0, tv2_W = 0;  // 2-D TV image shape
+  Ctrl* ctrl_idle = nullptr;     // an all-zero control block for clean-up launches after the loop has stopped
   bool tv2_dct = false;          // spectral (DCT) x-update instead of CG: both sides a power of two (dct.h)
   DctTables dctH{}, dctW{};
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)
@@ -845,6 +846,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(upload(e->mem, &e->s, desc->s, nn, mk, e->stream));
       E_TRY(e->mem.alloc(&e->tv_y, round_up(nn, 2)));
       E_TRY(e->mem.alloc(&e->tv_y2, round_up(nn, 2)));
+      {
+        double* ci = nullptr;
+        E_TRY(e->mem.alloc(&ci, (sizeof(Ctrl) + 7) / 8));
+        e->ctrl_idle = reinterpret_cast<Ctrl*>(ci);
+        E_HIP(hipMemsetAsync(e->ctrl_idle, 0, sizeof(Ctrl), e->stream));
+      }
       E_TRY(e->mem.alloc(&e->tv_zB, round_up(nn, 2)));
       E_TRY(e->mem.alloc(&e->tv_uB, round_up(nn, 2)));
       break;
@@ -1831,6 +1838,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     const auto t0 = std::chrono::steady_clock::now();
     int32_t done = 0;
     bool stop_seen = false;
+    // x only leaves the fused kernel when its history is recorded; otherwise one backward sweep after the loop
+    // rebuilds the final x from the forward-sweep vector the last executed iteration read (still intact: every
+    // launch after the stop flag is a no-op, and an iteration writes the OTHER y buffer)
+    ta.skip_x = (tv_fused && !e->xhist) ? 1 : 0;
     if (tv_fused) {  // the forward sweep of iteration 0; every later one is produced by the fused kernel
       TimerScope ts(e, ADMM_K_XSOLVE);
       ta.z = e->tv_zA;
@@ -1881,12 +1892,17 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       hipError_t le = hipGetLastError();
       if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
     }
-    const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (e->profiling) collect_timers(e);
     const int32_t steps = e->ctrl_host->steps;
     // iterations executed on the device decide which ping-pong buffer holds the final z, u
     e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
     e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+    if (ta.skip_x && steps > 0) {
+      ta.y = ((steps - 1) & 1) ? e->tv_y2 : e->tv_y;
+      launch_tv_sweep(ta, true, e->ctrl_idle, e->stream);  // the loop's own flag says "stopped" by now
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     e->last = admm_run_summary{};
     e->last.steps = steps;
     e->last.stopped_early = (steps < N) ? 1 : 0;

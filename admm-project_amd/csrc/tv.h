@@ -30,6 +30,8 @@ struct TvArgs {
   double* yout;            // forward-sweep result for the NEXT iteration
   int32_t ftile;           // owned positions per tile = 256*elems - 2*halo - 4
   int64_t part_stride;     // fused kernel: part is [S_COUNT][part_stride], one column per tile
+  int32_t skip_x;          // fused kernel: do not store x (no history wanted): the engine materialises the final x
+                           // with one backward sweep of the surviving y after the loop -- 7 vector passes instead of 8
 };
 
 // pivots of I + rho*D'D and the launch geometry for a given rho

@@ -467,17 +467,17 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, const Ctr
           }
         }
         if (own0 && own1) {
-          store2<NTS>(a.x + i0, admm_double2{x0, x1});
+          if (!a.skip_x) store2<NTS>(a.x + i0, admm_double2{x0, x1});
           store2<NTS>(a.zo + i0, admm_double2{zn0, zn1});
           store2<NTS>(a.uo + i0, admm_double2{un0, un1});
         } else {
           if (own0) {
-            a.x[i0] = x0;
+            if (!a.skip_x) a.x[i0] = x0;
             a.zo[i0] = zn0;
             a.uo[i0] = un0;
           }
           if (own1) {
-            a.x[i0 + 1] = x1;
+            if (!a.skip_x) a.x[i0 + 1] = x1;
             a.zo[i0 + 1] = zn1;
             a.uo[i0 + 1] = un1;
           }

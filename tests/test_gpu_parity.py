@@ -66,6 +66,24 @@ def test_lasso_tall(gpu, rows, cols, seed, xsolve):
     assert got["solverruntime"] >= got["runtime"] > 0
 
 
+@pytest.mark.parametrize("opts", [dict(maxiters=7, domaxiters=1), dict(maxiters=8, domaxiters=1), dict(),
+                                  dict(stopcond="hnorm", maxiters=40), dict(objevals=1, rho=2.0)])
+@pytest.mark.parametrize("n", [5000, 70001])
+def test_total_variation_without_history(gpu, n, opts):
+    """record_history=0: the fused kernel stops storing x; the final x is rebuilt from the surviving forward-sweep
+    vector after the loop (odd / even step counts, early stops)."""
+    p = gpu.synth.tv_problem(seed=n, n=n)
+    got = gpu.totalvariation(p["s"], p["lam"], dict(opts, record_history=0))
+    ref = S.totalvariation(p["s"], p["lam"], dict(opts))
+    assert got["steps"] == ref["steps"]
+    for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr"):
+        _close(k, got[k], ref[k], TOL, None)
+    if "objevals" in opts:
+        assert got["objopt"] == pytest.approx(ref["objopt"], rel=1e-9)
+    again = gpu.totalvariation(p["s"], p["lam"], dict(opts))  # with history: x stored every iteration
+    np.testing.assert_allclose(got["xopt"], again["xopt"], rtol=0, atol=1e-13 * np.max(np.abs(again["xopt"])))
+
+
 @pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
 def test_lasso_fat(gpu, xsolve):
     p = gpu.synth.lasso_problem(1, 32, 256)
