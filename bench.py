@@ -223,7 +223,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
     # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
     lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
-    k2 = max(5, a.steps // 8)
+    k2 = max(5, a.steps // 4)
     timed_run(lad, dist, 2)
     lad.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
     dt2, _ = timed_run(lad, dist, k2)

@@ -18,7 +18,8 @@ L = ap._lib
 XS = {"auto": L.XSOLVE_AUTO, "cg": L.XSOLVE_CG}[sys.argv[2] if len(sys.argv) > 2 else "auto"]
 e = ap.Engine(L.PROB_TV2D, s=np.asfortranarray(img).reshape(-1, order="F"), lam=1.0, shape=(H, W), xsolve=XS)
 e.set_profiling(True)
-for tag, k in (("warm", 3), ("timed", 20 if XS == L.XSOLVE_CG else 200)):
+TIMED = int(sys.argv[3]) if len(sys.argv) > 3 else (20 if XS == L.XSOLVE_CG else 200)
+for tag, k in (("warm", 3), ("timed", TIMED)):
     t0 = time.perf_counter()
     s = e.run(maxiters=k, domaxiters=1, record_history=0)
     dt = time.perf_counter() - t0
