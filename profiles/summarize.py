@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output directories (gpurun_out/prof_*) into profiles/<tag>_*.{csv,md}.
 
-    python profiles/summarize.py r1a gpurun_out/prof_r1_stats gpurun_out/prof_r1_fetch gpurun_out/prof_r1_write
+    python profiles/summarize.py r1a gpurun_out/prof_r1_stats gpurun_out/prof_r1_fetch gpurun_out/prof_r1_write \
+        [more_fetch_dir more_write_dir ...]
 
 stats dir : --kernel-trace --stats        -> per-kernel calls / average ns  (copied verbatim)
 fetch dir : --pmc FETCH_SIZE --kernel-trace -> KB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of a
@@ -27,6 +28,7 @@ def pmc(dirname):
 
 def main():
     tag, stats, fetch, write = sys.argv[1:5]
+    more = sys.argv[5:]  # further (fetch, write) directory pairs, e.g. the TV scripts
     here = os.path.dirname(os.path.abspath(__file__))
     ks = glob.glob(os.path.join(stats, "**", "*_kernel_stats.csv"), recursive=True)[0]
     shutil.copy(ks, os.path.join(here, f"{tag}_kernel_stats.csv"))
@@ -38,7 +40,8 @@ def main():
     lines += ["", "## HBM traffic per dispatch (PMC, separate passes)", "",
               "FETCH bytes = FETCH_SIZE[KB] x 1024 x 2 (gfx950 wide-read correction); WRITE bytes = WRITE_SIZE[KB] x 1024.",
               "", "| kernel | grid | dispatches | counter | avg MB per dispatch |", "|---|---|---|---|---|"]
-    for d, mult in ((fetch, 2.0), (write, 1.0)):
+    passes = [(fetch, 2.0), (write, 1.0)] + [(d, 2.0 if k % 2 == 0 else 1.0) for k, d in enumerate(more)]
+    for d, mult in passes:
         for (name, ctr, grid), vals in sorted(pmc(d).items(), key=lambda kv: -sum(kv[1]))[:12]:
             lines.append(f"| `{name[:70]}` | {grid} | {len(vals)} | {ctr} | "
                          f"{sum(vals) / len(vals) * 1024 * mult / 1e6:.2f} |")
