@@ -135,7 +135,9 @@ def cpu_baseline(p, factor, seconds, rho):
     out = dict(value=k / r["runtime"], unit="iterations/s", cores=int(threads), kind="port",
                sample=f"{k} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
                       f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves, factor taken from the GPU setup); "
-                      f"loop only, as results.runtime")
+                      f"loop only, as results.runtime",
+               note="cores = size of the BLAS thread pool the loop was allowed to use; LAPACK's triangular solve "
+                    "(BLAS-2) barely threads, compare single_thread")
     # MATLAB applies the factor it stored SPARSE (lasso.m:175-176) with single-threaded triangular solves:
     # the same loop pinned to one BLAS thread is the closer stand-in for the reference's CPU path
     try:
