@@ -444,15 +444,52 @@ def admm(xminf, zming, options):
         return _admm_adaptive(xminf, zming, options, prob)
     par = _setopt(options, "parallel", "none")
     if par in ("xminf", "zming", "both"):
-        # admm.m:343-468 (parproxf / parproxg): the prox is evaluated slice by slice on the pool's workers and
-        # the pieces are concatenated.  For the separable z-prox of the linear SVM that is the computation the
-        # fused kernel already does over all rows at once (and the transpose reduction W = sum D_i'D_i of
-        # unwrappedadmm.m:96-141 is the engine's cached factor of D'D), so the option only has to be validated.
-        if prob.kind != "linearsvm":
-            raise NotImplementedError("options.parallel in-prox slicing is engine-native for the linear SVM / "
-                                      "unwrapped ADMM only; other problems shard rows with parallel.Comm")
+        # admm.m:343-468 (parproxf / parproxg): the prox is evaluated slice by slice -- handle(x, z, u, rho, k)
+        # returns piece k -- and the pieces are concatenated.
         from .errorcheck import slicemaker
-        slicemaker(options.get("slices", 0), int(options.get("workers", 1)), prob.expect["nB"])  # errorcheck.m:216-267
+        workers = int(options.get("workers", 1))
+        if workers <= 0:
+            raise ValueError("There are no workers on this machine, cannot perform parallel ADMM!")  # admm.m:350
+        slices = options.get("slices", 0)
+        is_cell = isinstance(slices, (list, tuple)) and len(slices) == 2 and all(
+            isinstance(v, (list, tuple, np.ndarray)) for v in slices)
+        if par == "both" and not is_cell:  # admm.m:357-361
+            raise ValueError("For parallelizing both proximal ops, please:\n\tSpecify slices for f as a vector in "
+                             "options.slices.\n\tSpecify slices for g as a vector in options.slices.")
+        if par != "both" and is_cell:  # admm.m:362-364
+            raise ValueError("Trying to parallelize both proximal operators, but options.slices is not a 2 element "
+                             "cell!")
+        sl = {"xminf": slices[0] if par == "both" else slices, "zming": slices[1] if par == "both" else slices}
+
+        def sliced(fn, lengths, what):
+            # the caller's handle for ONE slice (k is 0-based here; MATLAB's is 1-based); the device loop sees an
+            # ordinary prox handle.  The reference's parfor is a plain loop on the engine's stream: the GPU is the
+            # parallel resource.
+            import torch
+
+            def whole(x, z, u, rho_):
+                pieces = []
+                for k, ln in enumerate(lengths):
+                    piece = fn(x, z, u, rho_, k)
+                    if not isinstance(piece, torch.Tensor) or piece.numel() != ln:
+                        raise ValueError(f"{what}: slice {k} must be a tensor of {ln} elements")
+                    pieces.append(piece.reshape(-1))
+                return torch.cat(pieces)
+
+            return whole
+
+        for name, is_lib, ln in (("xminf", x_lib, prob.expect["nA"]), ("zming", z_lib, prob.expect["nB"])):
+            if par not in (name, "both"):
+                continue
+            lengths = slicemaker(sl[name], workers, ln)  # errorcheck.m:216-267
+            if not is_lib:
+                callbacks[name[:4]] = sliced(callbacks[name[:4]], [int(v) for v in lengths], name)
+            elif not (prob.kind == "linearsvm" and name == "zming"):
+                # For the separable z-prox of the linear SVM, slicing is the computation the fused kernel already
+                # does over all rows at once (and the transpose reduction W = sum D_i'D_i of unwrappedadmm.m:96-141
+                # is the engine's cached factor of D'D): the option only has to be validated.
+                raise NotImplementedError("options.parallel on a library operator is engine-native for the linear "
+                                          "SVM z-update only; shard rows with parallel.Comm instead")
 
     quiet = _setopt(options, "quiet", 1)
     rho = float(_setopt(options, "rho", 1.0))

@@ -360,3 +360,40 @@ def test_adaptive_rho(gpu, solver):
         ref = S.quadraticprogram_bounded(P, q, 0.0, lb, ub, dict(o))
     _compare(got, ref, tol=1e-6)
     assert got["steps"] == o["maxiters"] and got["rho_final"] != 1.0
+
+
+@pytest.mark.parametrize("mode", ["zming", "xminf", "both"])
+def test_in_prox_slicing_of_user_handles(gpu, mode):
+    """a15 (admm.m:343-468, parproxf / parproxg): handle(x, z, u, rho, k) returns piece k, the pieces are
+    concatenated -- a pure map, so the iterates equal those of the unsliced handles bit for bit."""
+    import torch
+    from admm_project_amd.errorcheck import slicemaker
+    dev = torch.device("cuda", 0)
+    p = gpu.synth.lasso_problem(11, 260, 90)
+    D, s_, lam = p["D"], p["s"], p["lam"]
+    n, rho = D.shape[1], 1.0
+    tMinv = torch.tensor(np.linalg.inv(D.T @ D + rho * np.eye(n)), device=dev)
+    tDts = torch.tensor(D.T @ s_, device=dev)
+    soft = lambda v, t: torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0.0)
+    xfull = lambda _x, z, u, r_: tMinv @ (tDts + r_ * (z - u))
+    zfull = lambda x, _z, u, r_: soft(x + u, lam / r_)
+    sx, sz = slicemaker(0, 4, n), slicemaker([20, 30, 40], 4, n)  # balanced over 4 workers; explicit lengths
+    ox, oz = np.concatenate([[0], np.cumsum(sx)]).astype(int), np.concatenate([[0], np.cumsum(sz)]).astype(int)
+    xk = lambda x, z, u, r_, k: xfull(x, z, u, r_)[ox[k]:ox[k + 1]]
+    zk = lambda x, z, u, r_, k: zfull(x, z, u, r_)[oz[k]:oz[k + 1]]
+    base = dict(A=1, B=-1, c=0, m=n, nA=n, nB=n, maxiters=40, domaxiters=1, workers=4)
+    ref = gpu.admm(xfull, zfull, dict(base))
+    if mode == "zming":
+        got = gpu.admm(xfull, zk, dict(base, parallel="zming", slices=[20, 30, 40]))
+    elif mode == "xminf":
+        got = gpu.admm(xk, zfull, dict(base, parallel="xminf", slices=0))
+    else:
+        got = gpu.admm(xk, zk, dict(base, parallel="both", slices=([int(v) for v in sx], [20, 30, 40])))
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm"):
+        np.testing.assert_array_equal(got[k], ref[k])
+    with pytest.raises(ValueError, match="2 element"):
+        gpu.admm(xfull, zk, dict(base, parallel="zming", slices=([1], [2])))
+    with pytest.raises(ValueError, match="both proximal ops"):
+        gpu.admm(xk, zk, dict(base, parallel="both", slices=0))
+    with pytest.raises(Exception, match="slice 0 must be a tensor of 20"):
+        gpu.admm(xfull, lambda x, z, u, r_, k: zfull(x, z, u, r_)[:7], dict(base, parallel="zming", slices=[20, 30, 40]))
