@@ -21,7 +21,7 @@ PROB_LASSO, PROB_LASSO_CONSENSUS, PROB_LAD, PROB_HUBERFIT = 1, 2, 3, 4
 PROB_LINEARSVM, PROB_TOTALVARIATION, PROB_QP_BOUNDED, PROB_BASISPURSUIT = 5, 6, 7, 8
 PROB_MODEL, PROB_LINEARPROGRAM, PROB_QP_STANDARD, PROB_TV2D = 9, 10, 11, 12
 LOSS_HINGE, LOSS_01, LOSS_HINGE_OBJ01 = 0, 1, 2
-XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG = 0, 1, 2, 3
+XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG, XSOLVE_CALLBACK = 0, 1, 2, 3, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 STOP_STANDARD, STOP_HNORM, STOP_BOTH, STOP_NONE = 0, 1, 2, 3
 FAST_OFF, FAST_STRONG, FAST_WEAK = 0, 1, 2

@@ -280,9 +280,33 @@ def _generic_problem(options):
         raise ValueError("Must specify a matrix A in constraint Ax + Bz = c!")
     if B is None:
         raise ValueError("Must specify a matrix B in constraint Ax + Bz = c!")
-    if not (np.isscalar(A) and float(A) == 1.0 and np.isscalar(B) and float(B) == -1.0):
-        raise NotImplementedError("caller-supplied prox handles run with A = 1, B = -1; general constraint "
-                                  "matrices are only engine-native through the library's own problems")
+    if not (np.isscalar(B) and float(B) == -1.0):
+        raise NotImplementedError("caller-supplied prox handles run with B = -1 (every solver of the reference "
+                                  "uses it); a general B is not engine-native")
+    if hasattr(A, "toarray"):
+        A = A.toarray()  # sparse operators (totalvariation.m:127) are streamed as dense columns
+    if not np.isscalar(A) and np.ndim(A) == 2:
+        # a constraint matrix (admm.m:117-120: A(v) = A*v, At(v) = A'*v): the A = D engine of lad.m with no
+        # factor at all -- both prox operators are the caller's; D*x, D'*(.), the residuals run on the device
+        Am = np.asfortranarray(np.asarray(A, dtype=np.float64))
+        m, n = Am.shape
+        At = options.get("At")
+        if At is not None and not np.isscalar(At) and np.shape(At) != (n, m):
+            raise ValueError("options.At is not the transpose of options.A")
+        c = options.get("c", 0.0)
+        if np.isscalar(c):
+            if float(c) != 0.0:
+                raise NotImplementedError("scalar non-zero c is not supported")
+            cvec = np.zeros(m)
+        else:
+            cvec = np.asarray(c, dtype=np.float64).reshape(-1)
+            if cvec.size != m:
+                raise ValueError("Given vector c does not match the problem size")
+        eng = Engine(L.PROB_LAD, D=Am, s=cvec, xsolve=L.XSOLVE_CALLBACK, device=int(options.get("device", 0)))
+        return _Problem("generic", eng, dict(A="D", c="s", nA=n, nB=m))
+    if not (np.isscalar(A) and float(A) == 1.0):
+        raise NotImplementedError("caller-supplied prox handles run with A = 1 or a constraint matrix A; function "
+                                  "handles for A / At are not engine-native")
     c = options.get("c", 0.0)
     n = int(options.get("nA", 0) or options.get("nB", 0) or options.get("m", 0))
     cvec = None

@@ -537,6 +537,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, ~1 ms at n = 10^4);
   // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
   if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
+  if (xs == ADMM_XSOLVE_CALLBACK && desc->problem != ADMM_PROB_LAD)
+    return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=callback is the generic A = D engine: use ADMM_PROB_LAD with D = A, s = c"));
+  if (xs == ADMM_XSOLVE_CALLBACK && e->comm && comm_nranks(e->comm) > 1)
+    return bail(fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines"));
   // 2-D TV: AUTO = the direct spectral solve when both sides are powers of two, else (or on request) warm-started
   // CG; the CG vectors are allocated either way (one of them is the transposition scratch of the spectral solve)
   const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
@@ -627,7 +631,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (!desc->D || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "problem needs D (m x n)"));
       if (!svm && !desc->s) return bail(fail(ADMM_E_INVALID, "LAD/Huber need the signal vector s"));
       if (svm && !desc->ell) return bail(fail(ADMM_E_INVALID, "linear SVM needs the label vector ell"));
-      if (m_global < n)
+      if (m_global < n && xs != ADMM_XSOLVE_CALLBACK)
         return bail(fail(ADMM_E_INVALID, "D must have full column rank (m >= n) for chol(D'*D) (lad.m:134)"));
       e->a_identity = false;
       e->nA = n;
@@ -653,6 +657,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         E_TRY(e->mem.alloc(&e->tmpA, round_up(m, 2)));
         break;
       }
+      if (e->xsolve == ADMM_XSOLVE_CALLBACK) break;  // the caller's xminf is the x-update: nothing to factor
       const int64_t ld = round_up(n, 16);
       double* W = nullptr;
       E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
@@ -1251,6 +1256,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached slice factors were built for");
+  if (e->xsolve == ADMM_XSOLVE_CALLBACK && !e->xcb)
+    return fail(ADMM_E_INVALID, "this engine was created with xsolve=callback: set the xminf callback before running");
   if (o.relax != 1.0 && (e->problem == ADMM_PROB_LINEARSVM))
     return fail(ADMM_E_INVALID,
                 "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");

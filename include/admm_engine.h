@@ -65,7 +65,10 @@ enum {
   ADMM_XSOLVE_AUTO = 0,    /* TRSV up to n = 256, INVERSE beyond */
   ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form) */
   ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once */
-  ADMM_XSOLVE_CG = 3       /* matrix-free conjugate gradients on (D'D + rho I), A-streaming */
+  ADMM_XSOLVE_CG = 3,      /* matrix-free conjugate gradients on (D'D + rho I), A-streaming */
+  ADMM_XSOLVE_CALLBACK = 4 /* A = D problems (LAD shape: A x - z = c): no factor is built, D may have any shape;
+                              every run needs an xminf callback (admm_engine_set_callbacks) -- the generic
+                              results = admm(xminf, zming, options) with a matrix options.A (admm.m:117-120) */
 };
 
 /* where the desc's data pointers live */

@@ -83,8 +83,10 @@ def test_admm_handle_validation(ap):
     # caller-supplied handles need a device (they run on CUDA tensors): on a CPU box the engine fails loudly
     with pytest.raises(ap.AdmmError, match="no HIP device"):
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=-1, c=0, m=4, nA=4, nB=4))
-    with pytest.raises(NotImplementedError, match="A = 1, B = -1"):
-        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=np.eye(4), B=-1, c=0, m=4, nA=4, nB=4))
+    with pytest.raises(NotImplementedError, match="B = -1"):
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=np.eye(4), c=0, m=4, nA=4, nB=4))
+    with pytest.raises(NotImplementedError, match="function handles for A"):
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=lambda v: v, B=-1, c=0, m=4, nA=4, nB=4))
     with pytest.raises(TypeError):
         ap.admm(None, None, "not a struct")
     with pytest.raises(TypeError, match="not a function handle"):

@@ -182,8 +182,10 @@ def test_host_handles_are_rejected(gpu):
     o = _constraint(16, maxiters=5)
     with pytest.raises(TypeError, match="CUDA tensor"):
         gpu.admm(lambda x, z, u, r: np.zeros(16), lambda x, z, u, r: np.zeros(16), o)
-    with pytest.raises(NotImplementedError, match="A = 1, B = -1"):
-        gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=np.eye(16)))
+    with pytest.raises(NotImplementedError, match="B = -1"):
+        gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, B=np.eye(16)))
+    with pytest.raises(NotImplementedError, match="function handles for A"):
+        gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=lambda v: v))
     p = gpu.synth.tv_problem(0, 64)
     minx, _mz, _ = gpu.getproxops("totalvariation", {"s": p["s"], "lambda": 1.0})
     with pytest.raises(NotImplementedError, match="cannot be mixed"):
@@ -397,3 +399,40 @@ def test_in_prox_slicing_of_user_handles(gpu, mode):
         gpu.admm(xk, zk, dict(base, parallel="both", slices=0))
     with pytest.raises(Exception, match="slice 0 must be a tensor of 20"):
         gpu.admm(xfull, lambda x, z, u, r_, k: zfull(x, z, u, r_)[:7], dict(base, parallel="zming", slices=[20, 30, 40]))
+
+
+@pytest.mark.parametrize("rows,cols,opts", [
+    (300, 40, dict(objevals=1)), (300, 40, dict(relax=1.5)), (300, 40, dict(fast=1)),
+    (30, 70, dict(convtest=1, stopcond="both")),  # fat A: no factor could exist -- none is built
+    (120, 50, dict(sparseA=1)),
+])
+def test_generic_handles_with_constraint_matrix(gpu, rows, cols, opts):
+    """a2 (admm.m:117-120): options.A is a matrix, both prox handles are the caller's (a ridge-regularised LAD written
+    by the user): D*x, A'*(.), residuals, tolerances and the u-update run on the device, nothing is factored."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(rows + cols)
+    Amat = np.asfortranarray(rng.standard_normal((rows, cols)))
+    cvec = rng.standard_normal(rows)
+    eps, rho = 0.3, 1.0
+    Minv = np.linalg.inv(eps * np.eye(cols) + rho * Amat.T @ Amat)
+    tA, tc, tMinv = (torch.tensor(a, device=dev) for a in (Amat, cvec, Minv))
+    soft_t = lambda v, t: torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0.0)
+    soft_n = lambda v, t: np.sign(v) * np.maximum(np.abs(v) - t, 0.0)
+    relaxed = opts.get("relax", 1.0) != 1.0  # admm.m:521-530: zming then receives Axhat in place of x
+    xt = lambda _x, z, u, r_: tMinv @ (r_ * (tA.T @ (z + tc - u)))
+    xn = lambda _x, z, u, r_: Minv @ (r_ * (Amat.T @ (z + cvec - u)))
+    zt = lambda x, _z, u, r_: soft_t((x if relaxed else tA @ x) + u - tc, 1.0 / r_)
+    zn = lambda x, _z, u, r_: soft_n((x if relaxed else Amat @ x) + u - cvec, 1.0 / r_)
+    opts = dict(opts)
+    sparse = opts.pop("sparseA", 0)
+    o = dict(B=-1, c=cvec, m=rows, nA=cols, nB=rows, maxiters=60, **opts)
+    og, orf = dict(o, A=Amat, At=Amat.T), dict(o, A=Amat, At=Amat.T)
+    if sparse:
+        import scipy.sparse as sp
+        og["A"], og["At"] = sp.csr_matrix(Amat), sp.csr_matrix(Amat.T)
+    if opts.get("objevals"):
+        og["obj"] = lambda x, z: 0.5 * eps * torch.sum(x * x) + torch.sum(torch.abs(z))
+        orf["obj"] = lambda x, z: 0.5 * eps * np.sum(x * x) + np.sum(np.abs(z))
+    got, ref = gpu.admm(xt, zt, og), A.admm(xn, zn, orf)
+    _compare(got, ref, tol=1e-7)
