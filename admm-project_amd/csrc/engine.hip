@@ -1698,9 +1698,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   }
 
   if (e->problem == ADMM_PROB_TOTALVARIATION) {
-    if (o.relax != 1.0)
-      return fail(ADMM_E_UNSUPPORTED,
-                  "relaxation with total variation applies D twice in the reference (getProxOps.m:199); not implemented");
+    if (o.relax != 1.0 && alg != 0)
+      return fail(ADMM_E_UNSUPPORTED, "relaxation together with fast ADMM is not implemented for total variation");
     std::vector<double> prefix;
     double bstar = 0.0;
     int halo = 0, elems = 0, tile = 0;
@@ -1759,10 +1758,15 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       fa.obj_scale_z = e->lambda;
     }
     const int check_tv = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
-    if (alg != 0) {
+    const bool tv_relaxed = o.relax != 1.0;
+    if (alg != 0 || tv_relaxed) {
       // Fast / accelerated ADMM (admm.m:267-298, 563-600): the x-update takes (v, uhat), the generic fused prox
       // kernel does the z/u update, extrapolation, histories and partial sums on the vector D*x, and the D'
       // stencils of the dual residual come from dz = z - zprev and u.  z, u are updated in place here.
+      // Over-relaxation (admm.m:515-532) takes the same unfused route: the reference's z-closure applies D to the
+      // relaxed Axhat it is handed (getProxOps.m:199), so z comes from launch_tv_relax_z and the generic kernel
+      // does everything else with z given (PROX_GIVEN).
+      if (tv_relaxed && !e->zext) ADMM_TRY(e->mem.alloc(&e->zext, round_up(len, 2)));
       if (!e->dz) ADMM_TRY(e->mem.alloc(&e->dz, round_up(len, 2)));
       if (!e->tmpA) ADMM_TRY(e->mem.alloc(&e->tmpA, round_up(len, 2)));
       pa.dz = e->dz;
@@ -1780,8 +1784,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       while (donef < N && !stopf) {
         const int32_t batch = (N - donef < check_tv) ? N - donef : check_tv;
         for (int32_t b = 0; b < batch; ++b) {
-          ta.z = e->v;  // x = xminf(x, v, uhat, rho)   admm.m:506
-          ta.u = e->uhat;
+          ta.z = alg ? e->v : e->z;  // x = xminf(x, v, uhat, rho)   admm.m:506 (plain ADMM: z, u)
+          ta.u = alg ? e->uhat : e->u;
           ta.y = e->tv_y;
           {
             TimerScope ts(e, ADMM_K_XSOLVE);
@@ -1795,6 +1799,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
             pa.axsrc = e->tmpA;
             pa.naxpart = 1;
             pa.axld = 0;
+            if (tv_relaxed) {
+              launch_tv_relax_z(e->tmpA, e->z, e->u, e->n, o.relax, pa.t, e->zext, e->ctrl, e->stream);
+              pa.prox = PROX_GIVEN;
+              pa.zgiven = e->zext;
+            }
             launch_prox(pa, e->ctrl, &nblk, e->stream);
           }
           fa.nblk = nblk;

@@ -47,6 +47,9 @@ void launch_tv_dx(const double* x, const double* s, int64_t n, double lambda, in
                   double* objpart, int* nobj_out, const Ctrl* ctrl, hipStream_t stream);
 void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, int nblk, const Ctrl* ctrl,
                     hipStream_t stream);
+// z of the relaxed iteration as the reference computes it (D applied to Axhat): zgiven = soft(u + D*Axhat, t)
+void launch_tv_relax_z(const double* ax, const double* zp, const double* u, int64_t n, double relax, double t,
+                       double* zgiven, const Ctrl* ctrl, hipStream_t stream);
 bool tv_fused_ok(const TvArgs& a);
 // slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced)
 void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream);

@@ -589,6 +589,33 @@ void launch_tv_dx(const double* x, const double* s, int64_t n, double lambda, in
                      objevals, ax, objpart, ctrl);
 }
 
+// Over-relaxation with the reference's total-variation closures (admm.m:515-532 hands Axhat to zming in place of x,
+// and getProxOps.m:199 applies D to whatever it is given): z = soft(u + D*Axhat, t),
+// Axhat = relax*ax - (1-relax)*(-zprev) with ax = D*x -- D is applied twice, reproduced as is.
+__global__ __launch_bounds__(kBlock) void tv_relax_z_kernel(const double* __restrict__ ax, const double* __restrict__ zp,
+                                                            const double* __restrict__ u, int64_t n, double relax,
+                                                            double t, double* __restrict__ zgiven,
+                                                            const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    // the expression of prox_element / prez_kernel (c = 0), so that both see the same Axhat bit for bit
+    const double h0 = relax * ax[i] - (1.0 - relax) * ((-zp[i]) - 0.0);
+    double w = h0;
+    if (i + 1 < n) w = h0 - (relax * ax[i + 1] - (1.0 - relax) * ((-zp[i + 1]) - 0.0));
+    zgiven[i] = tv_soft(u[i] + w, t);
+  }
+}
+
+void launch_tv_relax_z(const double* ax, const double* zp, const double* u, int64_t n, double relax, double t,
+                       double* zgiven, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(n, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(tv_relax_z_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, ax, zp, u, n,
+                     relax, t, zgiven, ctrl);
+}
+
 void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, int nblk, const Ctrl* ctrl,
                     hipStream_t stream) {
   hipLaunchKernelGGL(tv_dual_kernel, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, stream, dz, u, n, part, ctrl);

@@ -66,6 +66,20 @@ def test_lasso_tall(gpu, rows, cols, seed, xsolve):
     assert got["solverruntime"] >= got["runtime"] > 0
 
 
+@pytest.mark.parametrize("opts", [dict(relax=1.5, objevals=1, maxiters=8, domaxiters=1),
+                                  dict(relax=0.6, rho=2.0, maxiters=8, domaxiters=1),
+                                  dict(relax=1.8, maxiters=6, domaxiters=1, record_history=0)])
+@pytest.mark.parametrize("n", [128, 5001])
+def test_total_variation_relaxed(gpu, n, opts):
+    """a10 with the TV closures: the reference hands Axhat to a z-closure that applies D to it (getProxOps.m:199),
+    i.e. z = soft(u + D*(alpha*D*x + (1-alpha)*z_prev)) -- reproduced as is.  That iteration is not a valid ADMM step
+    and grows geometrically (1e62 after 1000 iterations at alpha = 1.5), so parity is checked over a few iterations."""
+    p = gpu.synth.tv_problem(seed=n + 1, n=n)
+    ref_opts = {k: v for k, v in opts.items() if k != "record_history"}
+    _compare(gpu.totalvariation(p["s"], p["lam"], dict(opts)), S.totalvariation(p["s"], p["lam"], ref_opts),
+             keys=HIST if opts.get("record_history", 1) else ("pnorm", "dnorm", "perr", "derr", "objevals"))
+
+
 @pytest.mark.parametrize("opts", [dict(maxiters=7, domaxiters=1), dict(maxiters=8, domaxiters=1), dict(),
                                   dict(stopcond="hnorm", maxiters=40), dict(objevals=1, rho=2.0)])
 @pytest.mark.parametrize("n", [5000, 70001])
@@ -248,7 +262,7 @@ def test_total_variation_second_run_and_errors(gpu):
     np.testing.assert_array_equal(a["zopt"], a["zvals"][:, -1])
     np.testing.assert_array_equal(a["uopt"], a["uvals"][:, -1])
     with pytest.raises(gpu.AdmmError):
-        gpu.admm(minx, minz, dict(base, relax=1.5))
+        gpu.admm(minx, minz, dict(base, relax=1.5, fast=1))  # relaxation + fast ADMM: not implemented for TV
     c = gpu.admm(minx, minz, dict(base, fast=1, maxiters=7, domaxiters=1))  # fast ADMM: the unfused TV path
     assert c["steps"] == 7 and "avals" in c
 
