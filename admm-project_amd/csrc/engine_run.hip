@@ -1,0 +1,660 @@
+// engine_run.hip -- C ABI (include/admm_engine.h), part 2: run() = admm.m:252-767, the host side of the
+// device-resident ADMM loop (x-update dispatch, the per-problem iteration sequences, stop polling, epilogue).
+#include "engine_internal.h"
+
+extern "C" {
+
+static int cg_apply(admm_engine* e, const double* v, const double** qin, int32_t* nchunk, int64_t* ldq) {
+  if (e->problem == ADMM_PROB_TV2D) {  // operator I + rho*D'D: the stencil part here, the identity via shift = 1
+    TimerScope ts(e, ADMM_K_GEMV_N);
+    launch_tv2d_laplace(e->tv2_H, e->tv2_W, e->last_opts.rho, v, e->cg_tmp, e->ctrl, e->stream);
+    *qin = e->cg_tmp;
+    *nchunk = 1;
+    *ldq = 0;
+    return ADMM_OK;
+  }
+  const Ctrl* sk = e->cg_skip;  // no-ops once this solve has converged (or the run has stopped)
+  {
+    TimerScope ts(e, ADMM_K_GEMV_N);
+    launch_gemv_n(e->planDN, e->D, v, e->partDN, sk, e->stream);
+  }
+  launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, sk, e->stream);
+  {
+    TimerScope ts(e, ADMM_K_GEMV_T);
+    launch_gemv_t(e->planDT, e->D, e->tmpA, nullptr, nullptr, 1, e->partDT, sk, e->stream);
+  }
+  *qin = e->partDT;
+  *nchunk = e->planDT.nchunk;
+  *ldq = e->planDT.ldg;
+  if (e->comm && comm_nranks(e->comm) > 1) {  // sum_g D_g'(D_g v): n doubles per inner iteration
+    launch_sum_partials_t(e->planDT, e->partDT, 1, e->cg_tmp, round_up(e->n, 2), e->ctrl, e->stream);
+    ADMM_TRY(comm_allreduce_device(e->comm, e->cg_tmp, static_cast<size_t>(e->n), e->stream));
+    *qin = e->cg_tmp;
+    *nchunk = 1;
+    *ldq = 0;
+  }
+  return ADMM_OK;
+}
+
+}  // extern "C"
+
+namespace admm {
+
+// x <- solve of (D'D + shift I) x = y by warm-started CG (cg.hip); one poll of the device per solve
+int cg_solve(admm_engine* e, const double* y) {
+  if (e->problem == ADMM_PROB_TV2D) return cg_solve_tv2d(e, y);
+  CgArgs a{};
+  a.n = e->n;
+  a.shift = (e->problem == ADMM_PROB_TV2D) ? 1.0 : (e->cg_shift_is_rho ? e->last_opts.rho : 0.0);
+  a.tol = e->cg_tol;
+  a.maxit = e->cg_maxit;
+  a.y = y;
+  a.x = e->x;
+  a.r = e->cg_r;
+  a.p = e->cg_p;
+  a.q = e->cg_q;
+  a.part = e->cg_part;
+  a.st = e->cg_st;
+  a.ctrl = e->ctrl;
+  a.skip = &e->cg_skip->stop;
+  // clear iters/done of the previous solve (total keeps counting) and re-arm the operator kernels
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_skip->stop, 0, sizeof(int32_t), e->stream));
+  const double* qin;
+  int32_t nchunk;
+  int64_t ldq;
+  ADMM_TRY(cg_apply(e, e->x, &qin, &nchunk, &ldq));
+  CgArgs a0 = a;
+  a0.p = e->x;  // q = D'D x + shift*x
+  launch_cg_q(a0, qin, nchunk, ldq, false, e->stream);
+  launch_cg_init(a, e->stream);
+  // everything enqueued after convergence is a no-op (operator kernels included), so a chunk can be as long as
+  // the previous solve was: one or two polls of the device per solve instead of one per 4 iterations
+  const int chunk = e->cg_chunk;
+  for (int done_it = 0; done_it < e->cg_maxit;) {
+    const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
+    for (int c = 0; c < k; ++c) {
+      ADMM_TRY(cg_apply(e, e->cg_p, &qin, &nchunk, &ldq));
+      launch_cg_q(a, qin, nchunk, ldq, true, e->stream);
+      launch_cg_step_tail(a, e->stream);
+    }
+    done_it += k;
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
+  }
+  e->cg_chunk = std::min(64, std::max(4, static_cast<int>(e->cg_st_host->iters) + 2));
+  return ADMM_OK;
+}
+
+}  // namespace admm
+
+extern "C" {
+
+
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld);
+
+// one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
+static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+  TimerScope ts(e, ADMM_K_XSOLVE);
+  *axsrc = e->x;
+  *naxpart = 1;
+  *axld = 0;
+  if (e->xcb) {  // x = xminf(x, z, u, rho), fast ADMM: xminf(x, v, uhat, rho)   (admm.m:502, 506)
+    const bool fastalg = e->last_opts.fast != ADMM_FAST_OFF;
+    if (e->xcb(e->xuser, e->x, fastalg ? e->v : e->z, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
+               static_cast<void*>(e->stream)) != 0)
+      return fail(ADMM_E_INVALID, "the xminf callback reported a failure");
+    if (e->a_identity) {
+      *axsrc = e->xext;  // the fused kernel stores it into x (guarded by the device stop flag)
+    } else {  // A = D: D*x follows; copy through a kernel that honours the stop flag
+      launch_combine(e->xext, 1, 0, 1.0, nullptr, 0.0, nullptr, e->x, e->nA, e->ctrl, e->stream);
+    }
+    return ADMM_OK;
+  }
+  if (e->xsolve == ADMM_XSOLVE_CG) return cg_solve(e, e->a_identity ? e->rhs : e->g);
+  switch (e->problem) {
+    case ADMM_PROB_LASSO:
+      if (!e->fat) {
+        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
+      } else {
+        // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
+        launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
+        launch_sum_partials(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->m, e->tmpA, e->ctrl, e->stream);
+        ADMM_TRY(solve_factor(e, e->tmpA, e->tmpB));
+        launch_gemv_t(e->planDT, e->D, e->tmpB, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+        const double rho = e->last_opts.rho;
+        launch_combine(e->partDT, e->planDT.nchunk, e->planDT.ldg, -1.0 / (rho * rho), e->rhs, 1.0 / rho, nullptr,
+                       e->x, e->n, e->ctrl, e->stream);
+      }
+      break;
+    case ADMM_PROB_QP_BOUNDED:  // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
+    case ADMM_PROB_MODEL:
+      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
+      break;
+    case ADMM_PROB_LINEARPROGRAM:
+    case ADMM_PROB_QP_STANDARD:  // x = K*y + k0: the KKT solve of getProxOps.m:1363 / 1410, reduced once
+      launch_gemv_t(e->planK, e->Kmat, e->rhs, nullptr, nullptr, 1, e->partK, e->ctrl, e->stream);
+      launch_combine(e->partK, e->planK.nchunk, e->planK.ldg, 1.0, nullptr, 0.0, e->k0, e->x, e->n, e->ctrl,
+                     e->stream);
+      break;
+    case ADMM_PROB_BASISPURSUIT:
+      launch_gemv_t(e->planSq, e->Pmat, e->rhs, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+      launch_combine(e->partSq, e->planSq.nchunk, e->planSq.ldg, 1.0, nullptr, 0.0, e->q, e->x, e->n, e->ctrl,
+                     e->stream);
+      break;
+    default:  // LAD / Huber / SVM: rhs already holds D'*(c + z - u) (row 0 of g)
+      ADMM_TRY(solve_factor(e, e->g, e->x));
+      break;
+  }
+  return ADMM_OK;
+}
+
+// the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+  if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
+    return symv_apply(e, e->rhs, e->x);
+  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
+    launch_symv_small(e->Minv, e->nF, e->ldMinv, e->rhs, e->x, e->ctrl, e->stream);
+  } else {
+    launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
+  }
+  return ADMM_OK;
+}
+
+int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
+                              void* zuser, admm_obj_callback obj, void* objuser) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  const bool a1 = e->problem == ADMM_PROB_MODEL || e->problem == ADMM_PROB_QP_BOUNDED ||
+                  e->problem == ADMM_PROB_BASISPURSUIT || e->problem == ADMM_PROB_LINEARPROGRAM ||
+                  e->problem == ADMM_PROB_QP_STANDARD || (e->problem == ADMM_PROB_LASSO && !e->fat);
+  const bool ad = e->problem == ADMM_PROB_LAD || e->problem == ADMM_PROB_HUBERFIT || e->problem == ADMM_PROB_LINEARSVM;
+  if ((xmin || zmin || obj) && !((a1 || ad) && e->xsolve != ADMM_XSOLVE_CG))
+    return fail(ADMM_E_UNSUPPORTED,
+                "prox callbacks are supported for the A = 1 problems (model/generic, tall lasso, QP, LP, basis pursuit) "
+                "and the A = D problems (LAD, Huber, linear SVM / unwrapped ADMM) with a cached-factor x-solve");
+  if ((xmin || zmin || obj) && e->comm && comm_nranks(e->comm) > 1)
+    return fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines");
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  const int64_t n2 = round_up(e->len, 2);
+  if (!e->xext) ADMM_TRY(e->mem.alloc(&e->xext, round_up(e->nA, 2)));
+  if (!e->zext) ADMM_TRY(e->mem.alloc(&e->zext, n2));
+  if (!e->xh) ADMM_TRY(e->mem.alloc(&e->xh, n2));
+  e->xcb = xmin;
+  e->xuser = xuser;
+  e->zcb = zmin;
+  e->zuser = zuser;
+  e->ocb = obj;
+  e->ouser = objuser;
+  return ADMM_OK;
+}
+
+int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* summary) {
+  if (!e || !opts) return fail(ADMM_E_INVALID, "engine/options is NULL");
+  if (opts->struct_size != static_cast<int32_t>(sizeof(admm_options)))
+    return fail(ADMM_E_INVALID, "admm_options.struct_size mismatch (ABI version skew)");
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  admm_options o = *opts;
+  if (!(o.rho > 0.0)) return fail(ADMM_E_INVALID, "options.rho must be positive");
+  if (o.maxiters <= 0) o.maxiters = 1000;  // admm.m:334-339
+  if (o.restart <= 0.0 || o.restart >= 1.0) o.restart = 0.999;  // admm.m:285-287
+  if (o.fast != ADMM_FAST_OFF && o.fast != ADMM_FAST_WEAK && o.fast != ADMM_FAST_STRONG)
+    return fail(ADMM_E_INVALID, "bad options.fast");
+  if (o.rho != e->rho_factor && !o.stale_factor_ok && (e->F || e->has_zfac || e->Kmat) && e->problem != ADMM_PROB_LAD && e->problem != ADMM_PROB_HUBERFIT &&
+      e->problem != ADMM_PROB_LINEARSVM)
+    return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached factor was built for");
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS && o.rho != e->rho_factor)
+    return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached slice factors were built for");
+  if (e->xsolve == ADMM_XSOLVE_CALLBACK && !e->xcb)
+    return fail(ADMM_E_INVALID, "this engine was created with xsolve=callback: set the xminf callback before running");
+  if (o.relax != 1.0 && (e->problem == ADMM_PROB_LINEARSVM))
+    return fail(ADMM_E_INVALID,
+                "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");
+  if (o.relax != 1.0 && (e->problem == ADMM_PROB_LAD || e->problem == ADMM_PROB_HUBERFIT)) {
+    // lad.m:124-126 switches to the userelax closures, which take Axhat directly: same fused formula
+  }
+  if (e->problem == ADMM_PROB_MODEL) {
+    if (!e->has_xfac && !e->xcb)
+      return fail(ADMM_E_INVALID, "no x-update: the model was created without PtP/Ptr and no xminf callback is set");
+    if (!e->has_zfac && !e->zcb)
+      return fail(ADMM_E_INVALID, "no z-update: the model was created without QtQ/Qts and no zming callback is set");
+  }
+  e->last_opts = o;
+  const int alg = o.fast;  // 0, 1 (strong), 2 (weak)
+  const bool use_h = o.convtest || o.stopcond == ADMM_STOP_HNORM || o.stopcond == ADMM_STOP_BOTH;
+  const int64_t len = e->len, nA = e->nA;
+  const int32_t N = o.maxiters;
+
+  // ---- histories
+  free_hist(e);
+  e->hist_cap = N;
+  e->hist_vectors = o.record_history != 0;
+  e->hist_fast = alg != 0;
+  if (e->hist_vectors) {
+    ADMM_TRY(hist_alloc(e, &e->xhist, static_cast<size_t>(nA) * N));
+    ADMM_TRY(hist_alloc(e, &e->zhist, static_cast<size_t>(len) * N));
+    ADMM_TRY(hist_alloc(e, &e->uhist, static_cast<size_t>(len) * N));
+    if (alg != 0) {
+      ADMM_TRY(hist_alloc(e, &e->vhist, static_cast<size_t>(len) * N));
+      ADMM_TRY(hist_alloc(e, &e->uhathist, static_cast<size_t>(len) * N));
+    }
+  }
+  double** scal[] = {&e->pnorm, &e->dnorm, &e->perr, &e->derr, &e->objv, &e->hnorm, &e->avals, &e->dvals,
+                     &e->restarted};
+  for (double** p : scal) {
+    ADMM_TRY(hist_alloc(e, p, N));
+    ADMM_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(double) * N, e->stream));
+  }
+
+  // ---- initial iterates (admm.m:252-254) and control block
+  auto init_vec = [&](double* dst, const double* src, int64_t cnt) -> int {
+    if (src) ADMM_HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyHostToDevice, e->stream));
+    else ADMM_HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * cnt, e->stream));
+    return ADMM_OK;
+  };
+  ADMM_TRY(init_vec(e->x, o.x0, nA));
+  ADMM_TRY(init_vec(e->z, o.z0, len));
+  ADMM_TRY(init_vec(e->u, o.u0, len));
+  ADMM_HIP_TRY(hipMemcpyAsync(e->v, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));     // admm.m:269
+  ADMM_HIP_TRY(hipMemcpyAsync(e->uhat, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));  // admm.m:270
+  Ctrl c0{};
+  c0.acurr = 1.0;
+  c0.aprev = 1.0;
+  c0.d = INFINITY;
+  c0.dprev = INFINITY;
+  *e->ctrl_host = c0;
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl, e->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  for (auto& t : e->timers) {
+    t.used = 0;
+    t.total_ms = 0.0;
+    t.launches = 0;
+  }
+  if (e->cg_st) ADMM_HIP_TRY(hipMemsetAsync(e->cg_st, 0, sizeof(CgState), e->stream));
+
+  // ---- objective wiring (solver-supplied handles: lasso.m:227, lad.m:148, huberfit.m:180,
+  //      linearsvm.m:231-236, quadraticprogram.m:242, basispursuit.m:140)
+  ProxArgs pa{};
+  FinArgs fa{};
+  fa.obj_scale_part = 0.0;
+  pa.objz = OBJZ_NONE;
+  pa.objx = OBJX_NONE;
+  bool obj_lasso_gemv = false, obj_qp_gemv = false, obj_model_gemv = false;
+  if (o.objevals && e->ocb) {  // options.obj is the caller's handle (admm.m:603-605)
+    fa.obj_scale_part = 1.0;
+  } else if (o.objevals) {
+    switch (e->problem) {
+      case ADMM_PROB_LASSO:
+        obj_lasso_gemv = true;
+        fa.obj_scale_part = 0.5;
+        pa.objz = OBJZ_ABS;
+        fa.obj_scale_z = e->lambda;
+        break;
+      case ADMM_PROB_LAD:
+        pa.objz = OBJZ_ABS;
+        fa.obj_scale_z = 1.0;
+        break;
+      case ADMM_PROB_HUBERFIT:
+        pa.objz = OBJZ_HUBER;
+        fa.obj_scale_z = 0.5;
+        break;
+      case ADMM_PROB_LINEARSVM:
+        pa.objx = (e->loss == ADMM_LOSS_HINGE) ? OBJX_HINGE : OBJX_ZEROONE;  // linearsvm.m:231-237
+        fa.obj_scale_x = e->C;
+        fa.obj_half_xnorm = 0.5;
+        break;
+      case ADMM_PROB_QP_BOUNDED:
+      case ADMM_PROB_QP_STANDARD:
+        obj_qp_gemv = true;
+        fa.obj_scale_part = 1.0;
+        fa.obj_const = e->rconst;
+        break;
+      case ADMM_PROB_LINEARPROGRAM:  // b'*x   (linearprogram.m:178)
+        pa.objx = OBJX_DOT;
+        fa.obj_scale_x = 1.0;
+        break;
+      case ADMM_PROB_BASISPURSUIT:
+        pa.objx = OBJX_ABS;
+        fa.obj_scale_x = 1.0;
+        break;
+      case ADMM_PROB_MODEL:  // 1/2||P*x - r||^2 + 1/2||Q*z - s||^2   (model.m:133-134)
+        if (!e->D || !e->D2)
+          return fail(ADMM_E_INVALID, "objevals on the model problem needs the matrices P, Q and vectors r, s "
+                                      "(or an objective callback)");
+        obj_model_gemv = true;
+        fa.obj_scale_part = 0.5;
+        break;
+      default:
+        break;
+    }
+  }
+
+  // ---- static parts of the kernel argument blocks
+  pa.len = len;
+  pa.c = e->c;
+  pa.ell = e->ell;
+  pa.lb = e->lb;
+  pa.ub = e->ub;
+  pa.z = e->z;
+  pa.u = e->u;
+  pa.uhat = e->uhat;
+  pa.v = e->v;
+  pa.zprev = e->zprev;
+  pa.uprev = e->uprev;
+  pa.dz = e->dz;
+  pa.rhs = e->rhs;
+  pa.rhs_add = e->rhs_add;
+  pa.zhist = e->zhist;
+  pa.uhist = e->uhist;
+  pa.xhist = e->a_identity ? e->xhist : nullptr;
+  pa.vhist = e->vhist;
+  pa.uhathist = e->uhathist;
+  pa.part = e->part;
+  pa.rho = o.rho;
+  pa.relax = o.relax;
+  const bool split_z = e->zcb != nullptr || e->problem == ADMM_PROB_MODEL;  // z is computed between two kernels
+  pa.prox = split_z ? PROX_GIVEN : e->prox;
+  pa.zgiven = e->zext;
+  pa.rhs_kind = e->xcb ? RHS_NONE : e->rhs_kind;
+  pa.alg = alg;
+  pa.a_identity = e->a_identity ? 1 : 0;
+  switch (e->prox) {
+    case PROX_SOFT:
+      pa.t = (e->problem == ADMM_PROB_LASSO) ? e->lambda / o.rho : 1.0 / o.rho;  // getProxOps.m:455 | 810, 142
+      break;
+    case PROX_HINGE:
+      pa.t = e->C / o.rho;  // getProxOps.m:1096
+      break;
+    case PROX_01:
+      pa.t = o.rho / e->C;  // getProxOps.m:1100
+      break;
+    default:
+      pa.t = 0.0;
+      break;
+  }
+
+  fa.len = len;
+  fa.nA = nA;
+  fa.part = e->part;
+  fa.g = e->a_identity ? nullptr : e->g;
+  fa.ldg = e->ldg;
+  fa.x = e->a_identity ? nullptr : e->x;
+  fa.xhist = e->a_identity ? nullptr : e->xhist;
+  fa.cnorm = e->cnorm;
+  fa.rho = o.rho;
+  fa.rhoH = o.rho;
+  fa.abstol = o.abstol;
+  fa.reltol = o.reltol;
+  fa.Hnormtol = o.Hnormtol;
+  fa.convtol = o.convtol;
+  fa.restart = o.restart;
+  fa.dvaltol = o.dvaltol;
+  fa.alg = alg;
+  fa.a_identity = pa.a_identity;
+  fa.nodualerror = o.nodualerror;
+  fa.objevals = o.objevals;
+  fa.use_h = use_h ? 1 : 0;
+  fa.convtest = o.convtest;
+  fa.stopcond = o.stopcond;
+  fa.domaxiters = o.domaxiters;
+  fa.maxiters = N;
+  fa.pnorm = e->pnorm;
+  fa.dnorm = e->dnorm;
+  fa.perr = e->perr;
+  fa.derr = e->derr;
+  fa.objv = e->objv;
+  fa.hnorm = e->hnorm;
+  fa.avals = e->avals;
+  fa.dvals = e->dvals;
+  fa.restarted = e->restarted;
+  fa.ctrl = e->ctrl;
+
+  ExtrapArgs xa{};
+  xa.len = len;
+  xa.z = e->z;
+  xa.u = e->u;
+  xa.zprev = e->zprev;
+  xa.uprev = e->uprev;
+  xa.c = e->c;
+  xa.v = e->v;
+  xa.uhat = e->uhat;
+  xa.rhs = e->rhs;
+  xa.rhs_add = e->rhs_add;
+  xa.vhist = e->vhist;
+  xa.uhathist = e->uhathist;
+  xa.rho = o.rho;
+  xa.rhs_kind = e->xcb ? RHS_NONE : e->rhs_kind;
+
+  RunState rs{o, alg, N, len, pa, fa, xa};
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS) return run_consensus_lasso(e, rs, summary);
+  if (e->problem == ADMM_PROB_TV2D) return run_total_variation_2d(e, rs, summary);
+  if (e->problem == ADMM_PROB_TOTALVARIATION) return run_total_variation(e, rs, summary);
+
+  const int nrhs_dual = o.nodualerror ? 1 : 3;
+  const bool sharded = e->comm && comm_nranks(e->comm) > 1;
+  fa.len_global = e->len_global;
+  int check_every = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+
+  // ---- loop (admm.m:315 tic .. 756 toc)
+  const auto tstart = std::chrono::steady_clock::now();
+  // rhs of the first x-update from the initial iterates (zx = v = z0, ux = uhat = u0)
+  launch_initial_rhs(len, e->rhs_kind, o.rho, e->z, e->u, e->c, e->rhs_add, e->rhs, e->stream);
+  if (!e->a_identity) {
+    TimerScope ts(e, ADMM_K_GEMV_T);
+    launch_gemv_t(e->planDT, e->D, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+    launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+    if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
+  }
+  // One iteration = a fixed sequence of launches with iteration-independent arguments (the iteration
+  // index lives in ctrl->iter), and iterations past a stop condition or past maxiters are no-ops on the
+  // device, so a batch of iterations CAN be captured once into a hipGraph and replayed.  Measured on
+  // MI355X / ROCm 7.x (profiles/svm_bench.py, profiles/trsv_graph_bench.py) replay is never faster than
+  // eager launches on one stream -- SVM 6000x400: 23.0k vs 23.9k it/s; lasso 2000x512 with the 16-launch
+  // TRSV x-solve: 3.7k vs 4.9k -- so eager is the default and ADMM_HIP_GRAPH=1 opts in.  Never used when
+  // collectives or host callbacks sit inside the iteration, for the CG x-solve (which polls the device
+  // between inner iterations), with event timing on (hipEventElapsedTime rejects events recorded by graph
+  // nodes: "invalid resource handle"), or under rocprofv3 (which segfaults inside hipGraphLaunch).
+  const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
+  const char* preload = std::getenv("LD_PRELOAD");
+  const bool profiler_attached = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
+                                 (preload && std::strstr(preload, "rocprof") != nullptr);
+  const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 &&
+                         e->xsolve != ADMM_XSOLVE_CG && !profiler_attached && heavy <= (int64_t{32} << 20) &&
+                         !e->xcb && !e->zcb && !e->ocb;
+  auto enqueue_iteration = [&]() -> int {
+    {
+      const double* axsrc;
+      int32_t naxpart;
+      int64_t axld;
+      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld));
+      if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        axsrc = e->partDN;
+        naxpart = e->planDN.nchunk;
+        axld = e->planDN.ldy;
+      }
+      int nblk = 1;
+      if (split_z) {  // z = zming(x or Axhat, z, u or uhat, rho) between the two halves of the fused kernel
+        TimerScope ts(e, ADMM_K_PROX);
+        PreZArgs za{};
+        za.len = len;
+        za.axsrc = axsrc;
+        za.naxpart = naxpart;
+        za.axld = axld;
+        za.c = e->c;
+        za.z = e->z;
+        za.uo = (alg == 0) ? e->u : e->uhat;
+        za.add = e->qz;
+        za.xh = e->xh;
+        za.rz = e->zcb ? nullptr : e->rz;
+        za.rho = o.rho;
+        za.relax = o.relax;
+        launch_prez(za, e->ctrl, e->stream);
+        if (e->zcb) {
+          // admm.m:521-530: zming is called with x itself, or with the relaxed Axhat when relax != 1; with A = 1
+          // the two have the same length (xh), with A = D the un-relaxed call passes the n-vector x
+          const double* zarg = (e->a_identity || o.relax != 1.0) ? e->xh : e->x;
+          if (e->zcb(e->zuser, zarg, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
+            return fail(ADMM_E_INVALID, "the zming callback reported a failure");
+        } else {  // zminModel: (QtQ + rho I) \ (Qts + rho*(x + u))   getProxOps.m:1012
+          apply_slice_factor(e, e->zfac, e->rz, e->zext);
+        }
+      }
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        pa.axsrc = axsrc;
+        pa.naxpart = naxpart;
+        pa.axld = axld;
+        pa.x_out = e->a_identity ? e->x : nullptr;
+        launch_prox(pa, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      fa.slots_reduced = nullptr;
+      fa.objp_reduced = nullptr;
+      const bool shard_rows = sharded && !e->a_identity;  // z, u and the residual sums are row-local
+      if (alg == 2) {
+        if (shard_rows) {  // the restart decision needs the global ||u-uhat||^2, ||z-v||^2 (admm.m:572-573)
+          launch_pack_slots(e->part, nblk, e->red, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red, 16, e->stream));
+          fa.slots_reduced = e->red;
+        }
+        launch_fast_decide(fa, e->stream);
+        launch_extrapolate(xa, e->ctrl, e->stream);
+      }
+      if (!e->a_identity) {  // D'*[c+zx-ux, z-zprev, u]  (getProxOps.m:1514; admm.m:624, 654) in ONE pass
+        TimerScope ts(e, ADMM_K_GEMV_T);
+        launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs_dual, e->partDT, e->ctrl, e->stream);
+        launch_sum_partials_t(e->planDT, e->partDT, nrhs_dual, e->g, e->ldg, e->ctrl, e->stream);
+        if (shard_rows) {
+          // ONE all-reduce per iteration: d = sum_g D_g'(...) (unwrappedadmm.m:135-137) for up to
+          // three right-hand sides plus the 16 residual/objective partial sums (X3 + X6)
+          double* slots = e->g + 3 * e->ldg;
+          if (alg == 2) ADMM_HIP_TRY(hipMemcpyAsync(slots, e->red, 16 * sizeof(double), hipMemcpyDeviceToDevice,
+                                                     e->stream));
+          else launch_pack_slots(e->part, nblk, slots, e->ctrl, e->stream);
+          if (alg == 2) {  // slots were already reduced: only the vectors travel
+            ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(3 * e->ldg), e->stream));
+          } else {
+            ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(3 * e->ldg + 16), e->stream));
+          }
+          fa.slots_reduced = slots;
+        }
+      }
+      fa.objpart = nullptr;
+      fa.nobjpart = 0;
+      if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob = 0;
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        launch_residual_sq(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->s, e->m, e->objpart, &nob, e->ctrl,
+                           e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob;
+        if (sharded) {  // sum over the row shards of ||D_g*x - s_g||^2
+          launch_pack_sum(e->objpart, nob, e->red + 16, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 1, e->stream));
+          fa.objp_reduced = e->red + 16;
+        }
+      } else if (o.objevals && e->ocb) {  // objevals(i) = obj(x, z) with the caller's handle (admm.m:604)
+        if (e->ocb(e->ouser, e->x, nA, e->z, len, e->objpart, static_cast<void*>(e->stream)) != 0)
+          return fail(ADMM_E_INVALID, "the objective callback reported a failure");
+        fa.objpart = e->objpart;
+        fa.nobjpart = 1;
+      } else if (obj_model_gemv) {
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob1 = 0, nob2 = 0;
+        launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
+        launch_residual_sq(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->ell, e->m, e->objpart, &nob1, e->ctrl,
+                           e->stream);
+        launch_gemv_n(e->planD2N, e->D2, e->z, e->partD2N, e->ctrl, e->stream);
+        launch_residual_sq(e->partD2N, e->planD2N.nchunk, e->planD2N.ldy, e->s2, e->m2, e->objpart + nob1, &nob2,
+                           e->ctrl, e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob1 + nob2;
+      } else if (obj_qp_gemv) {  // 1/2 x'Px + q'x + r  (quadraticprogram.m:242)
+        int nob = 0;
+        const GemvTPlan& p = e->planSq;  // P is symmetric
+        launch_gemv_t(p, e->Pmat, e->x, nullptr, nullptr, 1, e->partSq, e->ctrl, e->stream);
+        launch_qp_objective(e->partSq, p.nchunk, p.ldg, e->x, e->q, e->n, e->objpart, &nob, e->ctrl, e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob;
+      }
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+    }
+    return ADMM_OK;
+  };
+
+  int32_t enq = 0;
+  bool stopped = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int32_t gbatch = 0;
+  if (use_graph) {
+    gbatch = (N < check_every) ? N : check_every;
+    hipError_t ge = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+    int rc_cap = ADMM_OK;
+    if (ge == hipSuccess) {
+      for (int32_t b = 0; b < gbatch && rc_cap == ADMM_OK; ++b) rc_cap = enqueue_iteration();
+      ge = hipStreamEndCapture(e->stream, &graph);
+    }
+    if (ge == hipSuccess && rc_cap == ADMM_OK) ge = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+    if (ge != hipSuccess || rc_cap != ADMM_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return fail(ADMM_E_DEVICE, std::string("hipGraph capture of the iteration failed: ") + hipGetErrorString(ge));
+    }
+  }
+  int loop_rc = ADMM_OK;
+  while (enq < N && !stopped && loop_rc == ADMM_OK) {
+    int32_t batch = (N - enq < check_every) ? N - enq : check_every;
+    if (gexec) {
+      batch = gbatch;  // a full batch; iterations beyond maxiters are device-side no-ops
+      if (hipGraphLaunch(gexec, e->stream) != hipSuccess) loop_rc = fail(ADMM_E_DEVICE, "hipGraphLaunch failed");
+    } else {
+      for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
+    }
+    enq += batch;
+    if (loop_rc == ADMM_OK && (!o.domaxiters || enq >= N)) {
+      if (hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+          hipStreamSynchronize(e->stream) != hipSuccess)
+        loop_rc = fail(ADMM_E_DEVICE, "polling the device control block failed");
+      else if (e->ctrl_host->stop) stopped = true;
+    }
+  }
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
+  ADMM_TRY(loop_rc);
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
+  if (e->profiling) collect_timers(e);
+  for (auto& t : e->timers) t.used = 0;
+
+  e->last = admm_run_summary{};
+  e->last.steps = e->ctrl_host->steps;
+  if (e->cg_st) {
+    ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
+    e->cg_total_last = e->cg_st_host->total;
+  }
+  e->last.stopped_early = (e->ctrl_host->steps < N) ? 1 : 0;
+  e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.runtime_s = runtime;
+  e->last.objopt = NAN;
+  if (o.objevals && e->last.steps > 0) {  // admm.m:752-754: obj(x,z) at the final iterates == last objevals entry
+    double v = NAN;
+    ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (e->last.steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+    e->last.objopt = v;
+  }
+  e->has_run = true;
+  if (summary) *summary = e->last;
+  return ADMM_OK;
+}
+
+}  // extern "C"

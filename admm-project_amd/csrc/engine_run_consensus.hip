@@ -1,0 +1,145 @@
+// engine_run_consensus.hip -- the iteration sequence of consensus lasso (getProxOps.m:383-442, 1217-1343; one slice
+// per rank when row-sharded), split out of admm_engine_run.
+#include "engine_internal.h"
+
+namespace admm {
+
+int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary) {
+  const admm_options& o = rs.o;
+  const int alg = rs.alg;
+  const int32_t N = rs.N;
+  const int64_t len = rs.len;
+  ProxArgs& pa = rs.pa;
+  FinArgs& fa = rs.fa;
+  ExtrapArgs& xa = rs.xa;
+  (void)alg; (void)len; (void)pa; (void)xa;
+
+  if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for consensus lasso");
+  if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for consensus lasso");
+  const bool shard = e->comm && comm_nranks(e->comm) > 1;
+  const int32_t K = static_cast<int32_t>(e->cslices.size());
+  const int64_t n = e->n, ldn = e->cldn;
+  // closure state at getproxops time: x_k = u_k = 0, z = 0, xave = 0 (getProxOps.m:390-411); admm's own
+  // u starts at options.u0 (admm.m:254) and only enters the first H-norm difference
+  ADMM_HIP_TRY(hipMemsetAsync(e->cX, 0, sizeof(double) * K * ldn, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->cU, 0, sizeof(double) * K * ldn, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->czc, 0, sizeof(double) * ldn, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->cxave, 0, sizeof(double) * ldn, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->cxaveprev, 0, sizeof(double) * ldn, e->stream));
+  ADMM_HIP_TRY(hipMemcpyAsync(e->cubar, e->u, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->cobjpart, 0, sizeof(double) * K * kMaxPartBlocks, e->stream));
+  ConsArgs ca{};
+  ca.n = n;
+  ca.ldn = ldn;
+  ca.K = K;
+  ca.Ntot = e->cons_total;
+  ca.rho = o.rho;
+  ca.lambda = e->lambda;
+  ca.sums = e->csums;
+  ca.X = e->cX;
+  ca.U = e->cU;
+  ca.zc = e->czc;
+  ca.xave = e->cxave;
+  ca.xaveprev = e->cxaveprev;
+  ca.ubar = e->cubar;
+  ca.xhist = e->xhist;
+  ca.zhist = e->zhist;
+  ca.uhist = e->uhist;
+  ca.part = e->part;
+  fa.specialnorms = 1;
+  fa.nslices_total = e->cons_total;
+  fa.g = nullptr;
+  fa.x = nullptr;
+  fa.xhist = nullptr;
+  fa.obj_scale_part = o.objevals ? 0.5 : 0.0;  // lasso.m:227 with the z admm holds (zeros): 0.5*||D*x - s||^2
+  fa.obj_scale_z = 0.0;
+  const int check_c = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+  const auto t0 = std::chrono::steady_clock::now();
+  int32_t done = 0;
+  bool stop_seen = false;
+  while (done < N && !stop_seen) {
+    const int32_t batch = (N - done < check_c) ? N - done : check_c;
+    for (int32_t b = 0; b < batch; ++b) {
+      {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
+          ConsSlice& sl = e->cslices[k];
+          launch_cons_rhs(n, o.rho, e->czc, e->cU + k * ldn, sl.Dts, e->cy, e->ctrl, e->stream);
+          apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
+        }
+      }
+      launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->ctrl, e->stream);
+      if (shard) ADMM_TRY(comm_allreduce_device(e->comm, e->csums, static_cast<size_t>(2 * ldn), e->stream));  // X1
+      int nblk = 1;
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        launch_cons_update(ca, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      fa.objpart = nullptr;
+      fa.nobjpart = 0;
+      fa.slots_reduced = nullptr;
+      fa.objp_reduced = nullptr;
+      if (o.objevals) {
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        for (int32_t k = 0; k < K; ++k) {
+          ConsSlice& sl = e->cslices[k];
+          int nob = 0;
+          launch_gemv_n(sl.planN, sl.D, e->cxave, e->partDN, e->ctrl, e->stream);
+          launch_residual_sq(e->partDN, sl.planN.nchunk, sl.planN.ldy, sl.s, sl.m, e->cobjpart + k * kMaxPartBlocks,
+                             &nob, e->ctrl, e->stream);
+        }
+        fa.objpart = e->cobjpart;
+        fa.nobjpart = K * kMaxPartBlocks;
+      }
+      if (shard) {  // X2: only sum_k ||x_k - xave||^2 and the objective are rank-local sums
+        launch_pack_slots(e->part, nblk, e->red, e->ctrl, e->stream);
+        ADMM_HIP_TRY(hipMemcpyAsync(e->red + 16, e->red + S_R2, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        if (o.objevals) launch_pack_sum(e->cobjpart, K * kMaxPartBlocks, e->red + 17, e->ctrl, e->stream);
+        ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 2, e->stream));
+        ADMM_HIP_TRY(hipMemcpyAsync(e->red + S_R2, e->red + 16, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        fa.slots_reduced = e->red;
+        if (o.objevals) fa.objp_reduced = e->red + 17;
+      }
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+    }
+    done += batch;
+    if (!o.domaxiters || done >= N) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      if (e->ctrl_host->stop) stop_seen = true;
+    }
+  }
+  // what admm holds at exit: x = mean x_k, z = 0 (q9), u = mean u_k
+  ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->cxave, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->z, 0, sizeof(double) * n, e->stream));
+  ADMM_HIP_TRY(hipMemcpyAsync(e->u, e->cubar, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (e->profiling) collect_timers(e);
+  const int32_t steps = e->ctrl_host->steps;
+  e->last = admm_run_summary{};
+  e->last.steps = steps;
+  e->last.stopped_early = (steps < N) ? 1 : 0;
+  e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.runtime_s = rt;
+  e->last.objopt = NAN;
+  if (o.objevals && steps > 0) {
+    double v = NAN;
+    ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+    e->last.objopt = v;
+  }
+  e->has_run = true;
+  if (summary) *summary = e->last;
+  return ADMM_OK;
+}
+
+}  // namespace admm

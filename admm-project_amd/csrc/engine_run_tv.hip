@@ -1,0 +1,415 @@
+// engine_run_tv.hip -- the iteration sequences of total variation (totalvariation.m:122-164; fused kernel, the
+// unfused fast / relaxed form) and of its 2-D extension (spectral or CG x-update), split out of admm_engine_run.
+#include "engine_internal.h"
+
+namespace admm {
+
+// 2-D TV: CG with the direction update fused into the stencil apply (10 instead of 14 vector passes and 3 instead
+// of 5 launches per inner iteration); p ping-pongs between cg_p and cg_tmp
+int cg_solve_tv2d(admm_engine* e, const double* y) {
+  CgArgs a{};
+  a.n = e->n;
+  a.shift = 1.0;
+  a.tol = e->cg_tol;
+  a.maxit = e->cg_maxit;
+  a.y = y;
+  a.x = e->x;
+  a.r = e->cg_r;
+  a.p = e->cg_p;
+  a.q = e->cg_q;
+  a.part = e->cg_part;
+  a.st = e->cg_st;
+  a.ctrl = e->ctrl;
+  const double rho = e->last_opts.rho;
+  ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
+  // r = y - (I + rho*D'D) x, p = r, rs, ||y||
+  launch_tv2d_laplace(e->tv2_H, e->tv2_W, rho, e->x, e->cg_tmp, e->ctrl, e->stream);
+  CgArgs a0 = a;
+  a0.p = e->x;
+  launch_cg_q(a0, e->cg_tmp, 1, 0, false, e->stream);
+  launch_cg_init(a, e->stream);
+  double* pbuf[2] = {e->cg_p, e->cg_tmp};
+  int cur = 0;
+  launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[1], true, e->stream);  // q = A p, p.q (beta = 0)
+  cur = 1;
+  const int chunk = e->cg_chunk;  // as long as the previous solve: launches after convergence are no-ops
+  for (int done_it = 0; done_it < e->cg_maxit;) {
+    const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
+    for (int c = 0; c < k; ++c) {
+      a.p = pbuf[cur];
+      launch_cg_update(a, e->stream);   // alpha, x += alpha p, r -= alpha q, (r.r)_new partials
+      launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[cur ^ 1], false, e->stream);
+      cur ^= 1;
+      launch_cg_advance(a, e->stream);  // rs <- (r.r)_new, convergence flag
+    }
+    done_it += k;
+    ADMM_HIP_TRY(hipMemcpyAsync(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->cg_st_host->done || e->ctrl_host->stop) break;
+  }
+  e->cg_chunk = std::min(64, std::max(4, static_cast<int>(e->cg_st_host->iters) + 2));
+  return ADMM_OK;
+}
+
+// 2-D TV x-update, direct: x = C2' diag(1/(1 + rho*(lamH_i + lamW_j))) C2 y with the 2-D DCT-II C2 (dct.h).
+// Five streaming passes (10 N doubles of traffic); y is overwritten, e->cg_r is the transposition scratch.
+static int dct_solve_tv2d(admm_engine* e, double* y) {
+  TimerScope ts(e, ADMM_K_XSOLVE);
+  const int64_t H = e->tv2_H, W = e->tv2_W;
+  launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);                 // along i, in place
+  launch_transpose(y, e->cg_r, H, W, e->ctrl, e->stream);                        // -> W x H
+  launch_dct_rows_solve(e->cg_r, H, W, e->last_opts.rho, e->dctH, e->dctW, e->ctrl, e->stream);
+  launch_transpose(e->cg_r, y, W, H, e->ctrl, e->stream);                        // -> H x W
+  launch_dct_cols_inverse(y, e->x, H, W, e->dctH, e->ctrl, e->stream);
+  return ADMM_OK;
+}
+
+int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summary) {
+  const admm_options& o = rs.o;
+  const int alg = rs.alg;
+  const int32_t N = rs.N;
+  const int64_t len = rs.len;
+  ProxArgs& pa = rs.pa;
+  FinArgs& fa = rs.fa;
+  ExtrapArgs& xa = rs.xa;
+  (void)alg; (void)len; (void)pa; (void)xa;
+
+  if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for 2-D total variation");
+  if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for 2-D total variation");
+  const int64_t Npix = e->tv2_H * e->tv2_W;
+  if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
+    ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+  }
+  Tv2Args ta{};
+  ta.H = e->tv2_H;
+  ta.W = e->tv2_W;
+  ta.rho = o.rho;
+  ta.thresh = e->lambda / o.rho;
+  ta.s = e->s;
+  ta.x = e->x;
+  ta.objevals = o.objevals;
+  ta.xhist = e->xhist;
+  ta.zhist = e->zhist;
+  ta.uhist = e->uhist;
+  ta.part = e->part;
+  fa.g = nullptr;
+  fa.x = nullptr;
+  fa.xhist = nullptr;
+  fa.dual_from_slots = 1;
+  if (o.objevals) {  // 1/2*||x - s||^2 + lambda*||D x||_1
+    fa.obj_scale_x = 0.5;
+    fa.obj_scale_z = e->lambda;
+  }
+  (void)Npix;
+  const int check_tv2 = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+  const auto t0 = std::chrono::steady_clock::now();
+  int32_t done = 0;
+  bool stop_seen = false;
+  while (done < N && !stop_seen) {
+    const bool a_cur = (done & 1) == 0;  // iteration k reads buffer A when k is even
+    ta.z = a_cur ? e->tv_zA : e->tv_zB;
+    ta.u = a_cur ? e->tv_uA : e->tv_uB;
+    ta.zo = a_cur ? e->tv_zB : e->tv_zA;
+    ta.uo = a_cur ? e->tv_uB : e->tv_uA;
+    if (done == 0) {  // later right-hand sides come out of the fused z/u pass of the previous iteration
+      TimerScope ts(e, ADMM_K_XSOLVE);
+      launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
+    }
+    // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
+    if (e->tv2_dct) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+    else ADMM_TRY(cg_solve(e, e->rhs));
+    int nblk = 1;
+    {
+      TimerScope ts(e, ADMM_K_PROX);
+      launch_tv2d_fused(ta, e->rhs, e->ctrl, &nblk, e->stream);
+    }
+    fa.nblk = nblk;
+    {
+      TimerScope ts(e, ADMM_K_FINALIZE);
+      launch_finalize(fa, e->stream);
+    }
+    done += 1;
+    // the CG path synchronises inside every solve anyway; the spectral path runs check_tv2 iterations ahead
+    // (everything enqueued after the stop flag is a no-op)
+    if (!e->tv2_dct || done % check_tv2 == 0 || done == N) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      if (e->ctrl_host->stop) stop_seen = true;
+    }
+  }
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (e->profiling) collect_timers(e);
+  const int32_t steps = e->ctrl_host->steps;
+  e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
+  e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+  ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
+  e->cg_total_last = e->cg_st_host->total;
+  e->last = admm_run_summary{};
+  e->last.steps = steps;
+  e->last.stopped_early = (steps < N) ? 1 : 0;
+  e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.runtime_s = rt;
+  e->last.objopt = NAN;
+  if (o.objevals && steps > 0) {
+    double v = NAN;
+    ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+    e->last.objopt = v;
+  }
+  e->has_run = true;
+  if (summary) *summary = e->last;
+  return ADMM_OK;
+}
+
+int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary) {
+  const admm_options& o = rs.o;
+  const int alg = rs.alg;
+  const int32_t N = rs.N;
+  const int64_t len = rs.len;
+  ProxArgs& pa = rs.pa;
+  FinArgs& fa = rs.fa;
+  ExtrapArgs& xa = rs.xa;
+  (void)alg; (void)len; (void)pa; (void)xa;
+
+  if (o.relax != 1.0 && alg != 0)
+    return fail(ADMM_E_UNSUPPORTED, "relaxation together with fast ADMM is not implemented for total variation");
+  std::vector<double> prefix;
+  double bstar = 0.0;
+  int halo = 0, elems = 0, tile = 0;
+  ADMM_TRY(tv_plan(o.rho, e->n, &prefix, &bstar, &halo, &elems, &tile));
+  if (prefix.size() > e->tv_bprefix_cap) {
+    ADMM_TRY(e->mem.alloc(&e->tv_bprefix, prefix.size()));
+    e->tv_bprefix_cap = prefix.size();
+  }
+  ADMM_HIP_TRY(hipMemcpyAsync(e->tv_bprefix, prefix.data(), sizeof(double) * prefix.size(), hipMemcpyHostToDevice,
+                              e->stream));
+  // the initial iterates were written to e->z / e->u; make buffer A the current one
+  if (e->z != e->tv_zA) {
+    ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+  }
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  TvArgs ta{};
+  ta.n = e->n;
+  ta.rho = o.rho;
+  ta.thresh = e->lambda / o.rho;
+  ta.s = e->s;
+  ta.x = e->x;
+  ta.y = e->tv_y;
+  ta.bprefix = e->tv_bprefix;
+  ta.nprefix = static_cast<int64_t>(prefix.size());
+  ta.bstar = bstar;
+  ta.halo = halo;
+  ta.elems = elems;
+  ta.tile = tile;
+  ta.ftile = 256 * elems - 2 * halo - 4;
+  ta.objevals = o.objevals;
+  ta.xhist = e->xhist;
+  ta.zhist = e->zhist;
+  ta.uhist = e->uhist;
+  ta.part = e->part;
+  // one fused launch per iteration (8 vector passes) when the halo is small; the three-kernel form otherwise
+  const bool tv_fused = tv_fused_ok(ta) && std::getenv("ADMM_HIP_TV_UNFUSED") == nullptr;
+  double* tv_part = nullptr;  // per-tile partials of the fused kernel (one column per tile)
+  if (tv_fused) {
+    ta.part_stride = round_up(ceil_div(e->n, ta.ftile), 2);
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * S_COUNT * ta.part_stride));
+    ta.part = tv_part;
+  }
+  struct DevFree {
+    void* p;
+    ~DevFree() {
+      if (p) (void)hipFree(p);
+    }
+  } tv_part_guard{tv_part};
+  fa.g = nullptr;
+  fa.x = nullptr;
+  fa.xhist = nullptr;
+  fa.dual_from_slots = 1;
+  if (o.objevals) {  // totalvariation.m:134-135
+    fa.obj_scale_x = 0.5;
+    fa.obj_scale_z = e->lambda;
+  }
+  const int check_tv = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
+  const bool tv_relaxed = o.relax != 1.0;
+  if (alg != 0 || tv_relaxed) {
+    // Fast / accelerated ADMM (admm.m:267-298, 563-600): the x-update takes (v, uhat), the generic fused prox
+    // kernel does the z/u update, extrapolation, histories and partial sums on the vector D*x, and the D'
+    // stencils of the dual residual come from dz = z - zprev and u.  z, u are updated in place here.
+    // Over-relaxation (admm.m:515-532) takes the same unfused route: the reference's z-closure applies D to the
+    // relaxed Axhat it is handed (getProxOps.m:199), so z comes from launch_tv_relax_z and the generic kernel
+    // does everything else with z given (PROX_GIVEN).
+    if (tv_relaxed && !e->zext) ADMM_TRY(e->mem.alloc(&e->zext, round_up(len, 2)));
+    if (!e->dz) ADMM_TRY(e->mem.alloc(&e->dz, round_up(len, 2)));
+    if (!e->tmpA) ADMM_TRY(e->mem.alloc(&e->tmpA, round_up(len, 2)));
+    pa.dz = e->dz;
+    pa.t = e->lambda / o.rho;  // getProxOps.m:199
+    pa.objz = OBJZ_NONE;
+    pa.objx = OBJX_NONE;
+    pa.x_out = nullptr;
+    fa.obj_scale_x = 0.0;
+    fa.obj_scale_z = 0.0;
+    fa.obj_scale_part = o.objevals ? 1.0 : 0.0;
+    ta.part = e->part;
+    const auto t0f = std::chrono::steady_clock::now();
+    int32_t donef = 0;
+    bool stopf = false;
+    while (donef < N && !stopf) {
+      const int32_t batch = (N - donef < check_tv) ? N - donef : check_tv;
+      for (int32_t b = 0; b < batch; ++b) {
+        ta.z = alg ? e->v : e->z;  // x = xminf(x, v, uhat, rho)   admm.m:506 (plain ADMM: z, u)
+        ta.u = alg ? e->uhat : e->u;
+        ta.y = e->tv_y;
+        {
+          TimerScope ts(e, ADMM_K_XSOLVE);
+          launch_tv_sweep(ta, false, e->ctrl, e->stream);
+          launch_tv_sweep(ta, true, e->ctrl, e->stream);
+        }
+        int nob = 0, nblk = 1;
+        launch_tv_dx(e->x, e->s, e->n, e->lambda, o.objevals, e->tmpA, e->objpart, &nob, e->ctrl, e->stream);
+        {
+          TimerScope ts(e, ADMM_K_PROX);
+          pa.axsrc = e->tmpA;
+          pa.naxpart = 1;
+          pa.axld = 0;
+          if (tv_relaxed) {
+            launch_tv_relax_z(e->tmpA, e->z, e->u, e->n, o.relax, pa.t, e->zext, e->ctrl, e->stream);
+            pa.prox = PROX_GIVEN;
+            pa.zgiven = e->zext;
+          }
+          launch_prox(pa, e->ctrl, &nblk, e->stream);
+        }
+        fa.nblk = nblk;
+        fa.slots_reduced = nullptr;
+        fa.objp_reduced = nullptr;
+        if (alg == 2) {
+          launch_fast_decide(fa, e->stream);
+          launch_extrapolate(xa, e->ctrl, e->stream);
+        }
+        launch_tv_dual(e->dz, e->u, e->n, e->part, nblk, e->ctrl, e->stream);
+        fa.objpart = o.objevals ? e->objpart : nullptr;
+        fa.nobjpart = o.objevals ? nob : 0;
+        {
+          TimerScope ts(e, ADMM_K_FINALIZE);
+          launch_finalize(fa, e->stream);
+        }
+      }
+      donef += batch;
+      if (!o.domaxiters || donef >= N) {
+        ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->ctrl_host->stop) stopf = true;
+      }
+    }
+    ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+    }
+    if (e->profiling) collect_timers(e);
+    const int32_t stepsf = e->ctrl_host->steps;
+    e->last = admm_run_summary{};
+    e->last.steps = stepsf;
+    e->last.stopped_early = (stepsf < N) ? 1 : 0;
+    e->last.convtest_failed_at = e->ctrl_host->convfail;
+    e->last.runtime_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0f).count();
+    e->last.objopt = NAN;
+    if (o.objevals && stepsf > 0) {
+      double v = NAN;
+      ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (stepsf - 1), sizeof(double), hipMemcpyDeviceToHost));
+      e->last.objopt = v;
+    }
+    e->has_run = true;
+    if (summary) *summary = e->last;
+    return ADMM_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  int32_t done = 0;
+  bool stop_seen = false;
+  // x only leaves the fused kernel when its history is recorded; otherwise one backward sweep after the loop
+  // rebuilds the final x from the forward-sweep vector the last executed iteration read (still intact: every
+  // launch after the stop flag is a no-op, and an iteration writes the OTHER y buffer)
+  ta.skip_x = (tv_fused && !e->xhist) ? 1 : 0;
+  if (tv_fused) {  // the forward sweep of iteration 0; every later one is produced by the fused kernel
+    TimerScope ts(e, ADMM_K_XSOLVE);
+    ta.z = e->tv_zA;
+    ta.u = e->tv_uA;
+    ta.y = e->tv_y;
+    launch_tv_sweep(ta, false, e->ctrl, e->stream);
+  }
+  while (done < N && !stop_seen) {
+    const int32_t batch = (N - done < check_tv) ? N - done : check_tv;
+    for (int32_t b = 0; b < batch; ++b) {
+      const bool a_cur = ((done + b) & 1) == 0;  // iteration k reads A when k is even
+      ta.z = a_cur ? e->tv_zA : e->tv_zB;
+      ta.u = a_cur ? e->tv_uA : e->tv_uB;
+      ta.zo = a_cur ? e->tv_zB : e->tv_zA;
+      ta.uo = a_cur ? e->tv_uB : e->tv_uA;
+      int nblk = 1;
+      if (tv_fused) {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        ta.yin = a_cur ? e->tv_y : e->tv_y2;
+        ta.yout = a_cur ? e->tv_y2 : e->tv_y;
+        launch_tv_fused(ta, e->red, e->ctrl, e->stream);
+        fa.slots_reduced = e->red;
+      } else {
+        {
+          TimerScope ts(e, ADMM_K_XSOLVE);
+          launch_tv_sweep(ta, false, e->ctrl, e->stream);
+          launch_tv_sweep(ta, true, e->ctrl, e->stream);
+        }
+        TimerScope ts(e, ADMM_K_PROX);
+        launch_tv_prox(ta, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+    }
+    done += batch;
+    if (!o.domaxiters || done >= N) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      if (e->ctrl_host->stop) stop_seen = true;
+    }
+  }
+  ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  if (e->profiling) collect_timers(e);
+  const int32_t steps = e->ctrl_host->steps;
+  // iterations executed on the device decide which ping-pong buffer holds the final z, u
+  e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
+  e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+  if (ta.skip_x && steps > 0) {
+    ta.y = ((steps - 1) & 1) ? e->tv_y2 : e->tv_y;
+    launch_tv_sweep(ta, true, e->ctrl_idle, e->stream);  // the loop's own flag says "stopped" by now
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  e->last = admm_run_summary{};
+  e->last.steps = steps;
+  e->last.stopped_early = (steps < N) ? 1 : 0;
+  e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.runtime_s = rt;
+  e->last.objopt = NAN;
+  if (o.objevals && steps > 0) {
+    double v = NAN;
+    ADMM_HIP_TRY(hipMemcpy(&v, e->objv + (steps - 1), sizeof(double), hipMemcpyDeviceToHost));
+    e->last.objopt = v;
+  }
+  e->has_run = true;
+  if (summary) *summary = e->last;
+  return ADMM_OK;
+}
+
+}  // namespace admm
