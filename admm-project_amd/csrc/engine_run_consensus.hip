@@ -15,7 +15,9 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
   (void)alg; (void)len; (void)pa; (void)xa;
 
   if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for consensus lasso");
-  if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for consensus lasso");
+  // options.relax: admm.m:515-532 only changes what it hands to zming and to the u-update -- the consensus closures
+  // ignore every argument (getProxOps.m:1217, 1272, 1312 take `~`) and options.altu replaces the u-update, so the
+  // iterates, norms and histories are those of relax = 1: accepted, no effect.
   const bool shard = e->comm && comm_nranks(e->comm) > 1;
   const int32_t K = static_cast<int32_t>(e->cslices.size());
   const int64_t n = e->n, ldn = e->cldn;

@@ -273,6 +273,7 @@ def test_total_variation_second_run_and_errors(gpu):
     (1000, 60, 8, dict(rho=2.0)),              # 8 slices of 125 rows (config-4 shape, scaled down)
     (515, 48, 3, dict(maxiters=15, domaxiters=1)),  # uneven slices 172/172/171
     (300, 70, 2, dict(u0=np.linspace(-1, 1, 70))),
+    (256, 64, 4, dict(relax=1.5)),             # the closures ignore what admm relaxes: same iterates as relax = 1
 ])
 def test_consensus_lasso(gpu, rows, cols, workers, opts, xsolve):
     """Config 4 semantics (getProxOps.m:1217-1343) incl. quirks q9-q11: z handed to admm is 0,
