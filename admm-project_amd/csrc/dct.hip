@@ -1,4 +1,4 @@
-// dct.hip -- LDS-resident fp64 DCT-II / DCT-III (length 2^p <= 4096) and the spectral x-update of 2-D total
+// dct.hip -- LDS-resident fp64 DCT-II / DCT-III (length 2^p <= 8192) and the spectral x-update of 2-D total
 // variation (dct.h).  One workgroup transforms TWO real sequences at once as one complex FFT (z = a + i*b):
 //   Makhoul's permutation   v[n] = x[2n], v[N-1-n] = x[2n+1]        turns the DCT-II into an N-point FFT of v,
 //   X_k = Re(e^{-i pi k/(2N)} V_k),  X_{N-k} = -Im(e^{-i pi k/(2N)} V_k),
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void transpose_kernel(const double* __restr
   }
 }
 
-bool dct_length_ok(int64_t n) { return n >= 8 && n <= 4096 && (n & (n - 1)) == 0; }
+bool dct_length_ok(int64_t n) { return n >= 8 && n <= 8192 && (n & (n - 1)) == 0; }
 
 void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam) {
   const long double pi = 3.141592653589793238462643383279502884L;
@@ -286,20 +286,29 @@ void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam)
 
 static size_t dct_lds_bytes(int n) { return sizeof(c64) * static_cast<size_t>(n); }
 
+// n = 8192 needs 128 KB of the CU's 160 KB LDS (one workgroup per CU): beyond the 64 KB a launch gets by default
+template <typename K>
+static void dct_allow_lds(K kernel, size_t bytes) {
+  if (bytes > (64u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
 void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
                              hipStream_t stream) {
+  dct_allow_lds(dct_cols_forward_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, img, H, th, ctrl);
 }
 
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream) {
+  dct_allow_lds(dct_cols_inverse_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, src, dst, H, th, ctrl);
 }
 
 void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const DctTables& th, const DctTables& tw,
                            const Ctrl* ctrl, hipStream_t stream) {
+  dct_allow_lds(dct_rows_solve_kernel, dct_lds_bytes(tw.n));
   hipLaunchKernelGGL(dct_rows_solve_kernel, dim3(static_cast<unsigned>(H / 2)), dim3(kBlock), dct_lds_bytes(tw.n),
                      stream, t, W, rho, th.lam, tw, ctrl);
 }

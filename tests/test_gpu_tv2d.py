@@ -37,7 +37,8 @@ def test_tv2d_matches_oracle(gpu, H, W, opts):
 
 
 @pytest.mark.parametrize("H,W,rho", [(8, 8, 1.0), (16, 64, 1.0), (64, 32, 2.5), (128, 256, 0.7), (32, 8, 1.0),
-                                     (512, 8, 1.0), (8, 1024, 1.3), (2048, 16, 1.0), (16, 4096, 0.5)])  # every radix plan
+                                     (512, 8, 1.0), (8, 1024, 1.3), (2048, 16, 1.0), (16, 4096, 0.5),
+                                     (8192, 8, 1.0), (8, 8192, 2.0)])  # every radix plan; 8192: 128 KB of LDS
 def test_tv2d_spectral_x_update(gpu, H, W, rho):
     """Power-of-two sides: (I + rho*D'D) is inverted through the 2-D DCT-II (dct.hip) -- against the oracle's
     sparse-direct solve, and against the engine's own CG path."""
