@@ -48,7 +48,7 @@ class ProblemDesc(C.Structure):
         ("device", C.c_int32), ("nslices", C.c_int32),
         ("slices", C.POINTER(C.c_int64)),
         ("comm", C.c_void_p),
-        ("cg_tol", C.c_double), ("cg_maxit", C.c_int32), ("reserved0", C.c_int32),
+        ("cg_tol", C.c_double), ("cg_maxit", C.c_int32), ("obj_gram", C.c_int32),
         ("Q", _dp), ("qz", _dp), ("D2", _dp), ("m2", C.c_int64), ("ldD2", C.c_int64), ("s2", _dp), ("c", _dp),
         ("K", _dp), ("k0", _dp),
     ]

@@ -415,6 +415,37 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
+          if (desc->obj_gram) {  // keep G = D'D (before the rho shift) in the symmetric kernel's tile-padded layout
+            e->planG = symv_plan(n);
+            e->ldG = e->planG.npad;
+            E_TRY(e->mem.alloc(&e->Gpad, static_cast<size_t>(e->ldG) * e->ldG));
+            E_HIP(hipMemsetAsync(e->Gpad, 0, sizeof(double) * e->ldG * e->ldG, e->stream));
+            E_HIP(hipMemcpy2DAsync(e->Gpad, e->ldG * sizeof(double), W, ld * sizeof(double), n * sizeof(double), n,
+                                   hipMemcpyDeviceToDevice, e->stream));
+            launch_symmetrize_lower(e->Gpad, n, e->ldG, e->stream);
+            E_TRY(e->mem.alloc(&e->gx, round_up(n, 2)));
+            E_TRY(e->mem.alloc(&e->negDts, round_up(n, 2)));
+            launch_combine(e->rhs_add, 1, 0, -1.0, nullptr, 0.0, nullptr, e->negDts, n, nullptr, e->stream);
+            if (n >= 1536) {
+              E_TRY(e->mem.alloc(&e->gN, e->planG.npart_elems()));
+              E_TRY(e->mem.alloc(&e->gT, e->planG.tpart_elems()));
+              E_HIP(hipMemsetAsync(e->gN, 0, sizeof(double) * e->planG.npart_elems(), e->stream));
+              E_HIP(hipMemsetAsync(e->gT, 0, sizeof(double) * e->planG.tpart_elems(), e->stream));
+            }
+            // 1/2*s's over all shards
+            std::vector<double> hs(static_cast<size_t>(m));
+            E_HIP(hipMemcpyAsync(hs.data(), e->s, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+            E_HIP(hipStreamSynchronize(e->stream));
+            double ssq = 0.0;
+            for (double v : hs) ssq += v * v;
+            if (sharded) {
+              E_HIP(hipMemcpyAsync(e->gx, &ssq, sizeof(double), hipMemcpyHostToDevice, e->stream));
+              E_TRY(comm_allreduce_device(e->comm, e->gx, 1, e->stream));
+              E_HIP(hipMemcpyAsync(&ssq, e->gx, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+              E_HIP(hipStreamSynchronize(e->stream));
+            }
+            e->half_ssq = 0.5 * ssq;
+          }
           launch_add_diag(W, n, ld, desc->rho, e->stream);
         } else {  // lasso.m:172  chol(1/rho*(D*D') + I)
           launch_gemm(0, 1, m, m, n, 1.0 / desc->rho, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);

@@ -117,6 +117,11 @@ struct admm_engine {
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix
   int64_t tv2_H = 0, tv2_W = 0;  // 2-D TV image shape
   Ctrl* ctrl_idle = nullptr;     // an all-zero control block for clean-up launches after the loop has stopped
+  // lasso objective through the Gram matrix (desc.obj_gram): tile-padded copy of D'D, -D's, G*x scratch, 1/2*s's
+  double *Gpad = nullptr, *negDts = nullptr, *gx = nullptr, *gN = nullptr, *gT = nullptr;
+  int64_t ldG = 0;
+  SymvPlan planG{};
+  double half_ssq = 0.0;
   bool tv2_dct = false;          // spectral (DCT) x-update instead of CG: both sides a power of two (dct.h)
   DctTables dctH{}, dctW{};
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)

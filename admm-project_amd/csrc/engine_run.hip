@@ -287,6 +287,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       case ADMM_PROB_LASSO:
         obj_lasso_gemv = true;
         fa.obj_scale_part = 0.5;
+        if (e->Gpad) {  // 1/2*x'Gx - x'D's + 1/2*s's  (desc.obj_gram)
+          fa.obj_scale_part = 1.0;
+          fa.obj_const = e->half_ssq;
+        }
         pa.objz = OBJZ_ABS;
         fa.obj_scale_z = e->lambda;
         break;
@@ -543,7 +547,15 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       }
       fa.objpart = nullptr;
       fa.nobjpart = 0;
-      if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
+      if (obj_lasso_gemv && e->Gpad) {  // the same number from the cached Gram matrix: one pass over its lower triangle
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob = 0;
+        if (e->gN) launch_symv_lower(e->planG, e->Gpad, e->ldG, e->x, e->gN, e->gT, e->gx, e->ctrl, e->stream);
+        else launch_symv_small(e->Gpad, e->n, e->ldG, e->x, e->gx, e->ctrl, e->stream);
+        launch_qp_objective(e->gx, 1, 0, e->x, e->negDts, e->n, e->objpart, &nob, e->ctrl, e->stream);
+        fa.objpart = e->objpart;
+        fa.nobjpart = nob;
+      } else if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
         TimerScope ts(e, ADMM_K_GEMV_N);
         int nob = 0;
         launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);

@@ -20,7 +20,7 @@ class Engine:
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
                  device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
-                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None):
+                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None, obj_gram=0):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -104,6 +104,7 @@ class Engine:
             d.cg_tol = float(cg_tol)
         if cg_maxit is not None:
             d.cg_maxit = int(cg_maxit)
+        d.obj_gram = int(bool(obj_gram))
         if slices is not None:
             sl = np.ascontiguousarray(np.asarray(slices, dtype=np.int64))
             keep.append(sl)

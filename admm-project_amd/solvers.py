@@ -38,7 +38,7 @@ def _colvec(s, name):
 
 
 def _engine_args(options, args):
-    for key in ("xsolve", "device", "comm", "cg_tol", "cg_maxit"):
+    for key in ("xsolve", "device", "comm", "cg_tol", "cg_maxit", "objgram"):
         if key in options:
             args[key] = options[key]
     return args

@@ -243,6 +243,18 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                           "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
     lad.close()
 
+    # objevals=1 with the objective taken from the cached Gram matrix (opt-in args.objgram): 4n^2 B instead of 8mn B
+    lg = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local, comm=comm,
+                   obj_gram=1)
+    kg = max(20, a.steps)
+    timed_run(lg, dist, 5, rho=rho, objevals=1)
+    dtg, _ = timed_run(lg, dist, kg, rho=rho, objevals=1)
+    out["objevals1_gram"] = {"iters_per_s": kg / dtg, "ms_per_step": dtg / kg * 1e3,
+                             "note": "objevals=1 with 1/2*||D*x - s||^2 = 1/2*x'Gx - x'D's + 1/2*s's from the cached "
+                                     "G = D'D (one more pass over an n x n lower triangle per iteration); opt-in: "
+                                     "absolute rounding error ~1e-16*||s||^2"}
+    lg.close()
+
     # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
     # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
     mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,

@@ -135,7 +135,10 @@ typedef struct admm_problem_desc {
   admm_comm* comm;     /* NULL = single device; else rows are sharded across the ranks */
   double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
   int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
-  int32_t reserved0;
+  int32_t obj_gram;    /* lasso, tall, factor built by the engine: 1 = evaluate the objective's 1/2*||D*x - s||^2 (lasso.m:227)
+                          as 1/2*x'Gx - x'D's + 1/2*s's with the cached Gram matrix G = D'D -- one pass over G's lower
+                          triangle (4n^2 B) instead of one over D (8mn B).  Absolute rounding error ~1e-16*||s||^2,
+                          i.e. relative error eps*||s||^2/objective: opt-in, 0 = the literal D*x form */
   /* ADMM_PROB_MODEL (getProxOps.m:83-89): P = args.PtP, q = args.Ptr above; and */
   const double* Q;     /* n x n: args.QtQ */
   const double* qz;    /* length n: args.Qts */

@@ -98,6 +98,21 @@ def test_total_variation_without_history(gpu, n, opts):
     np.testing.assert_allclose(got["xopt"], again["xopt"], rtol=0, atol=1e-13 * np.max(np.abs(again["xopt"])))
 
 
+@pytest.mark.parametrize("rows,cols,opts", [(256, 64, dict()), (2500, 1600, dict(maxiters=12, domaxiters=1)),
+                                            (700, 130, dict(rho=2.5, relax=1.4)), (400, 90, dict(fast=1, fasttype="strong", maxiters=40))])
+def test_lasso_objective_through_the_gram_matrix(gpu, rows, cols, opts):
+    """objgram=1 (engine-side option): 1/2*||D*x - s||^2 evaluated as 1/2*x'Gx - x'D's + 1/2*s's from the cached Gram
+    matrix -- same iterates, objective equal to the literal form up to eps*||s||^2."""
+    p = gpu.synth.lasso_problem(5, rows, cols)
+    o = dict(objevals=1, **opts)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, objgram=1, xsolve="inverse"))
+    ref = S.lasso(p["D"], p["s"], p["lam"], dict(o))
+    _compare(got, ref, keys=tuple(k for k in HIST if k != "objevals"))
+    bound = 1e-13 * float(p["s"] @ p["s"])
+    assert np.max(np.abs(got["objevals"] - ref["objevals"])) <= bound
+    assert abs(got["objopt"] - ref["objopt"]) <= bound
+
+
 @pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
 def test_lasso_fat(gpu, xsolve):
     p = gpu.synth.lasso_problem(1, 32, 256)
