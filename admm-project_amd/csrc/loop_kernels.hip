@@ -43,14 +43,30 @@ __device__ __forceinline__ void block_reduce_slots(double (&acc)[S_COUNT], doubl
 // u-update, fast-ADMM extrapolation, histories, the residual / objective partial sums and the next rhs.
 __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, double ax, int64_t it, double kcoef,
                                              double (&acc)[S_COUNT]) {
+  // Every input this element can need, loaded up front and unconditionally (operands a variant does not use are
+  // redirected to z: a cache hit): one memory round trip.  With the loads behind their (kernel-uniform) conditions
+  // hipcc waits for each one separately -- eight dependent L2 round trips, 9 us for a kernel with 2 us of work.
+  const double* puhat = (a.alg != 0) ? a.uhat : a.u;
+  const double* pc = a.c ? a.c : a.z;
+  // ell / lb / ub / zgiven / rhs_add are null unless this launch reads them (launch_prox clears the unused ones:
+  // some of them are shorter than len otherwise).  One null test per pointer: a compound condition here made hipcc
+  // (ROCm 7.2) drop one of its terms when it split the select across blocks.
+  const double* pell = a.ell ? a.ell : a.z;
+  const double* pzg = a.zgiven ? a.zgiven : a.z;
+  const double* plb = a.lb ? a.lb : a.z;
+  const double* pub = a.ub ? a.ub : a.z;
+  const double* pv = (a.alg == 2) ? a.v : a.z;
+  const double* padd = a.rhs_add ? a.rhs_add : a.z;
+  const double zp = a.z[i];
+  const double u_old = a.u[i];
+  const double uhat_i = puhat[i], c_i = pc[i], ell_i = pell[i], zg_i = pzg[i], lb_i = plb[i], ub_i = pub[i];
+  const double v_i = pv[i], add_i = padd[i];
   if (a.a_identity) {
     if (a.x_out) a.x_out[i] = ax;
     if (a.xhist) a.xhist[it * a.len + i] = ax;
   }
-  const double zp = a.z[i];
-  const double u_old = a.u[i];
-  const double uo = (a.alg == 0) ? u_old : a.uhat[i];
-  const double ci = a.c ? a.c[i] : 0.0;
+  const double uo = (a.alg == 0) ? u_old : uhat_i;
+  const double ci = a.c ? c_i : 0.0;
   // admm.m:517  Axhat = relax*A(x) - (1-relax)*(B(zprev) - c),  B = -1
   const double axh = (a.relax != 1.0) ? a.relax * ax - (1.0 - a.relax) * ((-zp) - ci) : ax;
   const double v = (axh + uo) - ci;
@@ -63,26 +79,26 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
       zn = 1.0 / (1.0 + a.rho) * (a.rho * v + soft(v, 1.0 + 1.0 / a.rho));
       break;
     case PROX_HINGE: {
-      const double l = a.ell[i];
+      const double l = ell_i;
       const double lv = l * v;
       zn = v + l * fmax(fmin(1.0 - lv, a.t), 0.0);
       break;
     }
     case PROX_01: {
-      const double l = a.ell[i];
+      const double l = ell_i;
       const double s = l * v;
       const double y = ((s >= 1.0) || (s < (1.0 - sqrt(2.0 / a.t)))) ? s : 1.0;
       zn = l * y;
       break;
     }
     case PROX_GIVEN:
-      zn = a.zgiven[i];
+      zn = zg_i;
       break;
     case PROX_POS:
       zn = fmax(v, 0.0);
       break;
     default:  // PROX_BOX
-      zn = fmin(a.ub[i], fmax(a.lb[i], v));
+      zn = fmin(ub_i, fmax(lb_i, v));
       break;
   }
   const double Bz = -zn;
@@ -98,12 +114,12 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
   acc[S_DU2] += du * du;
   if (a.objz == OBJZ_ABS) acc[S_OBJZ] += fabs(zn);
   else if (a.objz == OBJZ_HUBER) acc[S_OBJZ] += huber_cvx(zn);
-  if (a.objx == OBJX_HINGE) acc[S_OBJX] += fmax(1.0 - a.ell[i] * ax, 0.0);
+  if (a.objx == OBJX_HINGE) acc[S_OBJX] += fmax(1.0 - ell_i * ax, 0.0);
   else if (a.objx == OBJX_ZEROONE) {
-    const double q = 1.0 - a.ell[i] * ax;
+    const double q = 1.0 - ell_i * ax;
     acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
   } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
-  else if (a.objx == OBJX_DOT) acc[S_OBJX] += a.ell[i] * ax;
+  else if (a.objx == OBJX_DOT) acc[S_OBJX] += ell_i * ax;
 
   a.z[i] = zn;
   a.u[i] = un;
@@ -120,7 +136,7 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
     if (a.vhist) a.vhist[it * a.len + i] = zx;
     if (a.uhathist) a.uhathist[it * a.len + i] = ux;
   } else if (a.alg == 2) {  // decision needs d first: keep what the extrapolation kernel needs
-    const double vo = a.v[i];
+    const double vo = v_i;
     const double duh = un - uo, dzv2 = zn - vo;
     acc[S_DUH2] += duh * duh;
     acc[S_DZV2] += dzv2 * dzv2;
@@ -130,10 +146,10 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
   if (a.alg != 2 && a.rhs) {
     switch (a.rhs_kind) {
       case RHS_RHO_DTS:
-        a.rhs[i] = a.rho * (zx - ux) + a.rhs_add[i];
+        a.rhs[i] = a.rho * (zx - ux) + add_i;
         break;
       case RHS_RHO_MINUS_Q:
-        a.rhs[i] = a.rho * (zx - ux) - a.rhs_add[i];
+        a.rhs[i] = a.rho * (zx - ux) - add_i;
         break;
       case RHS_DIFF:
         a.rhs[i] = zx - ux;
@@ -147,25 +163,36 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
   }
 }
 
-__device__ __forceinline__ double prox_kcoef(const ProxArgs& a, const Ctrl* ctrl) {
-  if (a.alg != 1) return 0.0;
-  // admm.m:504, 567: aprev = acurr; acurr = (1+sqrt(1+4 aprev^2))/2
-  const double aprev = ctrl->acurr;
-  const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
-  return (aprev - 1.0) / acn;
+// sum of the chunk partials of A*x for element i, in chunk order; four loads in flight at a time
+__device__ __forceinline__ double gather_ax(const double* __restrict__ src, int32_t nchunk, int64_t ld, int64_t i) {
+  double ax = 0.0;
+  int32_t c = 0;
+  for (; c + 4 <= nchunk; c += 4) {
+    const double p0 = src[static_cast<int64_t>(c) * ld + i], p1 = src[static_cast<int64_t>(c + 1) * ld + i];
+    const double p2 = src[static_cast<int64_t>(c + 2) * ld + i], p3 = src[static_cast<int64_t>(c + 3) * ld + i];
+    ax = (((ax + p0) + p1) + p2) + p3;
+  }
+  for (; c < nchunk; ++c) ax += src[static_cast<int64_t>(c) * ld + i];
+  return ax;
 }
 
 __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
+  // the three control words in one scalar round trip, before the branch
+  const int32_t stop = ctrl->stop;
   const int64_t it = ctrl->iter;
+  const double aprev = ctrl->acurr;
+  if (stop) return;
   double acc[S_COUNT];
 #pragma unroll
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-  const double kcoef = prox_kcoef(a, ctrl);
+  double kcoef = 0.0;
+  if (a.alg == 1) {  // admm.m:504, 567: aprev = acurr; acurr = (1+sqrt(1+4 aprev^2))/2
+    const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+    kcoef = (aprev - 1.0) / acn;
+  }
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double ax = 0.0;
-    for (int32_t cidx = 0; cidx < a.naxpart; ++cidx) ax += a.axsrc[static_cast<int64_t>(cidx) * a.axld + i];
+    const double ax = gather_ax(a.axsrc, a.naxpart, a.axld, i);
     prox_element(a, i, ax, it, kcoef, acc);
   }
   block_reduce_slots(acc, a.part);
@@ -198,7 +225,15 @@ void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream) {
   hipLaunchKernelGGL(prez_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
 }
 
-void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+void launch_prox(const ProxArgs& args, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  ProxArgs a = args;  // operands this variant does not read -> null (the kernel loads every non-null one up front)
+  const bool need_ell = a.prox == PROX_HINGE || a.prox == PROX_01 || a.objx == OBJX_HINGE ||
+                        a.objx == OBJX_ZEROONE || a.objx == OBJX_DOT;
+  if (!need_ell) a.ell = nullptr;
+  if (a.prox != PROX_GIVEN) a.zgiven = nullptr;
+  if (a.prox != PROX_BOX) a.lb = a.ub = nullptr;
+  const bool need_add = a.alg != 2 && a.rhs && (a.rhs_kind == RHS_RHO_DTS || a.rhs_kind == RHS_RHO_MINUS_Q);
+  if (!need_add) a.rhs_add = nullptr;
   int64_t blocks = ceil_div(a.len, kBlock);
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
   if (blocks < 1) blocks = 1;
