@@ -7,7 +7,8 @@
 // (32 KiB) and then streams its share of the off-diagonal panel from HBM with coalesced
 // loads -- forward: rows below the block (column-major => lanes along rows); backward:
 // columns left of the block (lanes along the 64 contiguous rows of each column, shuffle
-// reduce).  No inter-workgroup communication inside a launch.
+// reduce).  No inter-workgroup communication inside a launch.  Every thread issues all of its loads before it
+// uses any (clamped addresses instead of branches around loads): 16.5 -> 8 us per step at n = 10^4.
 #include "kernels.h"
 
 namespace admm {
@@ -19,10 +20,20 @@ constexpr int TB = 64;  // diagonal block size (matches dense.hip NB)
 __device__ __forceinline__ void diag_apply_fwd(const double* __restrict__ dinv, const double* __restrict__ y,
                                                int64_t k0, int nb, double* sw, double* spart) {
   const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
+  // all 16 + 16 loads first (clamped, unconditional: a branch around a load makes hipcc wait for it separately),
+  // then the conditional accumulation in the original order
+  double dv[16], yv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = part * 16 + t;
+    dv[t] = dinv[i + c * TB];
+    yv[t] = y[k0 + (c < nb ? c : nb - 1)];
+  }
   double s = 0.0;
-#pragma unroll 4
-  for (int c = part * 16; c < part * 16 + 16; ++c) {
-    if (c < nb && c <= i) s = __builtin_fma(dinv[i + c * TB], y[k0 + c], s);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = part * 16 + t;
+    if (c < nb && c <= i) s = __builtin_fma(dv[t], yv[t], s);
   }
   spart[part * TB + i] = s;
   __syncthreads();
@@ -34,10 +45,18 @@ __device__ __forceinline__ void diag_apply_fwd(const double* __restrict__ dinv, 
 __device__ __forceinline__ void diag_apply_bwd(const double* __restrict__ dinv, const double* __restrict__ w,
                                                int64_t k0, int nb, double* sx, double* spart) {
   const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  double dv[16], wv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = part * 16 + t;
+    dv[t] = dinv[i + c * TB];
+    wv[t] = w[k0 + (i < nb ? i : nb - 1)];
+  }
   double s = 0.0;
-#pragma unroll 4
-  for (int i = part * 16; i < part * 16 + 16; ++i) {
-    if (i < nb && i >= c) s = __builtin_fma(dinv[i + c * TB], w[k0 + i], s);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = part * 16 + t;
+    if (i < nb && i >= c) s = __builtin_fma(dv[t], wv[t], s);
   }
   spart[part * TB + c] = s;
   __syncthreads();
@@ -55,20 +74,27 @@ __global__ __launch_bounds__(kBlock) void trsv_fwd_step_kernel(const double* __r
   __shared__ double spart[4 * TB];
   diag_apply_fwd(dinv, y, k0, nb, sw, spart);
   if (blockIdx.x == 0 && threadIdx.x < nb) wout[k0 + threadIdx.x] = sw[threadIdx.x];
-  const int64_t i = k0 + nb + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) {
-    const double* p = L + i + k0 * ld;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int c = 0;
-    for (; c + 4 <= nb; c += 4) {
-      s0 = __builtin_fma(p[(c + 0) * ld], sw[c + 0], s0);
-      s1 = __builtin_fma(p[(c + 1) * ld], sw[c + 1], s1);
-      s2 = __builtin_fma(p[(c + 2) * ld], sw[c + 2], s2);
-      s3 = __builtin_fma(p[(c + 3) * ld], sw[c + 3], s3);
-    }
-    for (; c < nb; ++c) s0 = __builtin_fma(p[c * ld], sw[c], s0);
-    y[i] -= (s0 + s1) + (s2 + s3);
+  // panel update: 64 rows per workgroup, the 64 columns split over the four waves (16 independent loads per thread,
+  // all in flight together; lanes along rows -> 512-byte contiguous segments per column)
+  const int r = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = k0 + nb + static_cast<int64_t>(blockIdx.x) * 64 + r;
+  const int64_t ic = i < n ? i : n - 1;  // clamped: loads stay unconditional
+  const double* p = L + ic + (k0 + grp * 16) * ld;
+  double v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) v[t] = (grp * 16 + t < nb) ? p[t * ld] : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int t = 0; t < 16; t += 4) {
+    s0 = __builtin_fma(v[t + 0], sw[grp * 16 + t + 0], s0);
+    s1 = __builtin_fma(v[t + 1], sw[grp * 16 + t + 1], s1);
+    s2 = __builtin_fma(v[t + 2], sw[grp * 16 + t + 2], s2);
+    s3 = __builtin_fma(v[t + 3], sw[grp * 16 + t + 3], s3);
   }
+  __syncthreads();  // spart is reused below
+  spart[grp * TB + r] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < n) y[i] -= ((spart[r] + spart[TB + r]) + spart[2 * TB + r]) + spart[3 * TB + r];
 }
 
 // Backward step k: x[k0:k0+nb] = x_k; w[j] -= L[k0:k0+nb, j]' * x_k for j < k0.
@@ -86,20 +112,28 @@ __global__ __launch_bounds__(kBlock) void trsv_bwd_step_kernel(const double* __r
   const int cslot = threadIdx.x >> 5;       // 0..7
   const int r = 2 * half;
   const double x0 = (r < nb) ? sx[r] : 0.0, x1 = (r + 1 < nb) ? sx[r + 1] : 0.0;
+  if (k0 == 0) return;  // first block: nothing to its left (and for n < 64 no 64-row panel to read)
   const int64_t jbase = static_cast<int64_t>(blockIdx.x) * 64;
-#pragma unroll 2
-  for (int pass = 0; pass < 8; ++pass) {
+  double sv[8];
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {  // the eight 16-byte loads of a thread first, all in flight together
     const int64_t j = jbase + pass * 8 + cslot;
+    const int64_t jc = j < k0 ? j : k0 - 1;  // clamped column: the load stays unconditional
+    // rows k0+r, k0+r+1 may run past n in the last (partial) block: still inside the allocation (they land in
+    // column jc+1 <= k0 <= n-1) and masked below
+    const double* p = L + k0 + r + jc * ld;
+    const double2_t d = *reinterpret_cast<const double2_t*>(p);
     double s = 0.0;
     if (j < k0) {
-      const double* p = L + k0 + r + j * ld;
-      if (r + 1 < nb) {
-        const double2_t d = *reinterpret_cast<const double2_t*>(p);
-        s = d.x * x0 + d.y * x1;
-      } else if (r < nb) {
-        s = p[0] * x0;
-      }
+      if (r + 1 < nb) s = d.x * x0 + d.y * x1;
+      else if (r < nb) s = d.x * x0;
     }
+    sv[pass] = s;
+  }
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int64_t j = jbase + pass * 8 + cslot;
+    double s = sv[pass];
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (half == 0 && j < k0) w[j] -= s;
@@ -136,7 +170,7 @@ void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, double* wor
     const int64_t k0 = k * TB;
     const int nb = static_cast<int>((n - k0 < TB) ? n - k0 : TB);
     const int64_t rows = n - k0 - nb;
-    const unsigned blocks = static_cast<unsigned>(rows > 0 ? ceil_div(rows, kBlock) : 1);
+    const unsigned blocks = static_cast<unsigned>(rows > 0 ? ceil_div(rows, 64) : 1);
     hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks), dim3(kBlock), 0, stream, p.L, p.ldl, n, k0, nb,
                        p.dinv + k * TB * TB, yy, w, ctrl);
   }
