@@ -255,6 +255,19 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                                      "absolute rounding error ~1e-16*||s||^2"}
     lg.close()
 
+    # the same loop with the factor applied literally (two triangular solves, the reference's form): a chain of
+    # 2*n/64 dependent block steps -- latency-bound, the reason xsolve=inverse exists
+    if world == 1:
+        lt = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_TRSV, device=local)
+        kt = max(10, a.steps // 4)
+        timed_run(lt, dist, 3, rho=rho)
+        dtt, _ = timed_run(lt, dist, kt, rho=rho)
+        out["xsolve_trsv"] = {"iters_per_s": kt / dtt, "ms_per_step": dtt / kt * 1e3,
+                              "algorithmic_GB_per_iter": 8.0 * n * (n + 1) / 1e9,
+                              "frac": 8.0 * n * (n + 1) * kt / dtt / 1e9 / HBM_PEAK_GBS,
+                              "note": "x = L'\\(L\\y) as getProxOps.m:1200 writes it; same iterates as the headline"}
+        lt.close()
+
     # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
     # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
     mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
