@@ -338,7 +338,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (!(desc->rho > 0.0)) return bail(fail(ADMM_E_INVALID, "rho must be a positive real (lasso.m:138)"));
 
   int xs = desc->xsolve;
-  // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, 2.6 ms at n = 10^4);
+  // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, 2.0 ms at n = 10^4);
   // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
   if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
   if (xs == ADMM_XSOLVE_CALLBACK && desc->problem != ADMM_PROB_LAD)
