@@ -19,8 +19,7 @@ __global__ __launch_bounds__(kBlock) void cg_q_kernel(CgArgs a, const double* __
   double acc = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.n;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double s = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) s += qin[static_cast<int64_t>(c) * ldq + i];
+    double s = gather_chunks(qin, nchunk, ldq, i);
     const double pv = a.p[i];
     const double qv = s + a.shift * pv;
     a.q[i] = qv;

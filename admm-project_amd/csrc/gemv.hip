@@ -109,9 +109,7 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
   if (ctrl && ctrl->stop) return;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double s = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) s += part[static_cast<int64_t>(c) * ld + i];
-    y[i] = s;
+    y[i] = gather_chunks(part, nchunk, ld, i);
   }
 }
 

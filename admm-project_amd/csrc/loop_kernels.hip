@@ -163,19 +163,6 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
   }
 }
 
-// sum of the chunk partials of A*x for element i, in chunk order; four loads in flight at a time
-__device__ __forceinline__ double gather_ax(const double* __restrict__ src, int32_t nchunk, int64_t ld, int64_t i) {
-  double ax = 0.0;
-  int32_t c = 0;
-  for (; c + 4 <= nchunk; c += 4) {
-    const double p0 = src[static_cast<int64_t>(c) * ld + i], p1 = src[static_cast<int64_t>(c + 1) * ld + i];
-    const double p2 = src[static_cast<int64_t>(c + 2) * ld + i], p3 = src[static_cast<int64_t>(c + 3) * ld + i];
-    ax = (((ax + p0) + p1) + p2) + p3;
-  }
-  for (; c < nchunk; ++c) ax += src[static_cast<int64_t>(c) * ld + i];
-  return ax;
-}
-
 __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __restrict__ ctrl) {
   // the three control words in one scalar round trip, before the branch
   const int32_t stop = ctrl->stop;
@@ -192,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
   }
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const double ax = gather_ax(a.axsrc, a.naxpart, a.axld, i);
+    const double ax = gather_chunks(a.axsrc, a.naxpart, a.axld, i);
     prox_element(a, i, ax, it, kcoef, acc);
   }
   block_reduce_slots(acc, a.part);
@@ -207,8 +194,7 @@ __global__ __launch_bounds__(kBlock) void prez_kernel(PreZArgs a, const Ctrl* __
   if (ctrl->stop) return;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double ax = 0.0;
-    for (int32_t cidx = 0; cidx < a.naxpart; ++cidx) ax += a.axsrc[static_cast<int64_t>(cidx) * a.axld + i];
+    const double ax = gather_chunks(a.axsrc, a.naxpart, a.axld, i);
     const double zp = a.z[i];
     const double ci = a.c ? a.c[i] : 0.0;
     // same expression as prox_kernel, so the split update is bit-identical to the fused one
@@ -525,8 +511,7 @@ __global__ __launch_bounds__(kBlock) void residual_sq_kernel(const double* __res
   double acc = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double y = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) y += part[static_cast<int64_t>(c) * ld + i];
+    const double y = gather_chunks(part, nchunk, ld, i);
     const double r = y - s[i];
     acc += r * r;
   }
@@ -554,8 +539,7 @@ __global__ __launch_bounds__(kBlock) void qp_objective_kernel(const double* __re
   double acc = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double y = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) y += part[static_cast<int64_t>(c) * ld + i];
+    const double y = gather_chunks(part, nchunk, ld, i);
     acc += x[i] * (0.5 * y + q[i]);
   }
   const double t = block_sum(acc, scratch);
@@ -579,8 +563,7 @@ __global__ __launch_bounds__(kBlock) void combine_kernel(const double* __restric
   if (ctrl && ctrl->stop) return;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    double s = 0.0;
-    for (int32_t c = 0; c < nchunk; ++c) s += part[static_cast<int64_t>(c) * ld + i];
+    double s = gather_chunks(part, nchunk, ld, i);
     double v = alpha * s;
     if (y) v += beta * y[i];
     if (add) v += add[i];
