@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
 // (A variant of this kernel that gathered x_i straight from symv_lower_kernel's partial sums -- 16 elements x 16
 // slots per workgroup, saving the symv_reduce launch -- was measured SLOWER on the headline loop: 10.29k vs
 // 11.55k it/s.  625 workgroups instead of 40 make the 12-slot block reductions and the finalize kernel's
-// partial sums cost more than the launch they save.)
+// partial sums cost more than the launch they save.  Re-measured after the finalize kernel's partial loads were
+// unrolled and the prox loads batched: still 10.24k against 10.32k it/s on the same box -- the two-kernel form stays.)
 
 __global__ __launch_bounds__(kBlock) void prez_kernel(PreZArgs a, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
