@@ -15,7 +15,7 @@ struct SliceFactor {
   int64_t ldM = 0;
   SymvPlan planSy{};        // lower-triangle application for n >= 1536, one wave per column below
   TrsvPlan trsv{};
-  double* work = nullptr;
+  double* work = nullptr;   // device storage of the blocked-substitution plan (xsolve = trsv)
   GemvTPlan plan{};
   double* part = nullptr;
 };

@@ -442,8 +442,8 @@ __global__ __launch_bounds__(kBlock) void zero_scratch_kernel(double* __restrict
 }
 
 int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double* dinv, double* X, int64_t ldx,
-                          hipStream_t stream) {
-  ADMM_HIP_TRY(hipMemsetAsync(X, 0, sizeof(double) * static_cast<size_t>(ldx) * n, stream));
+                          hipStream_t stream, bool clear) {
+  if (clear) ADMM_HIP_TRY(hipMemsetAsync(X, 0, sizeof(double) * static_cast<size_t>(ldx) * n, stream));
   hipLaunchKernelGGL(scatter_diag_inv_kernel, dim3(static_cast<unsigned>(ceil_div(n, NB))), dim3(kBlock), 0, stream,
                      dinv, n, X, ldx);
   for (int64_t b = NB; b < n; b *= 2) {

@@ -151,9 +151,8 @@ int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* L
       }
     }
   } else {
-    double* dv = e->dinv;
-    ADMM_TRY(trsv_build(W, nF, ld, &dv, &e->trsv, e->stream));
-    ADMM_TRY(e->mem.alloc(&e->trsv_work, trsv_workspace_elems(e->trsv)));
+    ADMM_TRY(e->mem.alloc(&e->trsv_buf, trsv_plan_elems(nF)));
+    ADMM_TRY(trsv_build(W, nF, ld, e->dinv, e->trsv_buf, &e->trsv, e->stream));
   }
   return ADMM_OK;
 }
@@ -178,7 +177,7 @@ int solve_factor(admm_engine* e, const double* y, double* out) {
   } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
     launch_symv_small(e->Minv, e->nF, e->ldMinv, y, out, e->ctrl, e->stream);
   } else {
-    launch_trsv_pair(e->trsv, y, out, e->trsv_work, e->ctrl, e->stream);
+    launch_trsv_pair(e->trsv, y, out, e->ctrl, e->stream);
   }
   return ADMM_OK;
 }
@@ -220,9 +219,8 @@ int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int
       ADMM_TRY(e->mem.alloc(&e->syT, f.planSy.tpart_elems()));
     }
   } else {
-    double* dv = f.dinv;
-    ADMM_TRY(trsv_build(W, n, ld, &dv, &f.trsv, e->stream));
-    ADMM_TRY(e->mem.alloc(&f.work, trsv_workspace_elems(f.trsv)));
+    ADMM_TRY(e->mem.alloc(&f.work, trsv_plan_elems(n)));
+    ADMM_TRY(trsv_build(W, n, ld, f.dinv, f.work, &f.trsv, e->stream));
   }
   return ADMM_OK;
 }
@@ -232,7 +230,7 @@ void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, d
     if (f.n >= 1536) launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream);
     else launch_symv_small(f.Minv, f.n, f.ldM, y, out, e->ctrl, e->stream);
   } else {
-    launch_trsv_pair(f.trsv, y, out, f.work, e->ctrl, e->stream);
+    launch_trsv_pair(f.trsv, y, out, e->ctrl, e->stream);
   }
 }
 

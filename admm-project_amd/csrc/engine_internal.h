@@ -97,7 +97,7 @@ struct admm_engine {
   double* Minv = nullptr;  // explicit inverse (symmetric, full), ld = ldMinv (tile-padded, zeros outside)
   int64_t ldMinv = 0;
   TrsvPlan trsv{};
-  double* trsv_work = nullptr;
+  double* trsv_buf = nullptr;  // device storage of the blocked-substitution plan (trsv_plan_elems)
 
   // GEMV plans + partial buffers
   GemvNPlan planDN{};   // D*x

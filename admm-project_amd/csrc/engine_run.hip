@@ -157,7 +157,7 @@ static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpar
   } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
     launch_symv_small(e->Minv, e->nF, e->ldMinv, e->rhs, e->x, e->ctrl, e->stream);
   } else {
-    launch_trsv_pair(e->trsv, e->rhs, e->x, e->trsv_work, e->ctrl, e->stream);
+    launch_trsv_pair(e->trsv, e->rhs, e->x, e->ctrl, e->stream);
   }
   return ADMM_OK;
 }

@@ -66,25 +66,32 @@ int cholesky_lower(double* A, int64_t n, int64_t lda, int32_t* info_dev, double*
 // invert the 64x64 diagonal blocks of an existing lower factor
 void launch_trtri_diag(const double* L, int64_t n, int64_t ldl, double* dinv, hipStream_t stream);
 // X = inv(L) (lower, upper part zero) from L and its inverted diagonal blocks
+// clear = false: X (lower block and its upper-right scratch) is already zero
 int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double* dinv, double* X, int64_t ldx,
-                          hipStream_t stream);
+                          hipStream_t stream, bool clear = true);
 // mirror the lower triangle into the upper one
 void launch_symmetrize_lower(double* A, int64_t n, int64_t lda, hipStream_t stream);
 void launch_add_diag(double* A, int64_t n, int64_t lda, double shift, hipStream_t stream);
 void launch_fill(double* p, size_t n, double v, hipStream_t stream);
 
 // ---------------------------------------------------------------- TRSV (trsv.hip)
-// x = L' \ (L \ y) with pre-inverted diagonal blocks.  Workspace sized by trsv_workspace_elems.
+// x = L' \ (L \ y) as blocked substitution over K coarse blocks whose diagonal-block inverses are folded
+// into the panels (one bandwidth-bound launch per block and sweep).
 struct TrsvPlan {
-  int64_t n, ldl;
-  int32_t nb;              // diagonal block size
-  int32_t nblk;
-  const double* L;
-  const double* dinv;      // [nblk][nb*nb] inverted diagonal blocks (lower, column-major, ld = nb)
+  int64_t n, npad;
+  int64_t ldm, ldp;
+  int32_t ntile, nblk, bt;   // 128-row tiles, coarse blocks, tiles per block
+  double* Fm;                // forward panels  [inv(L_kk); -L_below,k inv(L_kk)]   (lower, npad x npad)
+  double* Um;                // backward panels [-L_k,above' inv(L_kk)'; inv(L_kk)'] (upper, npad x npad)
+  double* P[2];              // [bt][npad] column-tile partials: the step in flight and the previous one
+  double *v, *w;             // running right-hand sides (npad)
+  bool streaming;            // non-temporal matrix loads (matrix larger than the caches)
 };
-int trsv_build(const double* L, int64_t n, int64_t ldl, double** dinv_out, TrsvPlan* plan, hipStream_t stream);
-void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, double* work, const Ctrl* ctrl,
-                      hipStream_t stream);
-size_t trsv_workspace_elems(const TrsvPlan& p);
+// doubles the plan needs in one caller-owned device buffer
+size_t trsv_plan_elems(int64_t n);
+// dinv64: the inverted 64x64 diagonal blocks of L (cholesky_lower / launch_trtri_diag)
+int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
+               hipStream_t stream);
+void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream);
 
 }  // namespace admm

@@ -131,18 +131,18 @@ int admm_op_trsv_pair(const double* L, int64_t n, int64_t ldL, const double* y, 
   if (!L || !y || !x || n <= 0 || ldL < n) return fail(ADMM_E_INVALID, "trsv_pair: bad argument");
   ADMM_TRY(need_device());
   Scratch sc;
-  double *dL, *dy, *dx, *work;
+  double *dL, *dy, *dx, *dinv, *buf;
   int64_t ld;
   ADMM_TRY(put_matrix(sc, &dL, &ld, L, n, n, ldL));
   ADMM_TRY(sc.alloc(&dy, round_up(n, 2)));
   ADMM_TRY(sc.alloc(&dx, round_up(n, 2)));
   ADMM_HIP_TRY(hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
   TrsvPlan plan{};
-  double* dinv = nullptr;
-  ADMM_TRY(trsv_build(dL, n, ld, &dinv, &plan, nullptr));
-  sc.ptrs.push_back(dinv);
-  ADMM_TRY(sc.alloc(&work, trsv_workspace_elems(plan)));
-  launch_trsv_pair(plan, dy, dx, work, nullptr, nullptr);
+  ADMM_TRY(sc.alloc(&dinv, static_cast<size_t>(ceil_div(n, 64)) * 64 * 64));
+  launch_trtri_diag(dL, n, ld, dinv, nullptr);
+  ADMM_TRY(sc.alloc(&buf, trsv_plan_elems(n)));
+  ADMM_TRY(trsv_build(dL, n, ld, dinv, buf, &plan, nullptr));
+  launch_trsv_pair(plan, dy, dx, nullptr, nullptr);
   ADMM_HIP_TRY(hipDeviceSynchronize());
   ADMM_HIP_TRY(hipMemcpy(x, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
   return ADMM_OK;

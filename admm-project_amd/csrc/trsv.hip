@@ -1,201 +1,380 @@
 // trsv.hip -- x = L' \ (L \ y): the cached-factor x-update (getProxOps.m:1200 `U \ (L \ y)`,
-// 1514 `Rt \ (R \ .)`, 1455, 1247) on a dense lower Cholesky factor.
+// 1514 `Rt \ (R \ .)`, 1455, 1247) on a dense lower Cholesky factor, as blocked substitution.
 //
-// v1 structure: blocked substitution with pre-inverted 64x64 diagonal blocks (so each
-// diagonal step is a tiny GEMV, no in-kernel dependency chain).  One launch per block
-// column and sweep: every workgroup recomputes the 64-vector of the current block from L2
-// (32 KiB) and then streams its share of the off-diagonal panel from HBM with coalesced
-// loads -- forward: rows below the block (column-major => lanes along rows); backward:
-// columns left of the block (lanes along the 64 contiguous rows of each column, shuffle
-// reduce).  No inter-workgroup communication inside a launch.  Every thread issues all of its loads before it
-// uses any (clamped addresses instead of branches around loads): panel loads ahead of the diagonal step: 16.5 -> 6.4 us per step at n = 10^4.
+// A triangular solve is a dependent chain; what bounds it on this part is the number of dependent steps, not
+// bytes (round 1: 2*n/64 launches of 6 us = 0.05 of the HBM roofline).  So the chain is cut into K COARSE blocks
+// (10 tiles of 128 = 1280 rows; K = 8 at n = 10^4) and each step is one bandwidth-bound launch:
+//
+//   forward  step k:  w_k = inv(L_kk) y_k ;   y_below -= L_below,k w_k
+//   backward step k:  x_k = inv(L_kk)' w_k ;  w_above -= L_k,above' x_k
+//
+// With the diagonal-block inverse folded into its panel at build time (a block Gauss transform),
+//   Fm[:, block k] = [ inv(L_kk) ; -L_below,k inv(L_kk) ]      (lower, block column k)
+//   Um[:, block k] = [ -L_k,above' inv(L_kk)' ; inv(L_kk)' ]   (upper, block column k)
+// a step is ONE column-panel GEMV  out = M[:, block k] * in_k  whose result rows inside the block are the
+// solution block and whose other rows are added to the running right-hand side.  Both sweeps use the same
+// kernel: lanes along rows (column-major => 16-byte coalesced non-temporal loads), register accumulation per
+// row, one-wave workgroups on 128 x W tiles (W chosen per step so that the grid keeps >= ~1500 waves).  The
+// W-column partial sums of a row tile are combined by the LAST wave to arrive (sc1 write-through partials,
+// s_waitcnt, one agent-scope counter add; the wave whose add came last sums all partials in fixed order):
+// deterministic, no float atomics, no separate reduce launch.  2K launches per solve pair; the explicit
+// inverses are only of the K diagonal blocks (forward error eps*cond(L_kk), like any blocked TRSV with
+// pre-inverted diagonal blocks), so this is the numerically safe fallback of the `inverse` form.
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace admm {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
-constexpr int TB = 64;  // diagonal block size (matches dense.hip NB)
+constexpr int kTsTile = 128;   // rows per wave = tile granularity of the blocks
+constexpr int kTsPanel = 8;    // columns per load group
+constexpr int kTsBlockTiles = 10;
 
-// w_k = inv(L_kk) * y[k0:k0+nb] into LDS sw[TB]; all 256 threads cooperate.
-__device__ __forceinline__ void diag_apply_fwd(const double* __restrict__ dinv, const double* __restrict__ y,
-                                               int64_t k0, int nb, double* sw, double* spart) {
-  const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
-  // all 16 + 16 loads first (clamped, unconditional: a branch around a load makes hipcc wait for it separately),
-  // then the conditional accumulation in the original order
-  double dv[16], yv[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int c = part * 16 + t;
-    dv[t] = dinv[i + c * TB];
-    yv[t] = y[k0 + (c < nb ? c : nb - 1)];
+struct TriStepArgs {
+  const double* M;         // Fm or Um (npad x npad, ld)
+  int64_t ld;
+  int64_t n;               // valid length of the vectors (caller vectors are not padded)
+  const double* base_in;   // running right-hand side: rows outside the diagonal block carry base + partial sums
+  double* base_out;
+  double* diag_out;        // where the PREVIOUS step's solution block is written (w forward, x backward)
+  const double* Pprev;     // [tiles of the previous block][ldp] column-tile partials of the previous step
+  double* Pcur;            // same for this step
+  int64_t ldp;
+  int32_t dt0, dt1;        // this step's diagonal block = its columns (tile range)
+  int32_t rt0, rt1;        // this step's panel rows (tile range)
+  int32_t upper;           // 0 = forward sweep on Fm (lower), 1 = backward sweep on Um (upper)
+  int32_t pd0, pd1;        // previous step: diagonal block,
+  int32_t pr0, pr1;        //                panel rows (tiles that have partials; empty range = none),
+  int32_t pupper;          //                orientation
+  int32_t x_use_base;      // the input block is base_in + partial sums (0: partial sums only)
+  int32_t ext0, ext1;      // row tiles of the previous solution block to write to diag_out (grid rows beyond the panel)
+  const Ctrl* ctrl;
+};
+
+// partial-sum range of row tile T in the previous step
+__device__ __forceinline__ void ts_prev_range(const TriStepArgs& a, int32_t T, int32_t& q0, int32_t& q1) {
+  q0 = 0;
+  q1 = 0;
+  if (T < a.pr0 || T >= a.pr1) return;
+  q1 = a.pd1 - a.pd0;
+  if (T >= a.pd0 && T < a.pd1) {  // triangular diagonal block: only the tiles that exist
+    if (!a.pupper) q1 = T - a.pd0 + 1;
+    else q0 = T - a.pd0;
   }
-  double s = 0.0;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int c = part * 16 + t;
-    if (c < nb && c <= i) s = __builtin_fma(dv[t], yv[t], s);
-  }
-  spart[part * TB + i] = s;
-  __syncthreads();
-  if (threadIdx.x < TB) sw[i] = spart[i] + spart[TB + i] + spart[2 * TB + i] + spart[3 * TB + i];
-  __syncthreads();
 }
 
-// x_k = inv(L_kk)' * w[k0:k0+nb]
-__device__ __forceinline__ void diag_apply_bwd(const double* __restrict__ dinv, const double* __restrict__ w,
-                                               int64_t k0, int nb, double* sx, double* spart) {
-  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  double dv[16], wv[16];
+// sum over the previous step's partials of the element pair at index e (fixed order; all loads of a group of
+// eight issued together)
+__device__ __forceinline__ double2_t ts_sum_prev(const TriStepArgs& a, int32_t q0, int32_t q1, int64_t e) {
+  double2_t t{0.0, 0.0};
+  const double* __restrict__ p = a.Pprev + e;
+  int32_t q = q0;
+  for (; q + 8 <= q1; q += 8) {
+    double2_t v[8];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int i = part * 16 + t;
-    dv[t] = dinv[i + c * TB];
-    wv[t] = w[k0 + (i < nb ? i : nb - 1)];
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2_t*>(p + static_cast<int64_t>(q + k) * a.ldp);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += v[k];
   }
-  double s = 0.0;
+  if (q < q1) {
+    double2_t v[8];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int i = part * 16 + t;
-    if (i < nb && i >= c) s = __builtin_fma(dv[t], wv[t], s);
-  }
-  spart[part * TB + c] = s;
-  __syncthreads();
-  if (threadIdx.x < TB) sx[c] = spart[c] + spart[TB + c] + spart[2 * TB + c] + spart[3 * TB + c];
-  __syncthreads();
-}
-
-// Forward step k: wout[k0:k0+nb] = w_k; y[i] -= L[i, k0:k0+nb] * w_k for i >= k0+nb.
-__global__ __launch_bounds__(kBlock) void trsv_fwd_step_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
-                                                               int64_t k0, int nb, const double* __restrict__ dinv,
-                                                               double* __restrict__ y, double* __restrict__ wout,
-                                                               const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
-  __shared__ double sw[TB];
-  __shared__ double spart[4 * TB];
-  // panel update: 64 rows per workgroup, the 64 columns split over the four waves (16 independent loads per thread,
-  // all in flight together; lanes along rows -> 512-byte contiguous segments per column).  The panel does not depend
-  // on w_k: its loads are issued BEFORE the diagonal step and complete while that runs.
-  const int r = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = k0 + nb + static_cast<int64_t>(blockIdx.x) * 64 + r;
-  const int64_t ic = i < n ? i : n - 1;  // clamped row and column: loads stay unconditional
-  double v[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int col = grp * 16 + t;
-    v[t] = L[ic + (k0 + (col < nb ? col : nb - 1)) * ld];
-  }
-  diag_apply_fwd(dinv, y, k0, nb, sw, spart);
-  if (blockIdx.x == 0 && threadIdx.x < nb) wout[k0 + threadIdx.x] = sw[threadIdx.x];
-#pragma unroll
-  for (int t = 0; t < 16; ++t)
-    if (grp * 16 + t >= nb) v[t] = 0.0;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-  for (int t = 0; t < 16; t += 4) {
-    s0 = __builtin_fma(v[t + 0], sw[grp * 16 + t + 0], s0);
-    s1 = __builtin_fma(v[t + 1], sw[grp * 16 + t + 1], s1);
-    s2 = __builtin_fma(v[t + 2], sw[grp * 16 + t + 2], s2);
-    s3 = __builtin_fma(v[t + 3], sw[grp * 16 + t + 3], s3);
-  }
-  __syncthreads();  // spart is reused below
-  spart[grp * TB + r] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (grp == 0 && i < n) y[i] -= ((spart[r] + spart[TB + r]) + spart[2 * TB + r]) + spart[3 * TB + r];
-}
-
-// Backward step k: x[k0:k0+nb] = x_k; w[j] -= L[k0:k0+nb, j]' * x_k for j < k0.
-// 32 lanes per column (16-B loads over the 64 contiguous rows), 8 columns per block pass.
-__global__ __launch_bounds__(kBlock) void trsv_bwd_step_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
-                                                               int64_t k0, int nb, const double* __restrict__ dinv,
-                                                               double* __restrict__ w, double* __restrict__ x,
-                                                               const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
-  __shared__ double sx[TB];
-  __shared__ double spart[4 * TB];
-  const int half = threadIdx.x & 31;        // row pair within the block column
-  const int cslot = threadIdx.x >> 5;       // 0..7
-  const int r = 2 * half;
-  const int64_t jbase = static_cast<int64_t>(blockIdx.x) * 64;
-  // the eight 16-byte panel loads of a thread first, all in flight together and BEFORE the diagonal step (the panel
-  // does not depend on x_k).  k0 == 0: nothing to the left (and for n < 64 no 64-row panel to read).
-  double2_t dv[8];
-  if (k0 > 0) {
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int64_t j = jbase + pass * 8 + cslot;
-      const int64_t jc = j < k0 ? j : k0 - 1;  // clamped column: the load stays unconditional
-      // rows k0+r, k0+r+1 may run past n in the last (partial) block: still inside the allocation (they land in
-      // column jc+1 <= k0 <= n-1) and masked below
-      dv[pass] = *reinterpret_cast<const double2_t*>(L + k0 + r + jc * ld);
+    for (int k = 0; k < 8; ++k) {
+      const int32_t qq = (q + k < q1) ? q + k : q1 - 1;  // clamped: loads stay unconditional
+      v[k] = *reinterpret_cast<const double2_t*>(p + static_cast<int64_t>(qq) * a.ldp);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (q + k < q1) t += v[k];
   }
-  diag_apply_bwd(dinv, w, k0, nb, sx, spart);
-  if (blockIdx.x == 0 && threadIdx.x < nb) x[k0 + threadIdx.x] = sx[threadIdx.x];
-  const double x0 = (r < nb) ? sx[r] : 0.0, x1 = (r + 1 < nb) ? sx[r + 1] : 0.0;
-  if (k0 == 0) return;
-  double sv[8];
+  return t;
+}
+
+__device__ __forceinline__ double2_t ts_load_vec(const double* __restrict__ b, int64_t e, int64_t n) {
+  double2_t v{0.0, 0.0};
+  if (e + 1 < n) v = double2_t{b[e], b[e + 1]};  // caller vectors are only 8-byte aligned
+  else if (e < n) v.x = b[e];
+  return v;
+}
+
+__device__ __forceinline__ void ts_store_vec(double* __restrict__ b, int64_t e, int64_t n, double2_t v) {
+  if (e < n) b[e] = v.x;
+  if (e + 1 < n) b[e + 1] = v.y;
+}
+
+__device__ __forceinline__ double ts_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+template <bool NT>
+__device__ __forceinline__ void ts_load(const double* __restrict__ Mr, int64_t ld, int64_t c, double2_t (&d)[kTsPanel]) {
 #pragma unroll
-  for (int pass = 0; pass < 8; ++pass) {
-    const int64_t j = jbase + pass * 8 + cslot;
-    const double2_t d = dv[pass];
-    double s = 0.0;
-    if (j < k0) {
-      if (r + 1 < nb) s = d.x * x0 + d.y * x1;
-      else if (r < nb) s = d.x * x0;
-    }
-    sv[pass] = s;
-  }
+  for (int k = 0; k < kTsPanel; ++k) d[k] = load2<NT>(Mr + (c + k) * ld);
+}
+
+// xp: lane l holds the input pair of this wave's columns (2l, 2l+1); co = first column of the panel within the wave
+__device__ __forceinline__ void ts_fma(double2_t xp, int co, const double2_t (&d)[kTsPanel], double& a0, double& a1) {
 #pragma unroll
-  for (int pass = 0; pass < 8; ++pass) {
-    const int64_t j = jbase + pass * 8 + cslot;
-    double s = sv[pass];
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (half == 0 && j < k0) w[j] -= s;
+  for (int k = 0; k < kTsPanel; ++k) {
+    const double xj = ts_readlane((k & 1) ? xp.y : xp.x, (co + k) >> 1);
+    a0 = __builtin_fma(d[k].x, xj, a0);
+    a1 = __builtin_fma(d[k].y, xj, a1);
   }
 }
 
-int trsv_build(const double* L, int64_t n, int64_t ldl, double** dinv_out, TrsvPlan* plan, hipStream_t stream) {
-  const int64_t nblk = ceil_div(n, TB);
-  double* dinv = *dinv_out;
-  if (!dinv) {
-    ADMM_HIP_TRY(hipMalloc(&dinv, sizeof(double) * nblk * TB * TB));
-    launch_trtri_diag(L, n, ldl, dinv, stream);
-    *dinv_out = dinv;
+// One workgroup = one 128 x 128 tile, WAVES waves of 128 x (128 / WAVES) columns each.
+template <int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * kWave) void tri_step_kernel(TriStepArgs a) {
+  if (a.ctrl && a.ctrl->stop) return;
+  constexpr int WC = kTsTile / WAVES;  // columns per wave
+  __shared__ double2_t red[WAVES > 1 ? WAVES : 1][kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t nrows = a.rt1 - a.rt0;
+  const int32_t c = static_cast<int32_t>(blockIdx.y);
+  if (static_cast<int32_t>(blockIdx.x) >= nrows) {  // write out the previous step's solution block
+    if (c != 0 || wave != 0) return;
+    const int32_t T = a.ext0 + static_cast<int32_t>(blockIdx.x) - nrows;
+    int32_t q0, q1;
+    ts_prev_range(a, T, q0, q1);
+    const int64_t e = static_cast<int64_t>(T) * kTsTile + 2 * lane;
+    ts_store_vec(a.diag_out, e, a.n, ts_sum_prev(a, q0, q1, e));
+    return;
   }
-  plan->n = n;
-  plan->ldl = ldl;
-  plan->nb = TB;
-  plan->nblk = static_cast<int32_t>(nblk);
-  plan->L = L;
-  plan->dinv = dinv;
+  const int32_t R = a.rt0 + static_cast<int32_t>(blockIdx.x);  // row tile
+  const bool diag = R >= a.dt0 && R < a.dt1;
+  if (diag && (a.upper ? c < R - a.dt0 : c > R - a.dt0)) return;  // all-zero tile of the triangular block
+  const int64_t r = static_cast<int64_t>(R) * kTsTile + 2 * lane;  // this lane's row pair
+  const int64_t cw0 = static_cast<int64_t>(a.dt0 + c) * kTsTile + wave * WC;  // this wave's first column
+  const double* __restrict__ Mr = a.M + r;
+  double2_t bufA[kTsPanel], bufB[kTsPanel];
+  ts_load<NT>(Mr, a.ld, cw0, bufA);  // the matrix does not depend on the vectors: in flight during the prologue
+  // input block of this wave's columns: (base +) the previous step's partial sums, pair (2l, 2l+1) in lane l
+  double2_t xp{0.0, 0.0};
+  {
+    int32_t q0, q1;
+    ts_prev_range(a, a.dt0 + c, q0, q1);
+    const int64_t e = cw0 + 2 * (lane < WC / 2 ? lane : 0);
+    xp = ts_sum_prev(a, q0, q1, e);
+    if (a.x_use_base) xp += ts_load_vec(a.base_in, e, a.n);
+  }
+  // rows outside the diagonal block carry on: base_out = base_in + previous partial sums (first column tile only)
+  if (!diag && c == 0 && wave == 0) {
+    int32_t q0, q1;
+    ts_prev_range(a, R, q0, q1);
+    if (q1 > q0 || a.base_out != a.base_in)
+      ts_store_vec(a.base_out, r, a.n, ts_load_vec(a.base_in, r, a.n) + ts_sum_prev(a, q0, q1, r));
+  }
+  double a0 = 0.0, a1 = 0.0;
+  if (WC > kTsPanel) {
+#pragma unroll 1
+    for (int co = 0; co < WC; co += 2 * kTsPanel) {
+      ts_load<NT>(Mr, a.ld, cw0 + co + kTsPanel, bufB);
+      ts_fma(xp, co, bufA, a0, a1);
+      if (co + 2 * kTsPanel < WC) ts_load<NT>(Mr, a.ld, cw0 + co + 2 * kTsPanel, bufA);
+      ts_fma(xp, co + kTsPanel, bufB, a0, a1);
+    }
+  } else {
+    ts_fma(xp, 0, bufA, a0, a1);
+  }
+  double2_t acc{a0, a1};
+  if (WAVES > 1) {
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) acc += red[w][lane];
+  }
+  *reinterpret_cast<double2_t*>(a.Pcur + static_cast<int64_t>(c) * a.ldp + r) = acc;
+}
+
+// x block of the last backward step: sum of its partials
+__global__ __launch_bounds__(kWave) void tri_fold_kernel(TriStepArgs a) {
+  if (a.ctrl && a.ctrl->stop) return;
+  const int32_t T = a.ext0 + static_cast<int32_t>(blockIdx.x);
+  int32_t q0, q1;
+  ts_prev_range(a, T, q0, q1);
+  const int64_t e = static_cast<int64_t>(T) * kTsTile + 2 * static_cast<int>(threadIdx.x);
+  ts_store_vec(a.diag_out, e, a.n, ts_sum_prev(a, q0, q1, e));
+}
+
+// Um(j, i) = X(i, j) for the nb x nb lower-triangular block X (transposed copy of a diagonal block)
+__global__ __launch_bounds__(kBlock) void ts_transpose_block_kernel(const double* __restrict__ X, int64_t ldx,
+                                                                    double* __restrict__ U, int64_t ldu, int64_t nb) {
+  __shared__ double T[32][33];
+  const int64_t bi = blockIdx.x, bj = blockIdx.y;
+  if (bi < bj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = bi * 32 + tx, j = bj * 32 + rr;
+    T[rr][tx] = (i < nb && j < nb && i >= j) ? X[i + j * ldx] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t i = bj * 32 + tx, j = bi * 32 + rr;  // U(i, j) = X(j, i)
+    if (i < nb && j < nb) U[i + j * ldu] = T[tx][rr];
+  }
+}
+
+static int ts_block_tiles() {
+  if (const char* f = std::getenv("ADMM_TRSV_BLOCK_TILES")) {
+    const int v = std::atoi(f);
+    if (v >= 1 && v <= 64) return v;
+  }
+  return kTsBlockTiles;
+}
+
+size_t trsv_plan_elems(int64_t n) {
+  const int64_t npad = round_up(n, kTsTile);
+  const int64_t ntile = npad / kTsTile;
+  const int64_t bt = std::min<int64_t>(ts_block_tiles(), ntile);
+  // Fm + Um + two partial buffers + v + w
+  return static_cast<size_t>(2 * npad * npad + 2 * bt * npad + 2 * npad);
+}
+
+// L: n x n lower factor (upper part ignored); dinv64: its inverted 64x64 diagonal blocks.
+// `buf` must hold trsv_plan_elems(n) doubles and is owned by the caller.
+int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
+               hipStream_t stream) {
+  TrsvPlan& p = *plan;
+  p.n = n;
+  p.npad = round_up(n, kTsTile);
+  p.ntile = static_cast<int32_t>(p.npad / kTsTile);
+  p.bt = static_cast<int32_t>(std::min<int64_t>(ts_block_tiles(), p.ntile));
+  p.nblk = static_cast<int32_t>(ceil_div(p.ntile, p.bt));
+  p.bt = static_cast<int32_t>(ceil_div(p.ntile, p.nblk));  // balanced blocks
+  p.ldm = p.npad;
+  p.ldp = p.npad;
+  const size_t msz = static_cast<size_t>(p.npad) * p.npad;
+  p.Fm = buf;
+  p.Um = p.Fm + msz;
+  p.P[0] = p.Um + msz;
+  p.P[1] = p.P[0] + static_cast<int64_t>(p.bt) * p.npad;
+  p.v = p.P[1] + static_cast<int64_t>(p.bt) * p.npad;
+  p.w = p.v + p.npad;
+  p.streaming = stream_hint(static_cast<int64_t>(msz) * 8);
+  ADMM_HIP_TRY(hipMemsetAsync(buf, 0, trsv_plan_elems(n) * sizeof(double), stream));
+  for (int32_t k = 0; k < p.nblk; ++k) {
+    const int64_t k0 = static_cast<int64_t>(k) * p.bt * kTsTile;
+    const int64_t nb = std::min<int64_t>(static_cast<int64_t>(p.bt) * kTsTile, n - k0);
+    if (nb <= 0) break;
+    double* Xk = p.Fm + k0 + k0 * p.ldm;
+    // X_k = inv(L_kk) into Fm's (already zero) diagonal block
+    ADMM_TRY(trtri_lower_from_diag(L + k0 + k0 * ldl, nb, ldl, dinv64 + (k0 / 64) * 64 * 64, Xk, p.ldm, stream, false));
+    const int64_t below = n - k0 - nb;
+    if (below > 0)  // Fm_below = -L_below,k * X_k
+      launch_gemm(0, 0, below, nb, nb, -1.0, L + (k0 + nb) + k0 * ldl, ldl, Xk, p.ldm, 0.0, p.Fm + (k0 + nb) + k0 * p.ldm,
+                  p.ldm, false, stream);
+    const unsigned tb = static_cast<unsigned>(ceil_div(nb, 32));
+    hipLaunchKernelGGL(ts_transpose_block_kernel, dim3(tb, tb), dim3(kBlock), 0, stream, Xk, p.ldm,
+                       p.Um + k0 + k0 * p.ldm, p.ldm, nb);
+    if (k0 > 0)  // Um_above = -(L_k,above)' * X_k'
+      launch_gemm(1, 1, k0, nb, nb, -1.0, L + k0, ldl, Xk, p.ldm, 0.0, p.Um + k0 * p.ldm, p.ldm, false, stream);
+  }
   return ADMM_OK;
 }
 
-size_t trsv_workspace_elems(const TrsvPlan& p) { return static_cast<size_t>(round_up(p.n, 2)) * 2; }
+template <int WAVES>
+static void ts_launch(const TriStepArgs& a, dim3 grid, bool nt, hipStream_t stream) {
+  if (nt) hipLaunchKernelGGL((tri_step_kernel<WAVES, true>), grid, dim3(WAVES * kWave), 0, stream, a);
+  else hipLaunchKernelGGL((tri_step_kernel<WAVES, false>), grid, dim3(WAVES * kWave), 0, stream, a);
+}
 
-// work: 2*n doubles (scratch copy of y, and w)
-void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, double* work, const Ctrl* ctrl,
-                      hipStream_t stream) {
-  const int64_t n = p.n;
-  double* yy = work;
-  double* w = work + round_up(n, 2);
-  (void)hipMemcpyAsync(yy, y, sizeof(double) * n, hipMemcpyDeviceToDevice, stream);
-  for (int64_t k = 0; k < p.nblk; ++k) {
-    const int64_t k0 = k * TB;
-    const int nb = static_cast<int>((n - k0 < TB) ? n - k0 : TB);
-    const int64_t rows = n - k0 - nb;
-    const unsigned blocks = static_cast<unsigned>(rows > 0 ? ceil_div(rows, 64) : 1);
-    hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(blocks), dim3(kBlock), 0, stream, p.L, p.ldl, n, k0, nb,
-                       p.dinv + k * TB * TB, yy, w, ctrl);
+static void ts_step(const TriStepArgs& a, bool nt, hipStream_t stream) {
+  const int32_t rows = a.rt1 - a.rt0, cols = a.dt1 - a.dt0;
+  // waves per 128 x 128 tile: as few as still give the grid ~1500 waves (HBM needs tens of KB in flight per CU)
+  int waves = 1;
+  while (waves < 16 && static_cast<int64_t>(rows) * cols * waves < 1536) waves <<= 1;
+  const dim3 grid(static_cast<unsigned>(rows + (a.ext1 - a.ext0)), static_cast<unsigned>(cols));
+  switch (waves) {
+    case 1: ts_launch<1>(a, grid, nt, stream); break;
+    case 2: ts_launch<2>(a, grid, nt, stream); break;
+    case 4: ts_launch<4>(a, grid, nt, stream); break;
+    case 8: ts_launch<8>(a, grid, nt, stream); break;
+    default: ts_launch<16>(a, grid, nt, stream); break;
   }
-  for (int64_t k = p.nblk - 1; k >= 0; --k) {
-    const int64_t k0 = k * TB;
-    const int nb = static_cast<int>((n - k0 < TB) ? n - k0 : TB);
-    const unsigned blocks = static_cast<unsigned>(k0 > 0 ? ceil_div(k0, 64) : 1);
-    hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(blocks), dim3(kBlock), 0, stream, p.L, p.ldl, n, k0, nb,
-                       p.dinv + k * TB * TB, w, x, ctrl);
+}
+
+// y, x: n elements (not padded); x may alias y.
+void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream) {
+  TriStepArgs a{};
+  a.ld = p.ldm;
+  a.ldp = p.ldp;
+  a.n = p.n;
+  a.ctrl = ctrl;
+  int cur = 0;
+  auto block = [&](int32_t k, int32_t& t0, int32_t& t1) {
+    t0 = k * p.bt;
+    t1 = std::min(p.ntile, t0 + p.bt);
+  };
+  // forward sweep: w = inv(L) y
+  a.M = p.Fm;
+  a.upper = 0;
+  a.x_use_base = 1;
+  a.diag_out = p.w;
+  for (int32_t k = 0; k < p.nblk; ++k, cur ^= 1) {
+    block(k, a.dt0, a.dt1);
+    a.rt0 = a.dt0;
+    a.rt1 = p.ntile;
+    a.base_in = (k == 0) ? y : p.v;
+    a.base_out = p.v;
+    a.Pcur = p.P[cur];
+    a.Pprev = p.P[cur ^ 1];
+    if (k == 0) {
+      a.pd0 = a.pd1 = a.pr0 = a.pr1 = a.ext0 = a.ext1 = 0;
+    } else {
+      block(k - 1, a.pd0, a.pd1);
+      a.pr0 = a.pd0;
+      a.pr1 = p.ntile;
+      a.ext0 = a.pd0;  // w_{k-1}
+      a.ext1 = a.pd1;
+    }
+    a.pupper = 0;
+    ts_step(a, p.streaming, stream);
   }
+  // backward sweep: x = inv(L)' w
+  a.M = p.Um;
+  a.upper = 1;
+  a.diag_out = x;
+  a.base_in = p.w;
+  a.base_out = p.w;
+  for (int32_t k = p.nblk - 1; k >= 0; --k, cur ^= 1) {
+    block(k, a.dt0, a.dt1);
+    a.rt0 = 0;
+    a.rt1 = a.dt1;
+    a.Pcur = p.P[cur];
+    a.Pprev = p.P[cur ^ 1];
+    if (k == p.nblk - 1) {  // the last forward step's partials ARE w of the last block
+      block(k, a.pd0, a.pd1);
+      a.pr0 = a.pd0;
+      a.pr1 = p.ntile;
+      a.pupper = 0;
+      a.x_use_base = 0;
+      a.ext0 = a.ext1 = 0;
+    } else {
+      block(k + 1, a.pd0, a.pd1);
+      a.pr0 = 0;
+      a.pr1 = a.pd1;
+      a.pupper = 1;
+      a.x_use_base = 1;
+      a.ext0 = a.pd0;  // x_{k+1}
+      a.ext1 = a.pd1;
+    }
+    ts_step(a, p.streaming, stream);
+  }
+  // x of block 0 from the last step's partials
+  block(0, a.pd0, a.pd1);
+  a.pr0 = 0;
+  a.pr1 = a.pd1;
+  a.pupper = 1;
+  a.Pprev = p.P[cur ^ 1];
+  a.ext0 = a.pd0;
+  a.ext1 = a.pd1;
+  hipLaunchKernelGGL(tri_fold_kernel, dim3(static_cast<unsigned>(a.ext1 - a.ext0)), dim3(kWave), 0, stream, a);
 }
 
 }  // namespace admm

@@ -77,15 +77,19 @@ def test_cholesky_rejects_indefinite(gpu):
     assert b"positive definite" in gpu._lib.load().admm_last_error()
 
 
-@pytest.mark.parametrize("n", [1, 3, 64, 65, 130, 400, 1000])
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 128, 129, 130, 400, 1000, 1280, 1281, 1409, 2560, 2700, 3333])
 def test_trsv_pair(gpu, n):
+    """blocked substitution: one coarse block up to n = 1280, several beyond (ragged last block included);
+    the strictly-upper part of the factor buffer holds garbage, as after an in-place Cholesky of a full matrix"""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n + 20, n)) / np.sqrt(n + 20)
     Lf = np.asfortranarray(sla.cholesky(G.T @ G + np.eye(n), lower=True))
+    Lf = np.asfortranarray(Lf + np.triu(rng.standard_normal((n, n)), 1))
     y = rng.standard_normal(n)
     x = np.zeros(n)
     gpu._lib.check(gpu._lib.load().admm_op_trsv_pair(_dp(gpu, Lf), n, n, _dp(gpu, y), _dp(gpu, x)))
-    ref = sla.solve_triangular(Lf.T, sla.solve_triangular(Lf, y, lower=True), lower=False)
+    Lc = np.tril(Lf)
+    ref = sla.solve_triangular(Lc.T, sla.solve_triangular(Lc, y, lower=True), lower=False)
     assert _rel(x, ref) < 1e-11
 
 
