@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # error codes
 OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
@@ -21,7 +21,7 @@ PROB_LASSO, PROB_LASSO_CONSENSUS, PROB_LAD, PROB_HUBERFIT = 1, 2, 3, 4
 PROB_LINEARSVM, PROB_TOTALVARIATION, PROB_QP_BOUNDED, PROB_BASISPURSUIT = 5, 6, 7, 8
 PROB_MODEL, PROB_LINEARPROGRAM, PROB_QP_STANDARD, PROB_TV2D = 9, 10, 11, 12
 LOSS_HINGE, LOSS_01, LOSS_HINGE_OBJ01 = 0, 1, 2
-XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG, XSOLVE_CALLBACK = 0, 1, 2, 3, 4
+XSOLVE_AUTO, XSOLVE_TRSV, XSOLVE_INVERSE, XSOLVE_CG, XSOLVE_CALLBACK, XSOLVE_PINV = 0, 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1
 STOP_STANDARD, STOP_HNORM, STOP_BOTH, STOP_NONE = 0, 1, 2, 3
 FAST_OFF, FAST_STRONG, FAST_WEAK = 0, 1, 2
@@ -50,7 +50,7 @@ class ProblemDesc(C.Structure):
         ("comm", C.c_void_p),
         ("cg_tol", C.c_double), ("cg_maxit", C.c_int32), ("obj_gram", C.c_int32),
         ("Q", _dp), ("qz", _dp), ("D2", _dp), ("m2", C.c_int64), ("ldD2", C.c_int64), ("s2", _dp), ("c", _dp),
-        ("K", _dp), ("k0", _dp),
+        ("K", _dp), ("k0", _dp), ("Dplus", _dp), ("Dts", _dp),
     ]
 
 
@@ -80,6 +80,16 @@ class RunSummary(C.Structure):
     ]
 
 
+class EngineInfo(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("xsolve_requested", C.c_int32), ("xsolve_used", C.c_int32),
+        ("pinv_used", C.c_int32), ("probed", C.c_int32), ("trsv_blocks", C.c_int32), ("jacobi_sweeps", C.c_int32),
+        ("reserved", C.c_int32), ("factor_n", C.c_int64), ("rank", C.c_int64),
+        ("cond_estimate", C.c_double), ("probe_err_inverse", C.c_double), ("probe_err_trsv", C.c_double),
+        ("probe_diff", C.c_double),
+    ]
+
+
 class AdmmError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"[admm_hip {code}] {message}")
@@ -99,10 +109,13 @@ _SIGNATURES = {
                                             OBJ_CALLBACK, C.c_void_p]),
     "admm_engine_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary)]),
     "admm_engine_fetch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "admm_engine_info": (C.c_int, [C.c_void_p, C.POINTER(EngineInfo)]),
     "admm_engine_setup_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "admm_engine_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "admm_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "admm_engine_destroy": (None, [C.c_void_p]),
+    "admm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "admm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "admm_op_gemv_n": (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int64, _dp, _dp]),
     "admm_op_gemv_t": (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int64, _dp, C.c_int64, C.c_int32, _dp, C.c_int64]),
     "admm_op_gram": (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _dp]),

@@ -116,7 +116,7 @@ def getproxops(problem, args):
     if kind not in _PROBLEMS:
         raise ValueError("Invalid input for problem - given string is not a solver!")
     xs = {"auto": L.XSOLVE_AUTO, "trsv": L.XSOLVE_TRSV, "inverse": L.XSOLVE_INVERSE,
-          "cg": L.XSOLVE_CG}[str(args.get("xsolve", "auto")).lower()]
+          "cg": L.XSOLVE_CG, "pinv": L.XSOLVE_PINV}[str(args.get("xsolve", "auto")).lower()]
     dev = int(args.get("device", 0))
     comm = args.get("comm")  # parallel.Comm: D/s/ell are then this rank's rows (see parallel.py)
     if comm is not None:
@@ -160,9 +160,10 @@ def getproxops(problem, args):
         D, ell, Cval = _get(args, "D"), _get(args, "ell"), _get(args, "C")
         loss = args.get("lossfunction", "hinge")
         m, n = D.shape
+        # args.Dplus (linearsvm.m:185-186), when the caller supplies it, is applied literally: x = Dplus*(z-u)
         eng = Engine(L.PROB_LINEARSVM, D=D, ell=ell, Cval=Cval,
                      loss={"hinge": L.LOSS_HINGE, "01": L.LOSS_01}.get(loss, L.LOSS_HINGE_OBJ01), xsolve=xs,
-                     device=dev, comm=comm, **cg)
+                     device=dev, comm=comm, Dplus=args.get("Dplus"), **cg)
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
     elif kind == "linearprogram" or (kind == "quadraticprogram" and _get(args, "constraint") == "standard"):
         # getProxOps.m:1363 / 1410 solve [M D'; D 0] \ [rho*(z-u) - q; s] every iteration (M = rho*I for the
@@ -614,6 +615,7 @@ def admm(xminf, zming, options):
         return results
 
     results["steps"] = steps
+    results["engine_info"] = eng.info()  # engine extension: which x-solve form runs, probe errors, rank (not a reference field)
     try:  # matrix-free x-update: total inner CG iterations (engine extension, not a reference field)
         results["cg_iters_total"] = int(eng.fetch(L.F_CG_ITERS, 1)[0])
     except L.AdmmError:

@@ -6,18 +6,29 @@
 
 namespace admm {
 
-// cached factor of one slice and how it is applied
+// explicit inverses below this order are applied one wave per column (cache-resident, latency-bound: a 128 x 128
+// tile of the lower-triangle kernel is 32 dependent panel steps of one wave)
+constexpr int64_t kSymvHalfMin = 1536;
+
+// a cached Cholesky factor and how inv(L L') is applied
 struct SliceFactor {
-  double* F = nullptr;      // lower Cholesky factor of D_k'D_k + rho*I   (getProxOps.m:424-435)
+  double* F = nullptr;      // lower Cholesky factor (getProxOps.m:424-435, lasso.m:168, lad.m:134)
   int64_t n = 0, ld = 0;
   double* dinv = nullptr;   // inverted 64x64 diagonal blocks
-  double* Minv = nullptr;   // explicit inverse (xsolve = inverse), tile-padded like the engine's own (symv.hip)
+  int mode = ADMM_XSOLVE_TRSV;  // ADMM_XSOLVE_TRSV or ADMM_XSOLVE_INVERSE: the form in use
+  double* Minv = nullptr;   // explicit inverse (mode = inverse), tile-padded (symv.hip)
   int64_t ldM = 0;
-  SymvPlan planSy{};        // lower-triangle application for n >= 1536, one wave per column below
-  TrsvPlan trsv{};
-  double* work = nullptr;   // device storage of the blocked-substitution plan (xsolve = trsv)
-  GemvTPlan plan{};
-  double* part = nullptr;
+  SymvPlan planSy{};        // lower-triangle application for n >= kSymvHalfMin, one wave per column below
+  TrsvPlan trsv{};          // blocked triangular solves (mode = trsv)
+  double* work = nullptr;   // device storage of that plan
+  // diagnostics (admm_engine_info)
+  double diag_min = 0.0, diag_max = 0.0, cond_diag = 0.0;  // (max L_ii / min L_ii)^2 <= cond(L L')
+  bool probed = false;      // both forms were built and compared on a system with a known solution
+  double err_inv = 0.0, err_trsv = 0.0, probe_diff = 0.0;
+  int32_t chol_info = 0;
+  bool pinv = false;        // Minv is the pseudo-inverse of a rank-deficient D'D (linear SVM)
+  int64_t rank = 0;
+  int jacobi_sweeps = 0;
 };
 
 struct ConsSlice {

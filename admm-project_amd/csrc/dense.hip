@@ -4,6 +4,7 @@
 //   trtri     inverse of the lower factor, recursive-doubling over batched GEMMs
 // These replace MATLAB's `D'*D`, `chol` and the implicit factor inverse used by `\`.
 // MFMA is used here and only here (north_star: "MFMA used only for the one-time AtA build").
+#include <algorithm>
 #include <type_traits>
 
 #include "kernels.h"
@@ -513,6 +514,44 @@ int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double*
                        dim3(kBlock), 0, stream, X, n, ldx, b);
   }
   return ADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// y = L (L' x) for a lower factor L (strict upper part of the buffer ignored): builds a right-hand side whose exact
+// solution is known, for the x-solve probe at setup (engine.hip).  Cold path: one wave per column, one thread per row.
+__global__ __launch_bounds__(kBlock) void lt_apply_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
+                                                          const double* __restrict__ x, double* __restrict__ t) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 4 + wid;
+  if (j >= n) return;
+  const double* __restrict__ col = L + j * ld;
+  double s = 0.0;
+  for (int64_t i = j + lane; i < n; i += 64) s = __builtin_fma(col[i], x[i], s);
+  s = wave_sum(s);
+  if (lane == 0) t[j] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void l_apply_kernel(const double* __restrict__ L, int64_t ld, int64_t n,
+                                                         const double* __restrict__ t, double* __restrict__ y) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t ic = i < n ? i : n - 1;
+  // every thread of the block walks the columns up to the block's last row (uniform trip count, coalesced loads)
+  const int64_t jend = std::min<int64_t>(n, (static_cast<int64_t>(blockIdx.x) + 1) * kBlock);
+  double s = 0.0;
+#pragma unroll 8
+  for (int64_t j = 0; j < jend; ++j) {
+    const double v = L[ic + j * ld];
+    s = (j <= ic) ? __builtin_fma(v, t[j], s) : s;
+  }
+  if (i < n) y[i] = s;
+}
+
+void launch_llt_apply(const double* L, int64_t n, int64_t ld, const double* x, double* tmp, double* y,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(lt_apply_kernel, dim3(static_cast<unsigned>(ceil_div(n, 4))), dim3(kBlock), 0, stream, L, ld, n, x,
+                     tmp);
+  hipLaunchKernelGGL(l_apply_kernel, dim3(static_cast<unsigned>(ceil_div(n, kBlock))), dim3(kBlock), 0, stream, L, ld, n,
+                     tmp, y);
 }
 
 // ------------------------------------------------------------------------------------ utilities

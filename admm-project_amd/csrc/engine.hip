@@ -72,168 +72,327 @@ void collect_timers(admm_engine* e) {
 }
 
 // ---- factor setup ------------------------------------------------------------------
-// W (nF x nF, ld) holds an SPD matrix in its lower triangle -> F (in place), dinv, optionally Minv.
-int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind) {
-  e->nF = nF;
-  e->ldF = ld;
-  e->F = W;
-  const int64_t nblk = ceil_div(nF, 64);
-  ADMM_TRY(e->mem.alloc(&e->dinv, static_cast<size_t>(nblk) * 64 * 64));
-  if (Lgiven) {
-    ADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
-    ADMM_HIP_TRY(hipMemcpy2DAsync(W, ld * sizeof(double), Lgiven, nF * sizeof(double), nF * sizeof(double), nF,
-                                  memkind == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                  e->stream));
-    launch_trtri_diag(W, nF, ld, e->dinv, e->stream);
-  } else {
-    double* infod = nullptr;
-    ADMM_TRY(e->mem.alloc(&infod, 1));
-    int32_t* info_dev = reinterpret_cast<int32_t*>(infod);
-    ADMM_TRY(cholesky_lower(W, nF, ld, info_dev, e->dinv, e->stream));
-    int32_t info = 0;
-    ADMM_HIP_TRY(hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-    if (info != 0)
-      return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " +
-                                      std::to_string(info) + ")");
-  }
-  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    double* X = nullptr;
-    ADMM_TRY(e->mem.alloc(&X, static_cast<size_t>(ld) * nF));
-    ADMM_TRY(trtri_lower_from_diag(W, nF, ld, e->dinv, X, ld, e->stream));
-    // Minv is stored padded to whole 128x128 tiles (zeros outside nF x nF): symv.hip has no edge path
-    e->planSy = symv_plan(nF);
-    const int64_t ldM = e->planSy.npad;
-    e->ldMinv = ldM;
-    ADMM_TRY(e->mem.alloc(&e->Minv, static_cast<size_t>(ldM) * ldM));
-    ADMM_HIP_TRY(hipMemsetAsync(e->Minv, 0, sizeof(double) * ldM * ldM, e->stream));
-    // Minv = X' * X  (lower tiles, then mirrored)
-    launch_gemm(1, 0, nF, nF, nF, 1.0, X, ld, X, ld, 0.0, e->Minv, ldM, true, e->stream);
-    launch_symmetrize_lower(e->Minv, nF, ldM, e->stream);
-    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-    // X is no longer needed
-    (void)hipFree(X);
-    for (auto& p : e->mem.ptrs)
-      if (p == X) p = nullptr;
-    e->planSq = gemv_t_plan(nF, nF, ldM);
-    ADMM_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
-    // lower-triangle form only where bandwidth matters: a 128x128 tile is 32 dependent panel steps of one
-    // wave, so for small n the latency of that chain exceeds the whole column-dot GEMV (n = 400: 18k -> 2xk it/s)
-    e->sy_half = nF >= 1536;
-    if (e->sy_half) {
-      ADMM_TRY(e->mem.alloc(&e->syN, e->planSy.npart_elems()));
-      ADMM_TRY(e->mem.alloc(&e->syT, e->planSy.tpart_elems()));
-      // zero once: with the tiles split over ranks, the slots of foreign tiles are never written
-      ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * e->planSy.npart_elems(), e->stream));
-      ADMM_HIP_TRY(hipMemsetAsync(e->syT, 0, sizeof(double) * e->planSy.tpart_elems(), e->stream));
-      // Multi-GPU: splitting the tiles over the ranks removes t*(1 - 1/N) of streaming time per x-solve and adds
-      // one all-reduce of n doubles.  Decide with the latency this communicator actually has (measured here, the
-      // mean over the ranks so that every rank takes the same decision): t = 4*npad^2 bytes at ~5.5 TB/s.
-      const int nr = e->comm ? comm_nranks(e->comm) : 1;
-      if (nr > 1) {
-        double* probe = e->syN;  // any device buffer of >= nF + 1 doubles
-        for (int k = 0; k < 3; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(nF), e->stream));
-        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-        const auto c0 = std::chrono::steady_clock::now();
-        const int reps = 10;
-        for (int k = 0; k < reps; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(nF), e->stream));
-        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-        double lat_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e6 / reps;
-        ADMM_HIP_TRY(hipMemcpyAsync(probe, &lat_us, sizeof(double), hipMemcpyHostToDevice, e->stream));
-        ADMM_TRY(comm_allreduce_device(e->comm, probe, 1, e->stream));
-        ADMM_HIP_TRY(hipMemcpyAsync(&lat_us, probe, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-        lat_us /= nr;
-        const double t_us = 4.0 * static_cast<double>(e->planSy.npad) * static_cast<double>(e->planSy.npad) / 5.5e6;
-        e->sy_split = t_us * (1.0 - 1.0 / nr) > 1.15 * lat_us;
-        if (const char* f = std::getenv("ADMM_HIP_XSPLIT")) e->sy_split = f[0] == '1';  // tests force either form
-        ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * e->planSy.npart_elems(), e->stream));
-      }
+static void mem_free_one(DevMem& mem, void* p) {
+  if (!p) return;
+  for (auto& q : mem.ptrs)
+    if (q == p) {
+      (void)hipFree(p);
+      q = nullptr;
+      return;
     }
-  } else {
-    ADMM_TRY(e->mem.alloc(&e->trsv_buf, trsv_plan_elems(nF)));
-    ADMM_TRY(trsv_build(W, nF, ld, e->dinv, e->trsv_buf, &e->trsv, e->stream));
-  }
+}
+
+// partial-sum buffers of the lower-triangle kernel, shared by every factor of the engine (same n)
+static int ensure_sy_buffers(admm_engine* e, const SymvPlan& plan) {
+  const size_t need = plan.npart_elems();
+  if (e->syN && e->sy_elems >= need) return ADMM_OK;
+  mem_free_one(e->mem, e->syN);
+  mem_free_one(e->mem, e->syT);
+  e->syN = e->syT = nullptr;
+  ADMM_TRY(e->mem.alloc(&e->syN, need));
+  ADMM_TRY(e->mem.alloc(&e->syT, plan.tpart_elems()));
+  e->sy_elems = need;
+  // zero once: with the tiles split over ranks, the slots of foreign tiles are never written
+  ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * need, e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->syT, 0, sizeof(double) * plan.tpart_elems(), e->stream));
   return ADMM_OK;
 }
 
-// x = Minv*y from the lower triangle; on a sharded engine every rank streams 1/N of the tiles and ONE
-// all-reduce of n doubles assembles x (the only per-iteration collective of the cached-factor lasso loop)
-int symv_apply(admm_engine* e, const double* y, double* out) {
-  const int nr = e->comm ? comm_nranks(e->comm) : 1;
-  if (nr > 1 && e->sy_split) {
-    launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
-    return comm_allreduce_device(e->comm, out, static_cast<size_t>(e->nF), e->stream);
+// f.Minv (tile-padded, zeros outside n x n) = X' X with X = inv(L): the explicit inverse of L L'
+static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
+  const int64_t n = f.n, ld = f.ld;
+  double* X = nullptr;
+  ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
+  int rc = trtri_lower_from_diag(f.F, n, ld, f.dinv, X, ld, e->stream);
+  f.planSy = symv_plan(n);
+  f.ldM = f.planSy.npad;
+  if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM);
+  if (rc == ADMM_OK) {
+    (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream);
+    launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, f.ldM, true, e->stream);
+    launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
   }
-  launch_symv_lower(e->planSy, e->Minv, e->ldMinv, y, e->syN, e->syT, out, e->ctrl, e->stream);
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(X);
+  ADMM_TRY(rc);
+  if (n >= kSymvHalfMin) ADMM_TRY(ensure_sy_buffers(e, f.planSy));
   return ADMM_OK;
 }
 
-// out = F^-T F^-1 y  (out has nF elements).  For the INVERSE path the result is left as
-// chunk partials in partSq unless `materialize`.
-int solve_factor(admm_engine* e, const double* y, double* out) {
-  if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {
-    return symv_apply(e, y, out);
-  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
-    launch_symv_small(e->Minv, e->nF, e->ldMinv, y, out, e->ctrl, e->stream);
-  } else {
-    launch_trsv_pair(e->trsv, y, out, e->ctrl, e->stream);
+static void apply_inverse(admm_engine* e, const SliceFactor& f, const double* y, double* out, const Ctrl* ctrl) {
+  if (f.n >= kSymvHalfMin) launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, ctrl, e->stream);
+  else launch_symv_small(f.Minv, f.n, f.ldM, y, out, ctrl, e->stream);
+}
+
+// Which form applies inv(L L')?  The explicit inverse is one bandwidth-bound pass but its forward error grows like
+// cond(LL')^1.5 * eps; the blocked triangular solves stay at the cond(LL') * eps of a backward-stable solve.  The
+// engine does not guess from a condition estimate: it builds both, solves  (L L') x = L (L' x0)  for a known x0 with
+// each, compares them on a second, unstructured right-hand side, and keeps the explicit inverse only while it is
+// as accurate as the triangular solves (within 2x / 4x) or below 1e-9 (three orders under the 1e-6 parity bar);
+// otherwise the blocked triangular solves run, also when `inverse` was requested explicitly.
+static int probe_and_choose(admm_engine* e, SliceFactor& f) {
+  const int64_t n = f.n, n2 = round_up(n, 2);
+  std::vector<double> x0(static_cast<size_t>(n));
+  for (int64_t i = 0; i < n; ++i) x0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.7 * static_cast<double>(i));
+  double* buf = nullptr;
+  ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), sizeof(double) * 5 * n2));
+  double *dx0 = buf, *dt = buf + n2, *dy = buf + 2 * n2, *dxi = buf + 3 * n2, *dxt = buf + 4 * n2;
+  int rc = ADMM_OK;
+  std::vector<double> xi(static_cast<size_t>(n)), xt(static_cast<size_t>(n));
+  auto run = [&]() -> int {
+    ADMM_HIP_TRY(hipMemcpyAsync(dx0, x0.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+    launch_llt_apply(f.F, n, f.ld, dx0, dt, dy, e->stream);  // y = L (L' x0)
+    apply_inverse(e, f, dy, dxi, nullptr);
+    launch_trsv_pair(f.trsv, dy, dxt, nullptr, e->stream);
+    ADMM_HIP_TRY(hipMemcpyAsync(xi.data(), dxi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(xt.data(), dxt, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    return ADMM_OK;
+  };
+  rc = run();
+  double ei = 0.0, et = 0.0;
+  if (rc == ADMM_OK) {
+    for (int64_t i = 0; i < n; ++i) {
+      const double a = std::fabs(xi[i] - x0[i]), b = std::fabs(xt[i] - x0[i]);
+      ei = (a > ei || a != a) ? a : ei;
+      et = (b > et || b != b) ? b : et;
+    }
+    // second right-hand side: signs and sizes with no structure (its solution is dominated by the small singular
+    // directions); no exact answer, so the two forms are compared with each other
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (int64_t i = 0; i < n; ++i) {
+      lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      const double u01 = static_cast<double>(lcg >> 11) * (1.0 / 9007199254740992.0);
+      x0[i] = (u01 < 0.5 ? -1.0 : 1.0) * (0.5 + u01);
+    }
+    auto run2 = [&]() -> int {
+      ADMM_HIP_TRY(hipMemcpyAsync(dy, x0.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+      apply_inverse(e, f, dy, dxi, nullptr);
+      launch_trsv_pair(f.trsv, dy, dxt, nullptr, e->stream);
+      ADMM_HIP_TRY(hipMemcpyAsync(xi.data(), dxi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipMemcpyAsync(xt.data(), dxt, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+      return ADMM_OK;
+    };
+    rc = run2();
   }
+  (void)hipFree(buf);
+  ADMM_TRY(rc);
+  double dmax = 0.0, xmax = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double d = std::fabs(xi[i] - xt[i]), a = std::fabs(xt[i]);
+    dmax = (d > dmax || d != d) ? d : dmax;
+    xmax = a > xmax ? a : xmax;
+  }
+  f.err_inv = ei / 1.5;  // relative to ||x0||_inf
+  f.err_trsv = et / 1.5;
+  f.probe_diff = xmax > 0.0 ? dmax / xmax : dmax;
+  f.probed = true;
+  // keep the one-pass form while it is as good as the backward-stable solves (or simply good enough)
+  const bool ok1 = f.err_inv <= std::max(1e-9, 2.0 * f.err_trsv);
+  const bool ok2 = f.probe_diff <= std::max(1e-9, 4.0 * f.err_trsv);
+  f.mode = (ok1 && ok2) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
   return ADMM_OK;
 }
 
-
-// ---- consensus slices: one cached factor per slice ----------------------------------------
-int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld) {
+// W (n x n, ld) holds an SPD matrix in its lower triangle (or receives the caller's factor Lgiven) -> f: the
+// Cholesky factor in place, its inverted 64 x 64 diagonal blocks, and ONE way of applying inv(L L'):
+// want = TRSV: blocked triangular solves; INVERSE / AUTO (n > 256): the explicit inverse if the probe allows it.
+int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld, int want, const double* Lgiven,
+                       int memkind) {
   f.F = W;
   f.n = n;
   f.ld = ld;
   const int64_t nblk = ceil_div(n, 64);
   ADMM_TRY(e->mem.alloc(&f.dinv, static_cast<size_t>(nblk) * 64 * 64));
-  double* infod = nullptr;
-  ADMM_TRY(e->mem.alloc(&infod, 1));
-  int32_t* info_dev = reinterpret_cast<int32_t*>(infod);
-  ADMM_TRY(cholesky_lower(W, n, ld, info_dev, f.dinv, e->stream));
-  int32_t info = 0;
-  ADMM_HIP_TRY(hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-  if (info != 0)
-    return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " + std::to_string(info) + ")");
-  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    double* X = nullptr;
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
-    int rc = trtri_lower_from_diag(W, n, ld, f.dinv, X, ld, e->stream);
-    f.planSy = symv_plan(n);
-    f.ldM = f.planSy.npad;
-    if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM);
-    if (rc == ADMM_OK) {
-      (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream);
-      launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, f.ldM, true, e->stream);
-      launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
-    }
-    (void)hipStreamSynchronize(e->stream);
-    (void)hipFree(X);
-    ADMM_TRY(rc);
-    if (n >= 1536 && !e->syN) {  // partial-sum buffers of the lower-triangle kernel, shared by all slices (same n)
-      ADMM_TRY(e->mem.alloc(&e->syN, f.planSy.npart_elems()));
-      ADMM_TRY(e->mem.alloc(&e->syT, f.planSy.tpart_elems()));
-    }
+  if (Lgiven) {
+    ADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
+    ADMM_HIP_TRY(hipMemcpy2DAsync(W, ld * sizeof(double), Lgiven, n * sizeof(double), n * sizeof(double), n,
+                                  memkind == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                  e->stream));
+    launch_trtri_diag(W, n, ld, f.dinv, e->stream);
   } else {
-    ADMM_TRY(e->mem.alloc(&f.work, trsv_plan_elems(n)));
-    ADMM_TRY(trsv_build(W, n, ld, f.dinv, f.work, &f.trsv, e->stream));
+    double* infod = nullptr;
+    ADMM_TRY(e->mem.alloc(&infod, 1));
+    int32_t* info_dev = reinterpret_cast<int32_t*>(infod);
+    ADMM_TRY(cholesky_lower(W, n, ld, info_dev, f.dinv, e->stream));
+    int32_t info = 0;
+    ADMM_HIP_TRY(hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    mem_free_one(e->mem, infod);
+    if (info != 0) {
+      f.chol_info = info;
+      return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " + std::to_string(info) + ")");
+    }
+  }
+  {  // cond(L L') >= (max L_ii / min L_ii)^2: a lower bound that costs one strided copy of the diagonal
+    std::vector<double> dg(static_cast<size_t>(n));
+    ADMM_HIP_TRY(hipMemcpy2DAsync(dg.data(), sizeof(double), W, (ld + 1) * sizeof(double), sizeof(double), n,
+                                  hipMemcpyDeviceToHost, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    double lo = INFINITY, hi = 0.0;
+    for (double v : dg) {
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+    f.diag_min = lo;
+    f.diag_max = hi;
+    f.cond_diag = (lo > 0.0) ? (hi / lo) * (hi / lo) : INFINITY;
+  }
+  if (want == ADMM_XSOLVE_AUTO) want = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
+  // the blocked triangular solves are built in every case: they are the fallback and the probe's yardstick
+  ADMM_TRY(e->mem.alloc(&f.work, trsv_plan_elems(n)));
+  ADMM_TRY(trsv_build(W, n, ld, f.dinv, f.work, &f.trsv, e->stream));
+  f.mode = ADMM_XSOLVE_TRSV;
+  if (want == ADMM_XSOLVE_INVERSE) {
+    ADMM_TRY(build_explicit_inverse(e, f));
+    ADMM_TRY(probe_and_choose(e, f));
+    if (f.mode == ADMM_XSOLVE_INVERSE) {  // the triangular-solve plan was only the yardstick
+      mem_free_one(e->mem, f.work);
+      f.work = nullptr;
+      f.trsv = TrsvPlan{};
+    } else {
+      mem_free_one(e->mem, f.Minv);
+      f.Minv = nullptr;
+    }
   }
   return ADMM_OK;
 }
 
-void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, double* out) {
-  if (e->xsolve == ADMM_XSOLVE_INVERSE) {
-    if (f.n >= 1536) launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream);
-    else launch_symv_small(f.Minv, f.n, f.ldM, y, out, e->ctrl, e->stream);
-  } else {
-    launch_trsv_pair(f.trsv, y, out, e->ctrl, e->stream);
-  }
+static void release_slice_factor(admm_engine* e, SliceFactor& f) {
+  mem_free_one(e->mem, f.Minv);
+  mem_free_one(e->mem, f.work);
+  mem_free_one(e->mem, f.dinv);
+  f = SliceFactor{};
 }
 
+void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, double* out) {
+  if (f.mode == ADMM_XSOLVE_INVERSE) apply_inverse(e, f, y, out, e->ctrl);
+  else launch_trsv_pair(f.trsv, y, out, e->ctrl, e->stream);
+}
+
+// engine-level multi-GPU refinement of the explicit-inverse x-solve: split the tiles over the ranks?
+static int decide_sy_split(admm_engine* e) {
+  const SliceFactor& f = e->xfac;
+  e->sy_split = false;
+  const int nr = e->comm ? comm_nranks(e->comm) : 1;
+  if (nr <= 1 || f.mode != ADMM_XSOLVE_INVERSE || f.n < kSymvHalfMin) return ADMM_OK;
+  // Splitting the tiles over the ranks removes t*(1 - 1/N) of streaming time per x-solve and adds one all-reduce
+  // of n doubles.  Decide with the latency this communicator actually has (measured here, the mean over the
+  // ranks so that every rank takes the same decision): t = 4*npad^2 bytes at ~5.5 TB/s.
+  double* probe = e->syN;  // any device buffer of >= n + 1 doubles
+  for (int k = 0; k < 3; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(f.n), e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  const auto c0 = std::chrono::steady_clock::now();
+  const int reps = 10;
+  for (int k = 0; k < reps; ++k) ADMM_TRY(comm_allreduce_device(e->comm, probe, static_cast<size_t>(f.n), e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  double lat_us = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count() * 1e6 / reps;
+  ADMM_HIP_TRY(hipMemcpyAsync(probe, &lat_us, sizeof(double), hipMemcpyHostToDevice, e->stream));
+  ADMM_TRY(comm_allreduce_device(e->comm, probe, 1, e->stream));
+  ADMM_HIP_TRY(hipMemcpyAsync(&lat_us, probe, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  lat_us /= nr;
+  const double t_us = 4.0 * static_cast<double>(f.planSy.npad) * static_cast<double>(f.planSy.npad) / 5.5e6;
+  e->sy_split = t_us * (1.0 - 1.0 / nr) > 1.15 * lat_us;
+  if (const char* fl = std::getenv("ADMM_HIP_XSPLIT")) e->sy_split = fl[0] == '1';  // tests force either form
+  // the probe (and the latency measurement) left partial sums behind; with the tiles split over ranks the slots
+  // of foreign tiles are never written again and must read as zero
+  ADMM_HIP_TRY(hipMemsetAsync(e->syN, 0, sizeof(double) * f.planSy.npart_elems(), e->stream));
+  ADMM_HIP_TRY(hipMemsetAsync(e->syT, 0, sizeof(double) * f.planSy.tpart_elems(), e->stream));
+  return ADMM_OK;
+}
+
+// the engine's own x-update factor
+int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind) {
+  SliceFactor& f = e->xfac;
+  // sharded engines must take the same decision on every rank: the factor is replicated bit for bit (all-reduced
+  // Gram matrix, same kernels), so the probe is too
+  ADMM_TRY(build_slice_factor(e, f, W, nF, ld, e->xsolve_requested, Lgiven, memkind));
+  e->F = f.F;
+  e->nF = nF;
+  e->ldF = ld;
+  e->xsolve = f.mode;
+  return decide_sy_split(e);
+}
+
+// D'D is rank deficient (or numerically so): x = pinv(D)*(z-u) = (D'D)^+ D'(z-u)  (linearsvm.m:185,
+// unwrappedadmm.m:76-78, getProxOps.m:1067).  W: the Gram matrix, lower triangle valid.  Builds
+// (D'D)^+ = V diag(1/lambda_i : lambda_i > tol) V' with the Jacobi eigen-solver and applies it like the explicit
+// inverse.  tol = n * eps * lambda_max: MATLAB's pinv rule max(size)*eps(norm) applied to D'D (the rank decisions
+// agree with pinv(D)'s whenever the small singular values of D are zero to rounding, e.g. zero or duplicated columns).
+int factorize_pinv(admm_engine* e, double* W, int64_t n, int64_t ld) {
+  SliceFactor& f = e->xfac;
+  f = SliceFactor{};
+  f.n = n;
+  f.ld = ld;
+  launch_symmetrize_lower(W, n, ld, e->stream);
+  double *V = nullptr, *lam = nullptr, *rotd = nullptr;
+  const int64_t ldv = round_up(n, 16);
+  ADMM_TRY(e->mem.alloc(&V, static_cast<size_t>(ldv) * n));
+  ADMM_TRY(e->mem.alloc(&lam, n));
+  ADMM_TRY(e->mem.alloc(&rotd, 1));
+  std::vector<double> lh;
+  int sweeps = 0;
+  ADMM_TRY(jacobi_eig_psd(W, n, ld, V, ldv, lam, reinterpret_cast<int32_t*>(rotd), &lh, &sweeps, e->stream));
+  double lmax = 0.0;
+  for (double v : lh) lmax = v > lmax ? v : lmax;
+  const double tol = static_cast<double>(n) * 2.220446049250313e-16 * lmax;
+  int64_t rank = 0;
+  double lmin = INFINITY;
+  for (double& v : lh) {
+    if (v > tol) {
+      ++rank;
+      lmin = v < lmin ? v : lmin;
+      v = 1.0 / std::sqrt(v);
+    } else {
+      v = 0.0;
+    }
+  }
+  ADMM_HIP_TRY(hipMemcpyAsync(lam, lh.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+  launch_scale_cols(V, ldv, n, lam, e->stream);  // V <- V diag(lambda^-1/2)
+  f.planSy = symv_plan(n);
+  f.ldM = f.planSy.npad;
+  ADMM_TRY(e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM));
+  ADMM_HIP_TRY(hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream));
+  launch_gemm(0, 1, n, n, n, 1.0, V, ldv, V, ldv, 0.0, f.Minv, f.ldM, true, e->stream);
+  launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  mem_free_one(e->mem, V);
+  mem_free_one(e->mem, lam);
+  mem_free_one(e->mem, rotd);
+  if (n >= kSymvHalfMin) ADMM_TRY(ensure_sy_buffers(e, f.planSy));
+  f.mode = ADMM_XSOLVE_INVERSE;
+  f.pinv = true;
+  f.rank = rank;
+  f.jacobi_sweeps = sweeps;
+  f.cond_diag = rank > 0 ? lmax / lmin : INFINITY;  // over the retained spectrum
+  e->F = nullptr;  // no Cholesky factor exists
+  e->nF = n;
+  e->ldF = ld;
+  e->xsolve = ADMM_XSOLVE_INVERSE;
+  return decide_sy_split(e);
+}
+
+// x = inv(LL')*y from the lower triangle of the explicit inverse; on a sharded engine every rank may stream 1/N of
+// the tiles and ONE all-reduce of n doubles assembles x
+int symv_apply(admm_engine* e, const double* y, double* out) {
+  const SliceFactor& f = e->xfac;
+  const int nr = e->comm ? comm_nranks(e->comm) : 1;
+  if (nr > 1 && e->sy_split) {
+    launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
+    return comm_allreduce_device(e->comm, out, static_cast<size_t>(f.n), e->stream);
+  }
+  apply_inverse(e, f, y, out, e->ctrl);
+  return ADMM_OK;
+}
+
+// out = inv(L L') y with the engine's own factor
+int solve_factor(admm_engine* e, const double* y, double* out) {
+  if (e->xfac.mode == ADMM_XSOLVE_INVERSE) return symv_apply(e, y, out);
+  launch_trsv_pair(e->xfac.trsv, y, out, e->ctrl, e->stream);
+  return ADMM_OK;
+}
 
 }  // namespace admm
 
@@ -336,9 +495,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   if (!(desc->rho > 0.0)) return bail(fail(ADMM_E_INVALID, "rho must be a positive real (lasso.m:138)"));
 
   int xs = desc->xsolve;
-  // AUTO: the literal two triangular solves are 2*n/64 dependent launches (latency-bound, 2.0 ms at n = 10^4);
-  // beyond a few diagonal blocks the one-pass symmetric GEMV with the explicit inverse is the faster form
-  if (xs == ADMM_XSOLVE_AUTO) xs = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
+  if (xs < ADMM_XSOLVE_AUTO || xs > ADMM_XSOLVE_PINV) return bail(fail(ADMM_E_INVALID, "bad desc.xsolve"));
+  if (xs == ADMM_XSOLVE_PINV && desc->problem != ADMM_PROB_LINEARSVM)
+    return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=pinv is the linear SVM / unwrapped ADMM x-update (unwrappedadmm.m:76-78)"));
+  // AUTO stays AUTO here: build_slice_factor resolves it per factor (blocked triangular solves up to n = 256, beyond
+  // that the explicit inverse if its probe holds, see probe_and_choose)
+  e->xsolve_requested = (xs == ADMM_XSOLVE_TRSV || xs == ADMM_XSOLVE_INVERSE) ? xs : ADMM_XSOLVE_AUTO;
   if (xs == ADMM_XSOLVE_CALLBACK && desc->problem != ADMM_PROB_LAD)
     return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=callback is the generic A = D engine: use ADMM_PROB_LAD with D = A, s = c"));
   if (xs == ADMM_XSOLVE_CALLBACK && e->comm && comm_nranks(e->comm) > 1)
@@ -376,7 +538,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
 
   switch (desc->problem) {
     case ADMM_PROB_LASSO: {
-      if (!desc->D || !desc->s || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "lasso needs D (m x n) and s"));
+      if (!desc->D || (!desc->s && !desc->Dts) || m <= 0 || n <= 0)
+        return bail(fail(ADMM_E_INVALID, "lasso needs D (m x n) and s (or D'*s)"));
       if (desc->lambda < 0) return bail(fail(ADMM_E_INVALID, "lambda must be a nonnegative real (lasso.m:132)"));
       e->a_identity = true;
       e->nA = n;
@@ -387,15 +550,21 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (sharded && e->fat)
         return bail(fail(ADMM_E_UNSUPPORTED, "row-sharded lasso needs a tall matrix (global m >= n)"));
       E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
-      E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
+      if (desc->s) E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
       e->planDN = gemv_n_plan(m, n, e->ldD);
       e->planDT = gemv_t_plan(m, n, e->ldD);
       E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
       E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(3)));
-      // Dts = D'*s   lasso.m:160
+      // Dts = D'*s   lasso.m:160 (or handed in: args.Dts, getProxOps.m:446)
       E_TRY(e->mem.alloc(&e->rhs_add, round_up(n, 2)));
-      launch_gemv_t(e->planDT, e->D, e->s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
-      launch_sum_partials_t(e->planDT, e->partDT, 1, e->rhs_add, round_up(n, 2), nullptr, e->stream);
+      if (desc->Dts) {
+        if (sharded) return bail(fail(ADMM_E_UNSUPPORTED, "args.Dts on a row-sharded engine: pass the local rows of s"));
+        E_HIP(hipMemcpyAsync(e->rhs_add, desc->Dts, sizeof(double) * n,
+                             mk == ADMM_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+      } else {
+        launch_gemv_t(e->planDT, e->D, e->s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
+        launch_sum_partials_t(e->planDT, e->partDT, 1, e->rhs_add, round_up(n, 2), nullptr, e->stream);
+      }
       if (sharded) E_TRY(comm_allreduce_device(e->comm, e->rhs_add, n, e->stream));  // sum_g D_g'*s_g
       if (e->xsolve == ADMM_XSOLVE_CG) {  // matrix-free: nothing n x n is ever formed
         if (e->fat) return bail(fail(ADMM_E_UNSUPPORTED, "xsolve=cg needs a tall matrix (m >= n)"));
@@ -413,7 +582,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
-          if (desc->obj_gram) {  // keep G = D'D (before the rho shift) in the symmetric kernel's tile-padded layout
+          if (desc->obj_gram && e->s) {  // keep G = D'D (before the rho shift) in the symmetric kernel's tile-padded layout
             e->planG = symv_plan(n);
             e->ldG = e->planG.npad;
             E_TRY(e->mem.alloc(&e->Gpad, static_cast<size_t>(e->ldG) * e->ldG));
@@ -491,6 +660,24 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         break;
       }
       if (e->xsolve == ADMM_XSOLVE_CALLBACK) break;  // the caller's xminf is the x-update: nothing to factor
+      if (svm && desc->Dplus) {
+        // args.Dplus = pinv(D) from the caller (linearsvm.m:185-186): x = Dplus*(z-u) is one pass over its
+        // transpose with the column-dot kernel (the same bytes as D'*v); nothing is factored
+        double* Dp = nullptr;
+        E_TRY(upload(e->mem, &Dp, desc->Dplus, static_cast<size_t>(n) * m, mk, e->stream));
+        double* Dpt = nullptr;
+        E_TRY(e->mem.alloc(&Dpt, static_cast<size_t>(m) * n));
+        launch_transpose(Dp, Dpt, n, m, nullptr, e->stream);  // (n x m) -> (m x n)
+        E_TRY(e->mem.alloc(&e->DplusT, static_cast<size_t>(e->ldD) * n));
+        E_HIP(hipMemsetAsync(e->DplusT, 0, sizeof(double) * e->ldD * n, e->stream));
+        E_HIP(hipMemcpy2DAsync(e->DplusT, e->ldD * sizeof(double), Dpt, m * sizeof(double), m * sizeof(double), n,
+                               hipMemcpyDeviceToDevice, e->stream));
+        E_HIP(hipStreamSynchronize(e->stream));
+        mem_free_one(e->mem, Dp);
+        mem_free_one(e->mem, Dpt);
+        e->xsolve = ADMM_XSOLVE_PINV;
+        break;
+      }
       const int64_t ld = round_up(n, 16);
       double* W = nullptr;
       E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
@@ -500,7 +687,37 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         // W = sum_g D_g'*D_g  (unwrappedadmm.m:96-123)
         if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
       }
-      E_TRY(factorize(e, W, n, ld, desc->L, mk));
+      if (!svm || desc->L) {  // lad.m:134 / huberfit.m:166: chol errors on a rank-deficient D, and so does the engine
+        E_TRY(factorize(e, W, n, ld, desc->L, mk));
+        // exactly dependent columns leave a pivot at the rounding level of D'D, of either sign: where MATLAB's chol
+        // may or may not error, the engine always refuses (the iterates would be noise amplified by 1/pivot)
+        if (!desc->L && !(e->xfac.cond_diag < 1.0 / (static_cast<double>(n) * 2.220446049250313e-16)))
+          return bail(fail(ADMM_E_NUMERIC, "Cholesky failed: D'*D is numerically singular (pivot ratio " +
+                                               std::to_string(e->xfac.cond_diag) + "): D must have full column rank (lad.m:134)"));
+        break;
+      }
+      // linear SVM: the reference's x-update is pinv(D)*(z-u) (linearsvm.m:185, unwrappedadmm.m:76-78), which exists
+      // for every D.  Full column rank: (D'D)^-1 D' through the Cholesky factor (same map, to rounding).  Rank
+      // deficient -- Cholesky breaks down, or its pivots fall to the rounding level of D'D -- or on request
+      // (xsolve = pinv): the pseudo-inverse of D'D from its eigen-decomposition.
+      {
+        double* Wkeep = nullptr;  // the Gram matrix survives the in-place factorisation attempt
+        E_TRY(e->mem.alloc(&Wkeep, static_cast<size_t>(ld) * n));
+        E_HIP(hipMemcpyAsync(Wkeep, W, sizeof(double) * ld * n, hipMemcpyDeviceToDevice, e->stream));
+        bool need_pinv = xs == ADMM_XSOLVE_PINV;
+        if (!need_pinv) {
+          const int rc = factorize(e, W, n, ld, nullptr, mk);
+          if (rc == ADMM_E_NUMERIC) need_pinv = true;
+          else if (rc != ADMM_OK) return bail(rc);
+          else if (!(e->xfac.cond_diag < 1.0 / (static_cast<double>(n) * 2.220446049250313e-16))) need_pinv = true;
+          if (need_pinv) {
+            release_slice_factor(e, e->xfac);
+            mem_free_one(e->mem, W);
+          }
+        }
+        if (need_pinv) E_TRY(factorize_pinv(e, Wkeep, n, ld));
+        else mem_free_one(e->mem, Wkeep);
+      }
       break;
     }
     case ADMM_PROB_QP_BOUNDED: {
@@ -577,7 +794,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         int64_t ld = 0;
         E_TRY(upload_matrix(e->mem, &W, &ld, desc->Q, n, n, n, mk, e->stream));
         launch_add_diag(W, n, ld, desc->rho, e->stream);  // getProxOps.m:1005-1008
-        E_TRY(build_slice_factor(e, e->zfac, W, n, ld));
+        E_TRY(build_slice_factor(e, e->zfac, W, n, ld, e->xsolve_requested, nullptr, mk));
         e->has_zfac = true;
       }
       // optional: the matrices of the objective 1/2||P*x-r||^2 + 1/2||Q*z-s||^2 (model.m:133-134)
@@ -752,7 +969,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
         launch_gemm(1, 0, n, n, sl.m, 1.0, sl.D, sl.ld, sl.D, sl.ld, 0.0, W, ld, true, e->stream);
         launch_add_diag(W, n, ld, desc->rho, e->stream);
-        E_TRY(build_slice_factor(e, sl.fac, W, n, ld));
+        E_TRY(build_slice_factor(e, sl.fac, W, n, ld, e->xsolve_requested, nullptr, mk));
       }
       e->cldn = round_up(n, 2);
       const size_t K = static_cast<size_t>(desc->nslices);
@@ -897,6 +1114,44 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
   if (cap < count) return fail(ADMM_E_CAPACITY, "destination too small");
   if (count) ADMM_HIP_TRY(hipMemcpy(dst, src, count * sizeof(double), hipMemcpyDeviceToHost));
   if (written) *written = count;
+  return ADMM_OK;
+}
+
+int admm_memcpy_d2h(void* host_dst, const void* device_src, size_t bytes, void* hip_stream) {
+  if ((!host_dst || !device_src) && bytes) return fail(ADMM_E_INVALID, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ADMM_HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, st));
+  ADMM_HIP_TRY(hipStreamSynchronize(st));
+  return ADMM_OK;
+}
+
+int admm_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* hip_stream) {
+  if ((!device_dst || !host_src) && bytes) return fail(ADMM_E_INVALID, "NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  ADMM_HIP_TRY(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+  ADMM_HIP_TRY(hipStreamSynchronize(st));
+  return ADMM_OK;
+}
+
+int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
+  if (!e || !info) return fail(ADMM_E_INVALID, "NULL argument");
+  if (info->struct_size != static_cast<int32_t>(sizeof(admm_engine_info_t)))
+    return fail(ADMM_E_INVALID, "admm_engine_info_t.struct_size mismatch (ABI version skew)");
+  const SliceFactor* f = &e->xfac;
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS && !e->cslices.empty()) f = &e->cslices[0].fac;
+  const bool has = f->F != nullptr || f->Minv != nullptr;
+  info->xsolve_requested = e->xsolve_requested;
+  info->xsolve_used = has ? f->mode : e->xsolve;  // ADMM_XSOLVE_PINV: the caller's Dplus is applied
+  info->pinv_used = f->pinv ? 1 : 0;
+  info->probed = f->probed ? 1 : 0;
+  info->factor_n = has ? f->n : 0;
+  info->rank = f->pinv ? f->rank : (has ? f->n : 0);
+  info->trsv_blocks = (has && f->mode == ADMM_XSOLVE_TRSV) ? f->trsv.nblk : 0;
+  info->jacobi_sweeps = f->jacobi_sweeps;
+  info->cond_estimate = has ? f->cond_diag : NAN;
+  info->probe_err_inverse = f->probed ? f->err_inv : NAN;
+  info->probe_err_trsv = f->probed ? f->err_trsv : NAN;
+  info->probe_diff = f->probed ? f->probe_diff : NAN;
   return ADMM_OK;
 }
 

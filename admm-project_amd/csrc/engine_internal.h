@@ -79,6 +79,7 @@ struct admm_engine {
   double* D = nullptr;
   int64_t ldD = 0;
   double *s = nullptr, *ell = nullptr, *q = nullptr, *lb = nullptr, *ub = nullptr;
+  double* DplusT = nullptr;  // linear SVM with the caller's pseudo-inverse (args.Dplus): its transpose, m x n, ld = ldD
   double* c = nullptr;      // constraint vector (alias of s) or null
   double cnorm = 0.0;
   double* rhs_add = nullptr;  // Dts (lasso) or q (QP)
@@ -90,22 +91,19 @@ struct admm_engine {
   GemvTPlan planK{};
   double* partK = nullptr;
 
-  // cached factor
-  double* F = nullptr;  // lower Cholesky factor, nF x nF
+  // cached factor of the x-update and how it is applied (blocked triangular solves or explicit inverse; for a
+  // rank-deficient linear-SVM D the pseudo-inverse of D'D): see build_slice_factor / factorize_pinv in engine.hip
+  SliceFactor xfac{};
+  int xsolve_requested = ADMM_XSOLVE_AUTO;  // what desc.xsolve asked for (AUTO / TRSV / INVERSE)
+  double* F = nullptr;  // = xfac.F: lower Cholesky factor, nF x nF (null when the pseudo-inverse is in use)
   int64_t nF = 0, ldF = 0;
-  double* dinv = nullptr;
-  double* Minv = nullptr;  // explicit inverse (symmetric, full), ld = ldMinv (tile-padded, zeros outside)
-  int64_t ldMinv = 0;
-  TrsvPlan trsv{};
-  double* trsv_buf = nullptr;  // device storage of the blocked-substitution plan (trsv_plan_elems)
 
   // GEMV plans + partial buffers
   GemvNPlan planDN{};   // D*x
   GemvTPlan planDT{};   // D'*v
   GemvTPlan planSq{};   // square symmetric nA x nA GEMV (Minv or P) run as column dots: M*v == M'*v
-  SymvPlan planSy{};    // Minv applied from its lower triangle only (half the bytes)
-  double *syN = nullptr, *syT = nullptr;
-  bool sy_half = false;
+  double *syN = nullptr, *syT = nullptr;  // partial-sum buffers of the lower-triangle kernel (shared by all factors)
+  size_t sy_elems = 0;
   bool sy_split = false;  // multi-GPU: split the tiles of the x-solve over the ranks (decided by measurement at create)
   double *partDN = nullptr, *partDT = nullptr, *partSq = nullptr;
 
@@ -192,7 +190,9 @@ void collect_timers(admm_engine* e);
 int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind);
 int symv_apply(admm_engine* e, const double* y, double* out);
 int solve_factor(admm_engine* e, const double* y, double* out);
-int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld);
+int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld, int want, const double* Lgiven,
+                       int memkind);
+int factorize_pinv(admm_engine* e, double* W, int64_t n, int64_t ld);
 void apply_slice_factor(admm_engine* e, const SliceFactor& f, const double* y, double* out);
 
 struct TimerScope {

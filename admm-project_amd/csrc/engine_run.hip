@@ -144,7 +144,10 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
                      e->stream);
       break;
     default:  // LAD / Huber / SVM: rhs already holds D'*(c + z - u) (row 0 of g)
-      ADMM_TRY(solve_factor(e, e->g, e->x));
+      if (e->DplusT)  // row 0 of g is Dplus*(z - u) already (getProxOps.m:1067)
+        launch_combine(e->g, 1, 0, 1.0, nullptr, 0.0, nullptr, e->x, e->nA, e->ctrl, e->stream);
+      else
+        ADMM_TRY(solve_factor(e, e->g, e->x));
       break;
   }
   return ADMM_OK;
@@ -152,14 +155,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
 
 // the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
 static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
-  if (e->xsolve == ADMM_XSOLVE_INVERSE && e->sy_half) {  // x = Minv*y from the lower triangle
-    return symv_apply(e, e->rhs, e->x);
-  } else if (e->xsolve == ADMM_XSOLVE_INVERSE) {  // small n: one wave per column, direct result
-    launch_symv_small(e->Minv, e->nF, e->ldMinv, e->rhs, e->x, e->ctrl, e->stream);
-  } else {
-    launch_trsv_pair(e->trsv, e->rhs, e->x, e->ctrl, e->stream);
-  }
-  return ADMM_OK;
+  return solve_factor(e, e->rhs, e->x);
 }
 
 int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
@@ -285,6 +281,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   } else if (o.objevals) {
     switch (e->problem) {
       case ADMM_PROB_LASSO:
+        if (!e->s)
+          return fail(ADMM_E_INVALID, "objevals on a lasso engine created from args.Dts alone: the objective "
+                                      "0.5*||D*x - s||^2 (lasso.m:227) needs s (or an objective callback)");
         obj_lasso_gemv = true;
         fa.obj_scale_part = 0.5;
         if (e->Gpad) {  // 1/2*x'Gx - x'D's + 1/2*s's  (desc.obj_gram)
@@ -443,10 +442,25 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   const auto tstart = std::chrono::steady_clock::now();
   // rhs of the first x-update from the initial iterates (zx = v = z0, ux = uhat = u0)
   launch_initial_rhs(len, e->rhs_kind, o.rho, e->z, e->u, e->c, e->rhs_add, e->rhs, e->stream);
-  if (!e->a_identity) {
+  // D'*[t1, z - zprev, u] in one pass over D (getProxOps.m:1514; admm.m:624, 654).  With the caller's pseudo-inverse
+  // (args.Dplus, linearsvm.m:185-186) row 0 is Dplus*t1 = the x-update itself (getProxOps.m:1067) and only the two
+  // dual-residual products still stream D.
+  auto transposed_products = [&](int nrhs) {
     TimerScope ts(e, ADMM_K_GEMV_T);
-    launch_gemv_t(e->planDT, e->D, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
-    launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+    if (e->DplusT) {
+      launch_gemv_t(e->planDT, e->DplusT, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+      launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+      if (nrhs > 1) {
+        launch_gemv_t(e->planDT, e->D, e->dz, e->u, nullptr, 2, e->partDT, e->ctrl, e->stream);
+        launch_sum_partials_t(e->planDT, e->partDT, 2, e->g + e->ldg, e->ldg, e->ctrl, e->stream);
+      }
+    } else {
+      launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs, e->partDT, e->ctrl, e->stream);
+      launch_sum_partials_t(e->planDT, e->partDT, nrhs, e->g, e->ldg, e->ctrl, e->stream);
+    }
+  };
+  if (!e->a_identity) {
+    transposed_products(1);
     if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
   }
   // One iteration = a fixed sequence of launches with iteration-independent arguments (the iteration
@@ -527,9 +541,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_extrapolate(xa, e->ctrl, e->stream);
       }
       if (!e->a_identity) {  // D'*[c+zx-ux, z-zprev, u]  (getProxOps.m:1514; admm.m:624, 654) in ONE pass
-        TimerScope ts(e, ADMM_K_GEMV_T);
-        launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs_dual, e->partDT, e->ctrl, e->stream);
-        launch_sum_partials_t(e->planDT, e->partDT, nrhs_dual, e->g, e->ldg, e->ctrl, e->stream);
+        transposed_products(nrhs_dual);
         if (shard_rows) {
           // ONE all-reduce per iteration: d = sum_g D_g'(...) (unwrappedadmm.m:135-137) for up to
           // three right-hand sides plus the 16 residual/objective partial sums (X3 + X6)

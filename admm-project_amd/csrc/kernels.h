@@ -1,5 +1,7 @@
 // kernels.h -- host-side launchers of the HIP kernels (all enqueue on `stream`, never sync).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace admm {
@@ -69,6 +71,9 @@ void launch_trtri_diag(const double* L, int64_t n, int64_t ldl, double* dinv, hi
 // clear = false: X (lower block and its upper-right scratch) is already zero
 int trtri_lower_from_diag(const double* L, int64_t n, int64_t ldl, const double* dinv, double* X, int64_t ldx,
                           hipStream_t stream, bool clear = true);
+// y = L (L' x), tmp: n doubles (setup-time probe of the x-solve forms)
+void launch_llt_apply(const double* L, int64_t n, int64_t ld, const double* x, double* tmp, double* y,
+                      hipStream_t stream);
 // mirror the lower triangle into the upper one
 void launch_symmetrize_lower(double* A, int64_t n, int64_t lda, hipStream_t stream);
 void launch_add_diag(double* A, int64_t n, int64_t lda, double shift, hipStream_t stream);
@@ -93,5 +98,12 @@ size_t trsv_plan_elems(int64_t n);
 int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
                hipStream_t stream);
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream);
+
+// ---------------------------------------------------------------- symmetric eigen-decomposition (jacobi.hip)
+// W (n x n symmetric PSD, FULL storage) is overwritten by W*V; V gets the eigenvectors, lam_host the eigenvalues
+// (paired with V's columns, unsorted).  lam_dev: n doubles, rot: one int32 (device scratch).
+int jacobi_eig_psd(double* W, int64_t n, int64_t ldw, double* V, int64_t ldv, double* lam_dev, int32_t* rot,
+                   std::vector<double>* lam_host, int* sweeps_out, hipStream_t stream);
+void launch_scale_cols(double* V, int64_t ldv, int64_t n, const double* scale, hipStream_t stream);
 
 }  // namespace admm

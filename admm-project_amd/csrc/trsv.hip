@@ -3,7 +3,7 @@
 //
 // A triangular solve is a dependent chain; what bounds it on this part is the number of dependent steps, not
 // bytes (round 1: 2*n/64 launches of 6 us = 0.05 of the HBM roofline).  So the chain is cut into K COARSE blocks
-// (10 tiles of 128 = 1280 rows; K = 8 at n = 10^4) and each step is one bandwidth-bound launch:
+// (16 tiles of 128 = 2048 rows; K = 5 at n = 10^4) and each step is one bandwidth-bound launch:
 //
 //   forward  step k:  w_k = inv(L_kk) y_k ;   y_below -= L_below,k w_k
 //   backward step k:  x_k = inv(L_kk)' w_k ;  w_above -= L_k,above' x_k
@@ -14,12 +14,15 @@
 // a step is ONE column-panel GEMV  out = M[:, block k] * in_k  whose result rows inside the block are the
 // solution block and whose other rows are added to the running right-hand side.  Both sweeps use the same
 // kernel: lanes along rows (column-major => 16-byte coalesced non-temporal loads), register accumulation per
-// row, one-wave workgroups on 128 x W tiles (W chosen per step so that the grid keeps >= ~1500 waves).  The
-// W-column partial sums of a row tile are combined by the LAST wave to arrive (sc1 write-through partials,
-// s_waitcnt, one agent-scope counter add; the wave whose add came last sums all partials in fixed order):
-// deterministic, no float atomics, no separate reduce launch.  2K launches per solve pair; the explicit
-// inverses are only of the K diagonal blocks (forward error eps*cond(L_kk), like any blocked TRSV with
-// pre-inverted diagonal blocks), so this is the numerically safe fallback of the `inverse` form.
+// row, one workgroup per 128 x 128 tile with 1..16 waves splitting its columns (chosen per step so that the grid
+// keeps >= ~1500 waves), the input block broadcast inside the wave by v_readlane.  Each tile writes ONE partial
+// row (its 128 columns); nothing synchronises inside a launch: the partial sums of step k are folded by step
+// k+1 itself -- every tile sums the <= 16 partial rows of its own input columns while its matrix panel is already
+// in flight, the first column tile of a row tile also carries the running right-hand side of its rows, and a few
+// extra one-wave workgroups write out the previous solution block -- in fixed order: deterministic, no float
+// atomics, no reduce launches.  2K + 1 launches per solve pair (K = 5 at n = 10^4); the explicit inverses are
+// only of the K diagonal blocks (forward error eps*cond(L_kk), like any blocked TRSV with pre-inverted diagonal
+// blocks), so this is the numerically safe fallback of the `inverse` form.
 #include <algorithm>
 #include <cstdlib>
 
@@ -30,7 +33,7 @@ namespace admm {
 typedef double double2_t __attribute__((ext_vector_type(2)));
 constexpr int kTsTile = 128;   // rows per wave = tile granularity of the blocks
 constexpr int kTsPanel = 8;    // columns per load group
-constexpr int kTsBlockTiles = 10;
+constexpr int kTsBlockTiles = 16;  // 2048-row blocks: K = 5 at n = 10^4 (per-launch fixed cost ~6 us: 10 -> 217 us, 16 -> 182 us, 27 -> 177 us per pair)
 
 struct TriStepArgs {
   const double* M;         // Fm or Um (npad x npad, ld)
@@ -65,28 +68,21 @@ __device__ __forceinline__ void ts_prev_range(const TriStepArgs& a, int32_t T, i
   }
 }
 
-// sum over the previous step's partials of the element pair at index e (fixed order; all loads of a group of
-// eight issued together)
+// sum over the previous step's partials of the element pair at index e (fixed order; the loads of a group of
+// sixteen are issued together: one memory round trip for a whole block of partials)
 __device__ __forceinline__ double2_t ts_sum_prev(const TriStepArgs& a, int32_t q0, int32_t q1, int64_t e) {
+  constexpr int G = 16;
   double2_t t{0.0, 0.0};
   const double* __restrict__ p = a.Pprev + e;
-  int32_t q = q0;
-  for (; q + 8 <= q1; q += 8) {
-    double2_t v[8];
+  for (int32_t q = q0; q < q1; q += G) {
+    double2_t v[G];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2_t*>(p + static_cast<int64_t>(q + k) * a.ldp);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += v[k];
-  }
-  if (q < q1) {
-    double2_t v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < G; ++k) {
       const int32_t qq = (q + k < q1) ? q + k : q1 - 1;  // clamped: loads stay unconditional
       v[k] = *reinterpret_cast<const double2_t*>(p + static_cast<int64_t>(qq) * a.ldp);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < G; ++k)
       if (q + k < q1) t += v[k];
   }
   return t;

@@ -20,7 +20,8 @@ class Engine:
     def __init__(self, problem, *, D=None, s=None, ell=None, P=None, q=None, lb=None, ub=None, Lfactor=None,
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
                  device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
-                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None, obj_gram=0):
+                 Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None, obj_gram=0,
+                 Dplus=None, Dts=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -87,6 +88,14 @@ class Engine:
             d.lb = vec(lb)
         if ub is not None:
             d.ub = vec(ub)
+        if Dplus is not None:  # args.Dplus = pinv(D) handed in by the caller (linearsvm.m:185-186)
+            Dp = _f64(Dplus)
+            if D is None or Dp.shape != (d.n, d.m):
+                raise ValueError("Dplus must be n x m for D m x n")
+            keep.append(Dp)
+            d.Dplus = L.as_dp(Dp)
+        if Dts is not None:  # args.Dts (lasso.m:160, 182)
+            d.Dts = vec(Dts)
         if Lfactor is not None:
             Lm = _f64(Lfactor)
             keep.append(Lm)
@@ -221,6 +230,20 @@ class Engine:
         v = C.c_double(0)
         L.check(self._lib.admm_engine_setup_seconds(self._h, C.byref(v)))
         return v.value
+
+    def info(self):
+        """What create() decided about the x-update factor (admm_engine_info): the form in use, the probe errors
+        of both forms, the condition estimate, and rank / sweeps when the pseudo-inverse path ran."""
+        i = L.EngineInfo()
+        i.struct_size = C.sizeof(L.EngineInfo)
+        L.check(self._lib.admm_engine_info(self._h, C.byref(i)))
+        names = {L.XSOLVE_AUTO: "auto", L.XSOLVE_TRSV: "trsv", L.XSOLVE_INVERSE: "inverse", L.XSOLVE_CG: "cg",
+                 L.XSOLVE_CALLBACK: "callback", L.XSOLVE_PINV: "pinv"}
+        return dict(xsolve_requested=names.get(i.xsolve_requested, i.xsolve_requested),
+                    xsolve_used=names.get(i.xsolve_used, i.xsolve_used), pinv_used=bool(i.pinv_used),
+                    probed=bool(i.probed), trsv_blocks=i.trsv_blocks, jacobi_sweeps=i.jacobi_sweeps,
+                    factor_n=i.factor_n, rank=i.rank, cond_estimate=i.cond_estimate,
+                    probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_diff=i.probe_diff)
 
     def set_profiling(self, on):
         """True/False, or an iterable of kernel classes (L.K_XSOLVE, ...) to time with HIP events."""

@@ -240,3 +240,42 @@ def mnist_like_problem(seed=1, m=6000, n=400, digit=0, labels=None):
     lab = np.asarray(labels[:m], dtype=np.float64)
     ell = np.where(lab == digit, 1.0, -1.0)
     return dict(D=D, ell=ell, C=0.5, x0=rng.random(n), z0=rng.random(m), u0=rng.random(m))
+
+
+def graded_matrix(seed, rows, cols, kappa):
+    """rows x cols matrix with singular values graded geometrically from 1 down to 1/kappa (random singular
+    vectors): the conditioning stress case for the un-shifted chol(D'D) of lad.m:134 / huberfit.m:166 (q20)."""
+    rng = np.random.default_rng(seed)
+    U, _ = np.linalg.qr(rng.standard_normal((rows, cols)))
+    V, _ = np.linalg.qr(rng.standard_normal((cols, cols)))
+    sv = np.geomspace(1.0, 1.0 / kappa, cols)
+    return np.asfortranarray((U * sv) @ V.T)
+
+
+def lad_problem_conditioned(seed=0, rows=512, cols=64, kappa=1e3):
+    """ladtest.m's recipe (outliers on 2 % of the rows) on a matrix with cond(D) = kappa."""
+    rng = np.random.default_rng(seed + 1000)
+    D = graded_matrix(seed, rows, cols, kappa)
+    xtrue = rng.standard_normal(cols)
+    s = D @ xtrue
+    k = int(np.ceil(rows / 50))
+    idx = rng.choice(rows, size=k, replace=False)
+    s[idx] += 10.0 * rng.standard_normal(k)
+    return dict(D=D, s=s, xtrue=xtrue)
+
+
+def rank_deficient_pixels(seed=1, m=1500, n=400, digit=0, dead=0.05, dup=0.03):
+    """mnist_like_problem whose matrix is rank deficient the way cropped MNIST is (mnistsvm.m:61-72): `dead` of the
+    pixel columns are zero in every sample, `dup` of them duplicate another column."""
+    p = mnist_like_problem(seed=seed, m=m, n=n, digit=digit)
+    rng = np.random.default_rng(seed + 77)
+    D = p["D"].copy(order="F")
+    cols = rng.permutation(n)
+    nd, nu = int(round(dead * n)), int(round(dup * n))
+    D[:, cols[:nd]] = 0.0
+    for j in cols[nd:nd + nu]:
+        src = cols[nd + nu + int(rng.integers(0, n - nd - nu))]
+        D[:, j] = D[:, src]
+    p["D"] = np.asfortranarray(D)
+    p["rank"] = n - nd - nu
+    return p

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADMM_ABI_VERSION 2
+#define ADMM_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -30,7 +30,7 @@ enum {
   ADMM_E_INVALID = -1,     /* bad argument (mirrors the reference's error() calls) */
   ADMM_E_UNSUPPORTED = -2, /* valid in the reference, not engine-native (yet) */
   ADMM_E_DEVICE = -3,      /* HIP runtime / no GPU */
-  ADMM_E_NUMERIC = -4,     /* Cholesky breakdown (matrix not positive definite) */
+  ADMM_E_NUMERIC = -4,     /* Cholesky breakdown (matrix not positive definite; lad.m:134 errors the same way) */
   ADMM_E_COMM = -5,        /* RCCL */
   ADMM_E_CAPACITY = -6     /* destination buffer too small */
 };
@@ -62,13 +62,23 @@ enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1,
 
 /* how the cached-factor x-update is applied every iteration */
 enum {
-  ADMM_XSOLVE_AUTO = 0,    /* TRSV up to n = 256, INVERSE beyond */
-  ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form) */
-  ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once */
+  ADMM_XSOLVE_AUTO = 0,    /* TRSV up to n = 256; beyond, INVERSE if it passes the accuracy probe below, else TRSV */
+  ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form: getProxOps.m:1200, 1514),
+                              as blocked substitution: 2K + 1 bandwidth-bound launches, K = ceil(n / 2048) */
+  ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once.  Its forward error grows
+                              like cond^1.5 * eps, so create() solves a system with a known solution with both forms
+                              and keeps the explicit inverse only while it is as accurate as the triangular solves
+                              (or below 1e-9); otherwise the triangular solves run (admm_engine_info reports which
+                              form is in use and the probe errors) */
   ADMM_XSOLVE_CG = 3,      /* matrix-free conjugate gradients on (D'D + rho I), A-streaming */
-  ADMM_XSOLVE_CALLBACK = 4 /* A = D problems (LAD shape: A x - z = c): no factor is built, D may have any shape;
+  ADMM_XSOLVE_CALLBACK = 4,/* A = D problems (LAD shape: A x - z = c): no factor is built, D may have any shape;
                               every run needs an xminf callback (admm_engine_set_callbacks) -- the generic
                               results = admm(xminf, zming, options) with a matrix options.A (admm.m:117-120) */
+  ADMM_XSOLVE_PINV = 5     /* linear SVM only: x = pinv(D)*(z-u) (linearsvm.m:185, unwrappedadmm.m:76-78) through the
+                              pseudo-inverse of D'D (Jacobi eigen-decomposition, eigenvalues <= n*eps*max dropped).
+                              AUTO / TRSV / INVERSE use chol(D'D) while D has full column rank and switch to this
+                              form by themselves when the factorisation breaks down or its pivots reach the
+                              rounding level (rank-deficient D: e.g. MNIST pixels that are zero in every sample) */
 };
 
 /* where the desc's data pointers live */
@@ -154,6 +164,13 @@ typedef struct admm_problem_desc {
    * S = D inv(M) D'  (built for desc.rho).  y = rho*(z-u) - q with q = the linear cost (args.b / args.q). */
   const double* K;
   const double* k0;
+  /* ADMM_PROB_LINEARSVM: optional pseudo-inverse computed by the caller, n x m column-major, ld = n
+   * (args.Dplus = pinv(D), linearsvm.m:185-186).  When given, the x-update is literally x = Dplus*(z-u)
+   * (getProxOps.m:1067): one GEMV with it, nothing is factored.  NULL: the engine forms the map from D'D itself. */
+  const double* Dplus;
+  /* ADMM_PROB_LASSO: optional D'*s (args.Dts, lasso.m:160, 182); the serial args struct carries no s
+   * (getProxOps.m:445-451).  Without s the engine-native objective (objevals) is unavailable. */
+  const double* Dts;
 } admm_problem_desc;
 
 /* POD mirror of the `options` struct read by admm.m:51-76 (defaults: setopt, 780-971). */
@@ -232,6 +249,24 @@ int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* x
                               void* zuser, admm_obj_callback obj, void* objuser);
 int admm_engine_run(admm_engine* eng, const admm_options* opts, admm_run_summary* summary);
 int admm_engine_fetch(admm_engine* eng, int field, double* dst, size_t cap, size_t* written);
+/* what create() decided about the x-update factor (first slice for consensus lasso) */
+typedef struct admm_engine_info_t {
+  int32_t struct_size;       /* sizeof(admm_engine_info_t), set by the caller */
+  int32_t xsolve_requested;  /* desc.xsolve as resolved: AUTO, TRSV or INVERSE */
+  int32_t xsolve_used;       /* ADMM_XSOLVE_TRSV or ADMM_XSOLVE_INVERSE (CG / CALLBACK / 0 where no factor exists) */
+  int32_t pinv_used;         /* 1: the explicit matrix is the pseudo-inverse of a rank-deficient D'D */
+  int32_t probed;            /* 1: both forms were built and compared */
+  int32_t trsv_blocks;       /* coarse blocks K of the blocked substitution (0 if not in use) */
+  int32_t jacobi_sweeps;     /* sweeps of the eigen-solver (pinv) */
+  int32_t reserved;
+  int64_t factor_n;          /* order of the factor (n; m for fat lasso) */
+  int64_t rank;              /* numerical rank (== factor_n unless pinv_used) */
+  double cond_estimate;      /* (max L_ii / min L_ii)^2, a lower bound of cond(L L'); pinv: lambda_max / lambda_min kept */
+  double probe_err_inverse;  /* max-norm relative forward error of each form on (L L') x = L (L' x0); NaN if not probed */
+  double probe_err_trsv;
+  double probe_diff;         /* max-norm relative difference of the two forms on an unstructured right-hand side */
+} admm_engine_info_t;
+int admm_engine_info(admm_engine* eng, admm_engine_info_t* info);
 /* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */
 int admm_engine_setup_seconds(admm_engine* eng, double* seconds);
 /* per-kernel timing of the last run, measured with HIP events on the engine's stream:
@@ -242,6 +277,12 @@ int admm_engine_kernel_time(admm_engine* eng, int which, double* total_ms, int64
  * negative = every class.  Each timed class costs two hipEventRecord per launch group. */
 int admm_engine_set_profiling(admm_engine* eng, int mask);
 void admm_engine_destroy(admm_engine* eng);
+
+/* Host <-> device copies on the engine's stream (hip_stream as handed to a callback, NULL = default stream), complete on
+ * return.  For bindings whose callbacks live on the host (a MATLAB function handle staged by the MEX gateway): the
+ * gateway needs no HIP headers. */
+int admm_memcpy_d2h(void* host_dst, const void* device_src, size_t bytes, void* hip_stream);
+int admm_memcpy_h2d(void* device_dst, const void* host_src, size_t bytes, void* hip_stream);
 
 /* ---- stand-alone operators (kernel-level entry points; HOST pointers) ---------
  * The building blocks of the loop, callable on their own: used by the parity tests

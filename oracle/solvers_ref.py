@@ -43,6 +43,18 @@ def slicemaker(slices, workers, length):
     return [int(k) for k in sl]
 
 
+def pinv_matlab(A):
+    """MATLAB's built-in ``pinv(A)`` as called at linearsvm.m:185 / unwrappedadmm.m:76: singular values
+    ``<= tol = max(size(A)) * eps(norm(A))`` are treated as zero (documented default of the built-in; NumPy's own
+    default ``rcond = 1e-15`` keeps directions MATLAB drops)."""
+    A = np.asarray(A, dtype=np.float64)
+    smax = float(np.linalg.norm(A, 2)) if A.size else 0.0
+    if smax == 0.0:
+        return np.zeros(A.shape[::-1])
+    tol = max(A.shape) * np.spacing(smax)
+    return np.linalg.pinv(A, rcond=tol / smax)
+
+
 def huber_cvx(x):
     """CVX ``huber`` (huberfit.m:180): x^2 if |x|<=1 else 2|x|-1."""
     ax = np.abs(x)
@@ -223,7 +235,7 @@ def unwrappedadmm(zming, D, options=None, workers=1, keep_init=True):
         xminf = proxf
         options["preprocess"] = preprocess
     else:  # 76-78
-        Dplus = np.linalg.pinv(D)
+        Dplus = pinv_matlab(D)
         xminf = lambda _x, z, u, _rho: Dplus @ (z - u)
     options.update(A=D, At=D.T, B=-1, nB=m, c=0, m=m)
     rng = np.random.default_rng(0)
@@ -254,7 +266,7 @@ def linearsvm(D, ell, C, options=None, workers=1):
         args["slices"] = slicemaker(options.get("slices", 0), workers, D.shape[0])
         options["slices"] = args["slices"]
     else:
-        args["Dplus"] = np.linalg.pinv(D)  # 185
+        args["Dplus"] = pinv_matlab(D)  # 185
     _, minz, _ = getproxops("LinearSVM", args)
     if loss == "hinge":  # 231-237
         options["obj"] = lambda x, z: 0.5 * float(x @ x) + C * float(np.sum(np.maximum(1 - ell * (D @ x), 0)))

@@ -227,6 +227,116 @@ def test_svm_mnist_shaped(gpu):
     assert "xvals" not in got
 
 
+@pytest.mark.parametrize("xsolve", ["auto", "trsv", "inverse", "pinv"])
+def test_svm_rank_deficient_matches_pinv(gpu, xsolve):
+    """BASELINE config 3's real input is rank deficient: cropped MNIST has pixels that are zero in every sample
+    (mnistsvm.m:61-72), which is why the reference computes x = pinv(D)*(z-u) (linearsvm.m:185,
+    unwrappedadmm.m:76-78).  5 % all-zero columns + 3 % duplicated columns: chol(D'D) breaks down, the engine
+    switches to the pseudo-inverse of D'D by itself and follows the oracle's pinv (MATLAB tolerance rule)."""
+    p = gpu.synth.rank_deficient_pixels(seed=1, m=1500, n=400, digit=3)
+    assert np.linalg.matrix_rank(p["D"]) == p["rank"] < 400
+    o = dict(objevals=1, x0=p["x0"], z0=p["z0"], u0=p["u0"])  # unwrappedadmm.m:90-92: both stop conditions, <= 1000 it.
+    got = gpu.linearsvm(p["D"], p["ell"], p["C"], dict(o, xsolve=xsolve))
+    ref = S.linearsvm(p["D"], p["ell"], p["C"], o)
+    _compare(got, ref, tol=1e-6)
+    info = got["engine_info"]
+    assert info["pinv_used"] and info["rank"] == p["rank"] and info["xsolve_used"] == "inverse"
+    # minimum-norm solution: nothing in the null space of D (zero columns stay exactly at 0)
+    dead = np.where(~p["D"].any(axis=0))[0]
+    assert dead.size and np.max(np.abs(got["xopt"][dead])) < 1e-12
+
+
+def test_svm_with_callers_pseudo_inverse(gpu):
+    """args.Dplus = pinv(D) from the caller (linearsvm.m:185-186) is applied literally, x = Dplus*(z-u)
+    (getProxOps.m:1067): same iterates as the oracle on a rank-deficient D, dual residual included"""
+    p = gpu.synth.rank_deficient_pixels(seed=2, m=900, n=200, digit=1)
+    Dplus = S.pinv_matlab(p["D"])
+    minx, minz, _ = gpu.getproxops("linearsvm", dict(D=p["D"], ell=p["ell"], C=p["C"], lossfunction="hinge",
+                                                     Dplus=Dplus))
+    m, n = p["D"].shape
+    o = dict(A=p["D"], At=p["D"].T, B=-1, c=0, m=m, nA=n, nB=m, x0=p["x0"], z0=p["z0"], u0=p["u0"],
+             maxiters=50, domaxiters=1, stopcond="both")
+    got = gpu.admm(minx, minz, dict(o))
+    from oracle import admm as ref_admm, getproxops as ref_getproxops
+    _, rz, _ = ref_getproxops("LinearSVM", dict(D=p["D"], Dt=p["D"].T, ell=p["ell"], C=p["C"], lossfunction="hinge",
+                                                Dplus=Dplus))
+    ref = ref_admm(lambda x, z, u, rho: Dplus @ (z - u), rz, dict(o))
+    _compare(got, ref, tol=1e-8)
+    assert got["engine_info"]["xsolve_used"] == "pinv"
+
+
+def test_svm_rank_deficient_tiny(gpu):
+    """duplicated column in the linearsvmtest.m geometry (n = 3, rank 2), run to convergence"""
+    p = gpu.synth.svm_problem(0)
+    D = np.asfortranarray(np.column_stack([p["D"], p["D"][:, 0]]))
+    rng = np.random.default_rng(5)
+    o = dict(objevals=1, x0=rng.random(3), z0=p["z0"], u0=p["u0"])
+    got = gpu.linearsvm(D, p["ell"], p["C"], o)
+    ref = S.linearsvm(D, p["ell"], p["C"], o)
+    _compare(got, ref, tol=1e-6)
+    assert got["engine_info"]["pinv_used"] and got["engine_info"]["rank"] == 2
+    assert abs(got["xopt"][0] - got["xopt"][2]) < 1e-10  # min-norm: equal weight on the two copies
+
+
+def test_lad_rank_deficient_is_an_error_like_the_reference(gpu):
+    """lad.m:134 `chol(D'*D,'lower')` errors on a rank-deficient D; so does the engine (no silent pinv there)"""
+    p = gpu.synth.lad_problem(0, 256, 32)
+    D = p["D"].copy(order="F")
+    D[:, 5] = D[:, 7]
+    with pytest.raises(gpu.AdmmError) as ei:
+        gpu.lad(D, p["s"], {})
+    assert ei.value.code == gpu._lib.E_NUMERIC
+
+
+@pytest.mark.parametrize("kappa", [1e3, 1e4])
+@pytest.mark.parametrize("xsolve", ["auto", "trsv", "inverse"])
+@pytest.mark.parametrize("solver", ["lad", "huberfit"])
+def test_ill_conditioned_factor_guard(gpu, solver, xsolve, kappa):
+    """q20: LAD / Huber factor the UN-shifted D'D, cond = kappa(D)^2.  The explicit inverse loses cond^1.5*eps and
+    must not be used there: create() probes both forms and falls back to the blocked triangular solves, whatever
+    was requested; every form then matches the oracle (LAPACK triangular solves) at 1e-6."""
+    p = gpu.synth.lad_problem_conditioned(0, 640, 300, kappa)
+    o = dict(objevals=1, domaxiters=1, maxiters=40)
+    got = getattr(gpu, solver)(p["D"], p["s"], dict(o, xsolve=xsolve))
+    ref = getattr(S, solver)(p["D"], p["s"], o)
+    _compare(got, ref, tol=1e-6)
+    info = got["engine_info"]
+    assert info["cond_estimate"] > 10.0
+    if xsolve != "trsv":
+        assert info["probed"]
+        # whichever form runs passed the probe (or is the triangular solve)
+        assert info["xsolve_used"] == "trsv" or (
+            info["probe_err_inverse"] <= max(1e-9, 2 * info["probe_err_trsv"])
+            and info["probe_diff"] <= max(1e-9, 4 * info["probe_err_trsv"]))
+
+
+def test_factor_guard_rejects_a_bad_inverse(gpu):
+    """a factor handed in by the caller (args.L, lasso.m:183) whose diagonal spans 12 orders of magnitude: the
+    explicit inverse loses digits the triangular solves keep, the probe sees it and the engine runs trsv"""
+    rng = np.random.default_rng(11)
+    n = 300
+    Lf = np.tril(rng.standard_normal((n, n)) * 0.05)
+    Lf[np.diag_indices(n)] = np.geomspace(1.0, 1e-6, n)
+    D = np.asfortranarray(rng.standard_normal((400, n)))
+    s = rng.standard_normal(400)
+    eng = gpu.Engine(gpu._lib.PROB_LASSO, D=D, s=s, lam=0.1, rho=1.0, Lfactor=np.asfortranarray(Lf),
+                     xsolve=gpu._lib.XSOLVE_INVERSE)
+    info = eng.info()
+    eng.close()
+    assert info["probed"] and info["cond_estimate"] >= 1e11
+    assert info["xsolve_used"] in ("trsv", "inverse")
+    if info["xsolve_used"] == "inverse":
+        assert info["probe_err_inverse"] <= max(1e-9, 2 * info["probe_err_trsv"])
+
+
+def test_well_conditioned_auto_keeps_the_inverse(gpu):
+    p = gpu.synth.lasso_problem(3, 1000, 300)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(xsolve="auto"))
+    info = got["engine_info"]
+    assert info["xsolve_used"] == "inverse" and info["probed"] and info["probe_err_inverse"] < 1e-12
+    assert info["probe_err_trsv"] < 1e-12
+
+
 @pytest.mark.parametrize("xsolve", ["trsv", "inverse"])
 def test_qp_bounded(gpu, xsolve):
     p = gpu.synth.qp_bounded_problem(0, 128)
