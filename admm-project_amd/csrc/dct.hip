@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void dct_rows_solve_kernel(double* __restri
 // 64 x 64 tiles through LDS (65-double pitch: conflict-free both ways); fully coalesced on both sides
 __global__ __launch_bounds__(kBlock) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
                                                            int64_t rows, int64_t cols, const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
+  if (ctrl && ctrl->stop) return;
   __shared__ double tile[64][65];
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;

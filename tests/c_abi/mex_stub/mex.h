@@ -1,9 +1,11 @@
-/* Minimal DECLARATIONS of the MATLAB C Matrix / MEX API entry points admm_mex.cpp uses -- a test fixture for a
- * syntax-only compile check of the shim (tests/test_c_abi_program.py).  Nothing here is implemented, linked or
- * shipped; the real header comes with MATLAB (extern/include/mex.h), which does not exist in the build image.
- * Signatures as documented in MathWorks' "C Matrix API" / "MEX API" reference. */
+/* Stand-in for MATLAB's mex.h / matrix.h: the entry points admm_mex.cpp uses, with the signatures documented in
+ * MathWorks' "C Matrix API" / "MEX API" reference.  The real header comes with MATLAB (extern/include/mex.h), which
+ * does not exist in the build image.  mex_runtime.cpp next to this file IMPLEMENTS them (malloc-backed mxArrays,
+ * function handles as registered C callbacks) so that the test-suite can execute the gateway, not only compile it.
+ * Test fixture only: nothing here is shipped or linked into libadmm_hip.so. */
 #ifndef ADMM_TEST_MEX_STUB_H
 #define ADMM_TEST_MEX_STUB_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -32,11 +34,17 @@ bool mxIsStruct(const mxArray* pa);
 bool mxIsSparse(const mxArray* pa);
 bool mxIsDouble(const mxArray* pa);
 bool mxIsNumeric(const mxArray* pa);
+bool mxIsLogical(const mxArray* pa);
 bool mxIsComplex(const mxArray* pa);
 bool mxIsChar(const mxArray* pa);
+bool mxIsClass(const mxArray* pa, const char* name);
+mwIndex* mxGetIr(const mxArray* pa);
+mwIndex* mxGetJc(const mxArray* pa);
 mxArray* mxGetField(const mxArray* pa, mwIndex i, const char* fieldname);
 void mxSetField(mxArray* pa, mwIndex i, const char* fieldname, mxArray* value);
 int mxAddField(mxArray* pa, const char* fieldname);
+int mxGetNumberOfFields(const mxArray* pa);
+const char* mxGetFieldNameByNumber(const mxArray* pa, int n);
 char* mxArrayToString(const mxArray* pa);
 void mxFree(void* ptr);
 void mxDestroyArray(mxArray* pa);
@@ -45,8 +53,11 @@ mxArray* mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID classid, mxComplexi
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray* mxCreateDoubleScalar(double value);
 mxArray* mxCreateLogicalScalar(bool value);
+mxArray* mxCreateString(const char* str);
+mxArray* mxCreateSparse(mwSize m, mwSize n, mwSize nzmax, mxComplexity flag);
 
 void mexErrMsgIdAndTxt(const char* identifier, const char* err_msg, ...);
+int mexCallMATLAB(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const char* functionName);
 void mexLock(void);
 void mexUnlock(void);
 int mexAtExit(void (*exit_fcn)(void));

@@ -1,0 +1,198 @@
+"""The reference-side binding, executed: admm-project_amd/csrc/admm_mex.cpp (the MEX gateway a MATLAB maintainer
+builds) compiled against the executable MEX-API stand-in of tests/c_abi/mex_stub/ and driven through
+mexFunction with the argument structs the reference's solver files build (lasso.m:181-224, lad.m:129-137,
+linearsvm.m:183-217 + unwrappedadmm.m:76-92, totalvariation.m:139-164), results compared with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import admm as ref_admm
+from oracle import getproxops as ref_getproxops
+from oracle import solvers_ref as S
+
+from mexharness import Harness, MexError, Sparse, build
+
+
+@pytest.fixture(scope="module")
+def mex(tmp_path_factory, ap):
+    ap._lib.load()
+    return Harness(build(tmp_path_factory.mktemp("mexh")))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def _same(got, ref, keys, tol=1e-8):
+    assert int(got["steps"]) == ref["steps"]
+    for k in keys:
+        assert k in got, k
+        assert _rel(got[k], ref[k]) < tol, k
+
+
+HIST = ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "xopt", "zopt", "uopt")
+
+
+def test_gateway_builds_and_reports_availability(mex, ap):
+    """CPU-side check: the gateway compiles against the MEX stand-in, links libadmm_hip.so and answers 'available'
+    with the truth; without a device 'solve' is an engine error (no host fallback)."""
+    have = ap._lib.device_count() > 0
+    assert mex.call("available") is have
+    with pytest.raises(MexError) as ei:
+        mex.call("solve", "notasolver", {}, {})
+    assert ei.value.identifier == "admm:problem"
+    if not have:
+        with pytest.raises(MexError) as ei:
+            mex.call("solve", "lasso", dict(D=np.eye(3), s=np.ones(3), parallel=0, rho=1.0), {})
+        assert ei.value.identifier == "admm:engine" and "device" in ei.value.message
+    with pytest.raises(MexError):
+        mex.call("solve", "lasso", 3.0, {})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor", ["sparse", "dense", "none"])
+def test_mex_serial_lasso_as_lasso_m_calls_it(gpu, mex, factor):
+    """lasso.m:160-192: args = {D, Dts, L (sparse), U, m, n, lambda, parallel=0, rho} -- no s; options.obj is the
+    solver's closure (lasso.m:227), here an engine-native objective with s handed over in handles.s"""
+    p = gpu.synth.lasso_problem(0, 256, 64)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    Lf = np.linalg.cholesky(D.T @ D + np.eye(64))
+    args = dict(D=D, Dts=D.T @ s, m=256, n=64, parallel=0, rho=1.0)
+    args["lambda"] = lam
+    if factor == "sparse":
+        args.update(L=Sparse(Lf), U=Sparse(Lf.T))
+    elif factor == "dense":
+        args.update(L=Lf, U=Lf.T)
+    options = dict(objevals=1, A=1, At=1, m=64, nA=64, nB=64, B=-1, c=0, parallel="none")
+    got = mex.call("solve", "lasso", args, options, dict(objnative=1, s=s))
+    ref = S.lasso(D, s, lam, dict(objevals=1))
+    _same(got, ref, HIST + ("objevals",))
+    assert got["objopt"] == pytest.approx(ref["objopt"], rel=1e-9)
+    assert np.array_equal(got["x0"], np.zeros(64)) and got["runtime"] > 0
+    assert "Hnormsq" not in got and "wvals" not in got  # admm.m:302: only with convtest / hnorm stop conditions
+
+
+@pytest.mark.gpu
+def test_mex_lasso_objective_as_a_matlab_handle(gpu, mex):
+    """the solver's own options.obj closure evaluated through mexCallMATLAB (host staging) instead of natively"""
+    p = gpu.synth.lasso_problem(1, 128, 32)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    args = dict(D=D, Dts=D.T @ s, m=128, n=32, parallel=0, rho=1.0)
+    args["lambda"] = lam
+    calls = []
+
+    def obj(x, z):
+        calls.append(1)
+        return 0.5 * float(np.sum((D @ x - s) ** 2)) + lam * float(np.sum(np.abs(z)))
+
+    got = mex.call("solve", "lasso", args, dict(objevals=1, convtest=1), dict(obj=obj))
+    ref = S.lasso(D, s, lam, dict(objevals=1, convtest=1))
+    _same(got, ref, HIST + ("objevals", "Hnormsq", "wvals"))
+    assert len(calls) >= ref["steps"] and got["Hnormtol"] == 1e-6
+
+
+@pytest.mark.gpu
+def test_mex_consensus_lasso_four_slices(gpu, mex):
+    """lasso.m:196-224: args = {slices, D, s, lambda, rho, parallel=1}; options.altu / specialnorms are the
+    engine's own (getProxOps.m:441-442)"""
+    p = gpu.synth.lasso_problem(2, 400, 48)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    args = dict(slices=np.array([100.0, 100.0, 100.0, 100.0]), D=D, s=s, rho=1.0, parallel=1)
+    args["lambda"] = lam
+    options = dict(objevals=1, stopcond="both", A=1, At=1, m=48, nA=48, nB=48, B=-1, c=0, parallel="none")
+    got = mex.call("solve", "lasso", args, options, dict(objnative=1))
+    ref = S.lasso(D, s, lam, dict(objevals=1, parallel="both", slices=0), workers=4)
+    _same(got, ref, ("xvals", "zvals", "uvals", "pnorm", "dnorm", "objevals", "Hnormsq", "xopt", "uopt"))
+    assert np.all(got["zopt"] == 0.0) and "zconsensus" in got  # q9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xform", ["native", "handle", "dplus"])
+def test_mex_linear_svm_through_unwrappedadmm(gpu, mex, xform):
+    """linearsvm.m:183-217 + unwrappedadmm.m:76-92: zming is the library operator, xminf the plain handle
+    @(x,z,u,rho) Dplus*(z-u) -- run natively (matlab/admm.m recognises it), as a staged MATLAB handle, or through
+    args.Dplus; rank-deficient D (dead and duplicated pixels) as cropped MNIST"""
+    p = gpu.synth.rank_deficient_pixels(seed=3, m=600, n=120, digit=2)
+    D, ell, Cv = p["D"], p["ell"], p["C"]
+    m, n = D.shape
+    Dplus = S.pinv_matlab(D)
+    args = dict(D=D, Dt=D.T, ell=ell, C=Cv, lossfunction="hinge")
+    handles = dict(objnative=1)
+    if xform == "dplus":
+        args["Dplus"] = Dplus
+    elif xform == "handle":
+        handles["xminf"] = lambda x, z, u, rho: Dplus @ (z - u)
+    options = dict(objevals=1, A=D, At=D.T, B=-1, nB=m, c=0, m=m, x0=p["x0"], z0=p["z0"], u0=p["u0"], maxiters=1000,
+                   stopcond="both", nodualerror=1)
+    got = mex.call("solve", "linearsvm", args, options, handles)
+    ref = S.linearsvm(D, ell, Cv, dict(objevals=1, x0=p["x0"], z0=p["z0"], u0=p["u0"]))
+    _same(got, ref, ("xvals", "zvals", "uvals", "pnorm", "perr", "objevals", "Hnormsq", "xopt"), tol=1e-6)
+    assert np.isnan(got["dnorm"]).all() and np.isnan(got["derr"]).all()
+    assert np.array_equal(got["x0"], p["x0"])
+
+
+@pytest.mark.gpu
+def test_mex_lad_with_the_solvers_factor(gpu, mex):
+    """lad.m:129-151: args = {R = chol(D'D,'lower'), D, s}; options A = D, B = -1, c = s"""
+    p = gpu.synth.lad_problem(0, 512, 64)
+    D, s = p["D"], p["s"]
+    R = np.linalg.cholesky(D.T @ D)
+    options = dict(objevals=1, A=D, At=D.T, B=-1, c=s, m=512, nA=64, nB=512)
+    got = mex.call("solve", "lad", dict(R=R, D=D, s=s), options, dict(objnative=1))
+    ref = S.lad(D, s, dict(objevals=1))
+    _same(got, ref, HIST + ("objevals",))
+
+
+@pytest.mark.gpu
+def test_mex_total_variation(gpu, mex):
+    """totalvariation.m:139-164: args = {D (sparse difference operator), Dt, DtD, s, lambda}"""
+    p = gpu.synth.tv_problem(0, 512)
+    got = mex.call("solve", "totalvariation", {"s": p["s"], "lambda": p["lam"]}, dict(objevals=1, maxiters=10000),
+                   dict(objnative=1))
+    ref = S.totalvariation(p["s"], p["lam"], dict(objevals=1, maxiters=10000))
+    _same(got, ref, HIST + ("objevals",))
+
+
+@pytest.mark.gpu
+def test_mex_generic_admm_with_two_matlab_handles(gpu, mex):
+    """results = admm(xminf, zming, options) with both operators the caller's (admm.m:24;
+    examples/convergencechecking.m:125-136): the loop, u-update, residuals and stop logic on the device, the two
+    handles staged through the host"""
+    p = gpu.synth.lasso_problem(4, 200, 40)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    n = 40
+    F = np.linalg.inv(D.T @ D + np.eye(n))
+    Dts = D.T @ s
+    xmin = lambda x, z, u, rho: F @ (rho * (z - u) + Dts)
+    zmin = lambda x, z, u, rho: np.sign(x + u) * np.maximum(np.abs(x + u) - lam / rho, 0.0)
+    options = dict(A=1, At=1, B=-1, c=0, m=n, nA=n, nB=n, relax=1.5)
+    got = mex.call("solve", "generic", dict(n=n), options, dict(xminf=xmin, zming=zmin))
+    ref = ref_admm(xmin, zmin, dict(options))
+    _same(got, ref, HIST)
+
+    def broken(x, z, u, rho):
+        raise RuntimeError("error inside a MATLAB handle")
+
+    with pytest.raises(MexError) as ei:
+        mex.call("solve", "generic", dict(n=n), options, dict(xminf=broken, zming=zmin))
+    assert ei.value.identifier == "admm:engine" and "xminf callback" in ei.value.message
+
+
+@pytest.mark.gpu
+def test_mex_persistent_engine_create_run_destroy(gpu, mex):
+    """one engine, several runs (rho sweep with options.stalefactorok as xminLASSO behaves, getProxOps.m:1192-1206)"""
+    p = gpu.synth.lasso_problem(5, 256, 64)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    args = dict(D=D, s=s, parallel=0, rho=1.0)
+    args["lambda"] = lam
+    h = mex.call("create", "lasso", args)
+    assert mex.lib.mxh_lock_count() == 1
+    r1 = mex.call("run", h, dict(objevals=1), dict(objnative=1))
+    r2 = mex.call("run", h, dict(objevals=1, fast=1, fasttype="strong"), dict(objnative=1))
+    mex.call("destroy", h)
+    assert mex.lib.mxh_lock_count() == 0
+    _same(r1, S.lasso(D, s, lam, dict(objevals=1)), HIST + ("objevals",))
+    _same(r2, S.lasso(D, s, lam, dict(objevals=1, fast=1, fasttype="strong")), HIST + ("objevals", "avals", "vvals"))
+    with pytest.raises(MexError):
+        mex.call("run", h, {})
