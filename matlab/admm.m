@@ -1,0 +1,256 @@
+function results = admm(xminf, zming, options)
+%ADMM  Engine-backed replacement of the reference's ADMM loop.
+%
+%   results = admm(xminf, zming, options)
+%
+% Same signature, option fields and result fields as the reference (admm.m:24; options admm.m:51-76 with
+% the defaults of setopt, admm.m:780-971; results admm.m:257-259, 582-616, 648-656, 681-682, 746-767).
+% The loop itself -- x-update, relaxation, z-update, u-update, fast / accelerated ADMM, objective,
+% histories, residuals and tolerances, H-norm test, the three stop conditions (admm.m:496-743) -- runs on
+% the GPU inside libadmm_hip.so; this file only decides WHAT to hand to the gateway admm_mex:
+%
+%   xminf / zming are descriptors from getproxops (this directory)  -> the engine's own operators
+%   xminf / zming are MATLAB function handles f(x, z, u, rho)        -> staged through host memory once per
+%       iteration by the gateway (mexCallMATLAB); everything else stays on the device.  Mixed pairs are
+%       fine: unwrappedadmm.m:78 builds xminf = @(x,z,u,rho) Dplus*(z-u) next to the library's SVM
+%       z-update (that particular handle is recognised and runs natively, with its Dplus);
+%       examples/convergencechecking.m:125-136 mixes a library operator with a deliberately broken one.
+%   options.obj is the closure a reference solver installs (lasso.m:227, lad.m:148, huberfit.m:180,
+%       totalvariation.m:134-135, linearsvm.m:232-236, basispursuit.m:140, linearprogram.m:180,
+%       quadraticprogram.m:242)                                      -> the engine's own objective;
+%       any other handle                                             -> evaluated by MATLAB once per iteration.
+%
+% Not engine-native (error): options.altu / options.specialnorms as caller-supplied handles, function-handle
+% or non-trivial options.B, options.adaptive (experimental in the reference, admm.m:724-741; the Python
+% binding steps it, see INTEGRATION.md).
+
+if ~isstruct(options)
+    error('Given options is not a struct! At least pass empty struct!');    % admm.m:48
+end
+
+xd = isdescriptor(xminf);
+zd = isdescriptor(zming);
+handles = struct();
+
+if isfield(options, 'adaptive') && any(options.adaptive) && isfield(options, 'convtest') && any(options.convtest)
+    error('admm:unsupported', 'options.adaptive is not available through the MEX gateway.');
+end
+
+if xd && zd
+    if xminf.id ~= zming.id
+        error('admm:mixed', 'The two library operators come from different getproxops calls.');
+    end
+    problem = xminf.problem;
+    args = xminf.args;
+elseif zd           % library z-update, caller's x-update (unwrappedadmm.m:78)
+    problem = zming.problem;
+    args = zming.args;
+    [native, args] = unwrappedxupdate(xminf, problem, args);
+    if ~native
+        handles.xminf = slicewrap(xminf, options, 'xminf');
+    end
+elseif xd           % library x-update, caller's z-update (linearprogram.m:158-164 altproxg, quadraticprogram.m)
+    problem = xminf.problem;
+    args = xminf.args;
+    handles.zming = slicewrap(zming, options, 'zming');
+else                % both operators are the caller's: the generic loop (admm.m:24)
+    problem = 'generic';
+    args = genericargs(options);
+    handles.xminf = slicewrap(xminf, options, 'xminf');
+    handles.zming = slicewrap(zming, options, 'zming');
+end
+
+if xd || zd
+    checkconstraint(problem, options);
+end
+
+% the consensus hooks must be the engine's own (lasso.m:222-223 copies them from extra)
+hooks = {'altu', 'specialnorms'};
+for k = 1:numel(hooks)
+    if isfield(options, hooks{k}) && isa(options.(hooks{k}), 'function_handle')
+        error('admm:unsupported', ['options.', hooks{k}, ' as a caller-supplied handle is not engine-native.']);
+    end
+end
+
+[args, handles] = attachobjective(problem, args, options, handles);
+args = reducekkt(problem, args, options);
+
+% rho the cached factor is built for = the rho of this run (the reference's closures re-factor on
+% rho ~= rhoprev, getProxOps.m:1222-1238, 1446-1453; xminLASSO keeps the caller's factor, 1192-1206)
+if isfield(options, 'rho') && ~(isfield(args, 'L') || isfield(args, 'R'))
+    args.rho = options.rho;
+end
+
+results = admm_mex('solve', problem, args, options, handles);
+results.options = options;                                                  % admm.m:767
+
+end
+
+% -------------------------------------------------------------------------------------------------------
+function tf = isdescriptor(f)
+tf = isstruct(f) && isfield(f, 'admm_engine_descriptor');
+end
+
+function checkconstraint(problem, options)
+% the library operators fix the constraint of their problem (lasso.m:232-238, lad.m:140-145,
+% totalvariation.m:151-157, unwrappedadmm.m:81-86); function-handle A / At / B are not engine-native
+names = {'A', 'At', 'B'};
+for k = 1:numel(names)
+    if isfield(options, names{k}) && isa(options.(names{k}), 'function_handle')
+        error('admm:unsupported', ['options.', names{k}, ' as a function handle is not engine-native (', problem, ').']);
+    end
+end
+if isfield(options, 'B') && isnumeric(options.B) && ~(isscalar(options.B) && options.B == -1)
+    error('admm:unsupported', 'Only B = -1 is engine-native (every reference solver uses it).');
+end
+end
+
+function args = genericargs(options)
+% A = 1 (or absent): x - z = c.  A a matrix: A*x - z = c with the caller's handles (admm.m:117-120).
+args = struct();
+checkconstraint('generic', options);
+if isfield(options, 'A') && isnumeric(options.A) && numel(options.A) > 1
+    args.A = full(options.A);
+    nB = size(options.A, 1);
+else
+    if isfield(options, 'A') && ~(isscalar(options.A) && options.A == 1)
+        error('admm:unsupported', 'A scalar constraint operator other than A = 1 is not engine-native.');
+    end
+    if isfield(options, 'nA')
+        args.n = options.nA;
+    elseif isfield(options, 'm')
+        args.n = options.m;
+    elseif isfield(options, 'x0')
+        args.n = numel(options.x0);
+    else
+        error('admm:arg', 'The generic loop needs the vector length: set options.nA (or m, or x0).');
+    end
+    nB = args.n;
+end
+if isfield(options, 'c') && isnumeric(options.c)
+    if isscalar(options.c)
+        args.c = options.c*ones(nB, 1);                                     % admm.m:79-110
+    else
+        args.c = options.c(:);
+    end
+end
+end
+
+function [native, args] = unwrappedxupdate(xminf, problem, args)
+% unwrappedadmm.m:76-78  xminf = @(x,z,u,rho) Dplus*(z - u)   -> the engine applies Dplus itself
+% unwrappedadmm.m:125-141 xminf = @proxf (transpose reduction) -> the engine's cached factor of sum Di'*Di
+native = false;
+if ~strcmp(problem, 'linearsvm') || ~isa(xminf, 'function_handle')
+    return;
+end
+txt = regexprep(func2str(xminf), '\s', '');
+if strcmp(txt, '@(x,z,u,rho)Dplus*(z-u)')
+    native = true;
+    if ~isfield(args, 'Dplus')
+        info = functions(xminf);
+        if isfield(info, 'workspace') && ~isempty(info.workspace) && isfield(info.workspace{1}, 'Dplus')
+            args.Dplus = info.workspace{1}.Dplus;
+        end
+    end
+elseif ~isempty(regexp(txt, 'unwrappedadmm/proxf$', 'once'))
+    native = true;
+end
+end
+
+function f = slicewrap(f, options, which)
+% admm.m:343-468 (parproxf / parproxg): with options.parallel naming this operator, the handle has the
+% form f(x, z, u, rho, k) and returns slice k; the slices are concatenated in order
+if ~isa(f, 'function_handle')
+    error('admm:arg', 'A proximal operator must be a function handle or a getproxops descriptor.');
+end
+if ~isfield(options, 'parallel') || ~ischar(options.parallel)
+    return;
+end
+if ~(strcmp(options.parallel, which) || strcmp(options.parallel, 'both'))
+    return;
+end
+if ~isfield(options, 'slices')
+    error('admm:arg', 'options.parallel needs options.slices.');
+end
+count = numel(options.slices);
+g = f;
+f = @(x, z, u, rho) concatslices(g, x, z, u, rho, count);
+end
+
+function v = concatslices(g, x, z, u, rho, count)
+parts = cell(count, 1);
+for k = 1:count
+    parts{k} = reshape(g(x, z, u, rho, k), [], 1);
+end
+v = cell2mat(parts);
+end
+
+function [args, handles] = attachobjective(problem, args, options, handles)
+% options.obj (admm.m:248, 603-605).  The closures the reference solvers install are restated on the device;
+% they are recognised by their text.  Anything else is evaluated by MATLAB.
+if ~(isfield(options, 'objevals') && any(options.objevals)) || ~isfield(options, 'obj') || ...
+        ~isa(options.obj, 'function_handle')
+    return;
+end
+txt = regexprep(func2str(options.obj), '\s', '');
+known = struct( ...
+    'lasso', {{'@(x,z)0.5*sum((D*x-s).^2)+lambda*norm(z,1)'}}, ...
+    'lad', {{'@(x,z)norm(z,1)'}}, ...
+    'huberfit', {{'@(x,z)1/2*sum(huber(z))'}}, ...
+    'totalvariation', {{'@(x,z)1/2*norm(x-s,''fro'')^2+lambda*sum(abs(x(2:length(x))-x(1:length(x)-1)))'}}, ...
+    'linearsvm', {{'@(x,z)1/2*norm(x,''fro'')^2+C*sum(max(1-ell.*(D*x),0))', ...
+                   '@(x,z)1/2*norm(x,''fro'')^2+C*sum(max(sign(1-ell.*(D*x)),0))'}}, ...
+    'basispursuit', {{'@(x,z)norm(x,1)'}}, ...
+    'linearprogram', {{'@(x,z)b''*x'}}, ...
+    'quadraticprogram', {{'@(x,z)1/2*x''*P*x+q''*x+r'}});
+if isfield(known, problem) && any(strcmp(txt, known.(problem)))
+    handles.objnative = 1;
+    info = functions(options.obj);
+    ws = struct();
+    if isfield(info, 'workspace') && ~isempty(info.workspace)
+        ws = info.workspace{1};
+    end
+    if strcmp(problem, 'lasso') && ~isfield(args, 's')                     % getProxOps.m:445-451 has no s
+        if isfield(ws, 's')
+            handles.s = ws.s;
+        else
+            handles = rmfield(handles, 'objnative');
+            handles.obj = options.obj;
+        end
+    end
+    if strcmp(problem, 'quadraticprogram') && isfield(ws, 'r')              % quadraticprogram.m:242
+        handles.r = ws.r;
+    end
+else
+    handles.obj = options.obj;
+end
+end
+
+function args = reducekkt(problem, args, options)
+% getProxOps.m:1363 (linear program) and 1410 (standard-form QP) solve
+%     [M D'; D 0] * [x; nu] = [rho*(z - u) - q; s],   M = rho*I  or  P + rho*I
+% in every iteration.  Eliminating nu once gives the affine map the device applies:
+%     x = K*y + k0,  K = inv(M) - inv(M)*D'*inv(S)*D*inv(M),  k0 = inv(M)*D'*inv(S)*s,  S = D*inv(M)*D'.
+standard = strcmp(problem, 'linearprogram') || (strcmp(problem, 'quadraticprogram') && ...
+    isfield(args, 'constraint') && strcmp(args.constraint, 'standard'));
+if ~standard
+    return;
+end
+rho = 1.0;
+if isfield(options, 'rho')
+    rho = options.rho;
+end
+D = full(args.D);
+n = size(D, 2);
+if strcmp(problem, 'linearprogram')
+    M = rho*eye(n);
+else
+    M = full(args.P) + rho*eye(n);
+end
+MiDt = M \ D';
+S = D*MiDt;
+K = inv(M) - MiDt*(S \ MiDt');
+args.K = (K + K')/2;
+args.k0 = MiDt*(S \ args.s(:));
+args.rho = rho;
+end
