@@ -113,6 +113,7 @@ _SIGNATURES = {
     "admm_engine_setup_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "admm_engine_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "admm_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "admm_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "admm_engine_destroy": (None, [C.c_void_p]),
     "admm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "admm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -45,7 +45,7 @@ struct Ctrl {
   int32_t steps;           // results.steps (admm.m:746)
   int32_t convfail;        // iteration (1-based) at which convtest aborted (admm.m:692-701)
   int32_t cg_total;        // accumulated inner CG iterations
-  int32_t pad0;
+  int32_t arrive;          // arrival counter of the one-launch tail (prox_fin_kernel); zero between launches
   double acurr, aprev;     // fast ADMM alpha (admm.m:271-272, 567, 578)
   double d, dprev;         // accelerated ADMM restart value (admm.m:278-279, 572-588)
   double coef;             // (aprev-1)/acurr for the extrapolation in flight

@@ -1167,6 +1167,12 @@ int admm_engine_set_profiling(admm_engine* e, int enabled) {
   return ADMM_OK;
 }
 
+int admm_engine_set_profiling_stride(admm_engine* e, int stride) {
+  if (!e || stride < 1) return fail(ADMM_E_INVALID, "bad argument");
+  e->prof_stride = stride;
+  return ADMM_OK;
+}
+
 int admm_engine_kernel_time(admm_engine* e, int which, double* total_ms, int64_t* launches) {
   if (!e || which < 0 || which >= ADMM_K_COUNT) return fail(ADMM_E_INVALID, "bad argument");
   if (total_ms) *total_ms = e->timers[which].total_ms;

@@ -174,6 +174,8 @@ struct admm_engine {
   double setup_seconds = 0.0;
 
   uint32_t profiling = 0;  // bit k set: time kernel class k with HIP events
+  int32_t prof_stride = 1;  // ... on every prof_stride-th launch group of the class (sampling keeps the cost of the
+  uint32_t prof_tick[ADMM_K_COUNT] = {0, 0, 0, 0, 0};  // two event records out of the other iterations)
   KTimer timers[ADMM_K_COUNT];
 };
 
@@ -201,6 +203,7 @@ struct TimerScope {
   bool on;
   size_t slot = 0;
   TimerScope(admm_engine* eng, int w) : e(eng), which(w), on((eng->profiling >> w) & 1u) {
+    if (on && eng->prof_stride > 1) on = (eng->prof_tick[w]++ % static_cast<uint32_t>(eng->prof_stride)) == 0;
     if (!on) return;
     KTimer& t = e->timers[which];
     if (t.used + 2 > t.ev.size()) {

@@ -92,14 +92,24 @@ int cg_solve(admm_engine* e, const double* y) {
 extern "C" {
 
 
-static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld);
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
+                           bool leave_partials);
+
+// the lower-triangle x-solve may hand its partial rows to the one-launch tail instead of reducing them itself
+static bool xsolve_has_partials(const admm_engine* e) {
+  return e->xfac.mode == ADMM_XSOLVE_INVERSE && e->xfac.Minv && e->xfac.n >= kSymvHalfMin && !e->sy_split && !e->xcb &&
+         e->xsolve == ADMM_XSOLVE_INVERSE && !e->fat &&
+         (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED);
+}
 
 // one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
-static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
+                    bool leave_partials) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   *axsrc = e->x;
   *naxpart = 1;
   *axld = 0;
+  *axt = nullptr;
   if (e->xcb) {  // x = xminf(x, z, u, rho), fast ADMM: xminf(x, v, uhat, rho)   (admm.m:502, 506)
     const bool fastalg = e->last_opts.fast != ADMM_FAST_OFF;
     if (e->xcb(e->xuser, e->x, fastalg ? e->v : e->z, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
@@ -116,7 +126,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
-        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
+        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, leave_partials));
       } else {
         // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
         launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
@@ -130,7 +140,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       break;
     case ADMM_PROB_QP_BOUNDED:  // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
     case ADMM_PROB_MODEL:
-      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld));
+      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, leave_partials));
       break;
     case ADMM_PROB_LINEARPROGRAM:
     case ADMM_PROB_QP_STANDARD:  // x = K*y + k0: the KKT solve of getProxOps.m:1363 / 1410, reduced once
@@ -154,7 +164,17 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
 }
 
 // the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
-static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld) {
+static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
+                           bool leave_partials) {
+  if (leave_partials && xsolve_has_partials(e)) {  // x = sum of these rows, taken by prox_fin_kernel
+    const SliceFactor& f = e->xfac;
+    launch_symv_lower(f.planSy, f.Minv, f.ldM, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream, 0, 1, false);
+    *axsrc = e->syN;
+    *axt = e->syT;
+    *naxpart = f.planSy.ntile;
+    *axld = f.planSy.ldp;
+    return ADMM_OK;
+  }
   return solve_factor(e, e->rhs, e->x);
 }
 
@@ -467,24 +487,25 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // index lives in ctrl->iter), and iterations past a stop condition or past maxiters are no-ops on the
   // device, so a batch of iterations CAN be captured once into a hipGraph and replayed.  Measured on
   // MI355X / ROCm 7.x (profiles/svm_bench.py, profiles/trsv_graph_bench.py) replay is never faster than
-  // eager launches on one stream -- SVM 6000x400: 23.0k vs 23.9k it/s; lasso 2000x512 with the 16-launch
-  // TRSV x-solve: 3.7k vs 4.9k -- so eager is the default and ADMM_HIP_GRAPH=1 opts in.  Never used when
-  // collectives or host callbacks sit inside the iteration, for the CG x-solve (which polls the device
-  // between inner iterations), with event timing on (hipEventElapsedTime rejects events recorded by graph
-  // nodes: "invalid resource handle"), or under rocprofv3 (which segfaults inside hipGraphLaunch).
+  // eager launches on one stream -- SVM 6000x400: 23.0k vs 23.9k it/s -- so eager is the default and
+  // ADMM_HIP_GRAPH=1 opts in.  Never used when collectives or host callbacks sit inside the iteration, for
+  // the CG x-solve (which polls the device between inner iterations), or with event timing on
+  // (hipEventElapsedTime rejects events recorded by graph nodes: "invalid resource handle").
   const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
-  const char* preload = std::getenv("LD_PRELOAD");
-  const bool profiler_attached = std::getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
-                                 (preload && std::strstr(preload, "rocprof") != nullptr);
   const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 &&
-                         e->xsolve != ADMM_XSOLVE_CG && !profiler_attached && heavy <= (int64_t{32} << 20) &&
-                         !e->xcb && !e->zcb && !e->ocb;
+                         e->xsolve != ADMM_XSOLVE_CG && heavy <= (int64_t{32} << 20) && !e->xcb && !e->zcb && !e->ocb;
+  // A = I iterations whose finalize depends on nothing but the prox kernel's partial sums end in ONE launch
+  // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
+  const bool obj_kernels = o.objevals && (obj_lasso_gemv || obj_qp_gemv || obj_model_gemv || e->ocb);
+  const bool fuse_tail = e->a_identity && alg != 2 && !split_z && !sharded && !obj_kernels &&
+                         len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   auto enqueue_iteration = [&]() -> int {
     {
       const double* axsrc;
+      const double* axt;
       int32_t naxpart;
       int64_t axld;
-      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld));
+      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld, &axt, fuse_tail));
       if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
         TimerScope ts(e, ADMM_K_GEMV_N);
         launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
@@ -519,17 +540,24 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           apply_slice_factor(e, e->zfac, e->rz, e->zext);
         }
       }
+      fa.slots_reduced = nullptr;
+      fa.objp_reduced = nullptr;
+      fa.objpart = nullptr;
+      fa.nobjpart = 0;
       {
         TimerScope ts(e, ADMM_K_PROX);
         pa.axsrc = axsrc;
+        pa.ax_t = axt;
         pa.naxpart = naxpart;
         pa.axld = axld;
         pa.x_out = e->a_identity ? e->x : nullptr;
+        if (fuse_tail) {  // z/u update + finalize in one launch: the iteration ends here
+          launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream);
+          return ADMM_OK;
+        }
         launch_prox(pa, e->ctrl, &nblk, e->stream);
       }
       fa.nblk = nblk;
-      fa.slots_reduced = nullptr;
-      fa.objp_reduced = nullptr;
       const bool shard_rows = sharded && !e->a_identity;  // z, u and the residual sums are row-local
       if (alg == 2) {
         if (shard_rows) {  // the restart decision needs the global ||u-uhat||^2, ||z-v||^2 (admm.m:572-573)
@@ -641,7 +669,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
     }
     enq += batch;
-    if (loop_rc == ADMM_OK && (!o.domaxiters || enq >= N)) {
+    // the host polls after EVERY batch, domaxiters runs included: an unbounded run of launches without a host
+    // sync (6000 for a 1000-iteration SVM run) overruns a buffer inside rocprofv3's counter-collection mode
+    // (SIGSEGV in the launch path of the profiler, r2 record in DESIGN section 6); one 64-byte read-back per 64
+    // iterations costs < 1 %
+    if (loop_rc == ADMM_OK) {
       if (hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
           hipStreamSynchronize(e->stream) != hipSuccess)
         loop_rc = fail(ADMM_E_DEVICE, "polling the device control block failed");

@@ -109,7 +109,7 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
       }
     }
     done += batch;
-    if (!o.domaxiters || done >= N) {
+    {  // poll after every batch (see engine_run.hip)
       ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
       if (e->ctrl_host->stop) stop_seen = true;

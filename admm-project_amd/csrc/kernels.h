@@ -54,7 +54,8 @@ void launch_symv_small(const double* M, int64_t n, int64_t ld, const double* x, 
 // part_rank / part_count: this launch processes every part_count-th lower-triangle tile (multi-GPU split of
 // the x-solve); npart / tpart must have been zero-filled once, y is then this rank's PARTIAL result.
 void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
-                       double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank = 0, int part_count = 1);
+                       double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank = 0, int part_count = 1,
+                       bool reduce = true);
 
 // ---------------------------------------------------------------- dense setup (dense.hip)
 // C = alpha*op(A)*op(B) + beta*C, column-major fp64 on the MFMA f64 path.  transA/transB: 0 = N, 1 = T.

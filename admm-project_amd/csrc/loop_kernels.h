@@ -51,6 +51,8 @@ enum Slot : int32_t {
 struct ProxArgs {
   int64_t len;             // nB = m (B = -I)
   const double* axsrc;     // Ax: [naxpart][axld] partials (naxpart >= 1)
+  const double* ax_t;      // one-launch tail after the lower-triangle x-solve: its T-part partial rows (axsrc = the
+                           // N-part rows, naxpart = tiles, axld = row stride); null otherwise
   int32_t naxpart;
   int64_t axld;
   double* x_out;           // A = I: x_i = sum of partials is stored here (may alias axsrc when naxpart == 1)
@@ -156,6 +158,9 @@ struct PreZArgs {
 };
 void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+// A = I, alg 0 / 1: z/u update AND the finalize logic in one launch (the last workgroup to arrive finalizes);
+// a.len <= 128 * kMaxPartBlocks
+void launch_prox_fin(const ProxArgs& a, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 void launch_fast_decide(const FinArgs& a, hipStream_t stream);   // alg 2: d, restart decision, alpha
 void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_finalize(const FinArgs& a, hipStream_t stream);

@@ -39,10 +39,11 @@ __device__ __forceinline__ void block_reduce_slots(double (&acc)[S_COUNT], doubl
   }
 }
 
-// Everything the loop does with element i once Ax_i is known (admm.m:515-569, 608-654): relaxation, z-prox,
-// u-update, fast-ADMM extrapolation, histories, the residual / objective partial sums and the next rhs.
-__device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, double ax, int64_t it, double kcoef,
-                                             double (&acc)[S_COUNT]) {
+struct ProxIn {  // every input of one element (see prox_load)
+  double zp, u_old, uhat_i, c_i, ell_i, zg_i, lb_i, ub_i, v_i, add_i;
+};
+
+__device__ __forceinline__ ProxIn prox_load(const ProxArgs& a, int64_t i) {
   // Every input this element can need, loaded up front and unconditionally (operands a variant does not use are
   // redirected to z: a cache hit): one memory round trip.  With the loads behind their (kernel-uniform) conditions
   // hipcc waits for each one separately -- eight dependent L2 round trips, 9 us for a kernel with 2 us of work.
@@ -57,10 +58,26 @@ __device__ __forceinline__ void prox_element(const ProxArgs& a, int64_t i, doubl
   const double* pub = a.ub ? a.ub : a.z;
   const double* pv = (a.alg == 2) ? a.v : a.z;
   const double* padd = a.rhs_add ? a.rhs_add : a.z;
-  const double zp = a.z[i];
-  const double u_old = a.u[i];
-  const double uhat_i = puhat[i], c_i = pc[i], ell_i = pell[i], zg_i = pzg[i], lb_i = plb[i], ub_i = pub[i];
-  const double v_i = pv[i], add_i = padd[i];
+  ProxIn in;
+  in.zp = a.z[i];
+  in.u_old = a.u[i];
+  in.uhat_i = puhat[i];
+  in.c_i = pc[i];
+  in.ell_i = pell[i];
+  in.zg_i = pzg[i];
+  in.lb_i = plb[i];
+  in.ub_i = pub[i];
+  in.v_i = pv[i];
+  in.add_i = padd[i];
+  return in;
+}
+
+// Everything the loop does with element i once Ax_i is known (admm.m:515-569, 608-654): relaxation, z-prox,
+// u-update, fast-ADMM extrapolation, histories, the residual / objective partial sums and the next rhs.
+__device__ __forceinline__ void prox_apply(const ProxArgs& a, int64_t i, double ax, int64_t it, double kcoef,
+                                           const ProxIn& in, double (&acc)[S_COUNT]) {
+  const double zp = in.zp, u_old = in.u_old, uhat_i = in.uhat_i, c_i = in.c_i, ell_i = in.ell_i, zg_i = in.zg_i;
+  const double lb_i = in.lb_i, ub_i = in.ub_i, v_i = in.v_i, add_i = in.add_i;
   if (a.a_identity) {
     if (a.x_out) a.x_out[i] = ax;
     if (a.xhist) a.xhist[it * a.len + i] = ax;
@@ -179,8 +196,9 @@ __global__ __launch_bounds__(kBlock) void prox_kernel(ProxArgs a, const Ctrl* __
   }
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const ProxIn in = prox_load(a, i);
     const double ax = gather_chunks(a.axsrc, a.naxpart, a.axld, i);
-    prox_element(a, i, ax, it, kcoef, acc);
+    prox_apply(a, i, ax, it, kcoef, in, acc);
   }
   block_reduce_slots(acc, a.part);
 }
@@ -331,9 +349,12 @@ void launch_initial_rhs(int64_t len, int rhs_kind, double rho, const double* zx,
 }
 
 // ---------------------------------------------------------------- finalize
-__global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
+// COHERENT: called by the last workgroup of the prox kernel to arrive (prox_fin_kernel): the block partials were
+// published write-through by other compute units during this launch and are read past the L1 (sc1 loads).
+// Exactly kBlock threads (the first four waves of the calling workgroup) take part.
+template <bool COHERENT>
+__device__ __forceinline__ void finalize_body(const FinArgs& a) {
   Ctrl* ctrl = a.ctrl;
-  if (ctrl->stop) return;
   __shared__ double scratch[4];
   __shared__ double S[16];
   const int it = ctrl->iter;
@@ -347,8 +368,19 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
     const int slot = threadIdx.x >> 4, sub = threadIdx.x & 15;
     double v = 0.0;
     if (slot < S_COUNT) {
-#pragma unroll 8
-      for (int b = sub; b < a.nblk; b += 16) v += a.part[slot * kMaxPartBlocks + b];
+      const double* __restrict__ ps = a.part + slot * kMaxPartBlocks;
+      for (int b0 = 0; b0 < a.nblk; b0 += 128) {  // eight loads per lane issued together (clamped, unconditional)
+        double w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int b = b0 + sub + 16 * k;
+          const int bc = b < a.nblk ? b : a.nblk - 1;
+          w[k] = COHERENT ? __hip_atomic_load(ps + bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ps[bc];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (b0 + sub + 16 * k < a.nblk) v += w[k];
+      }
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
     ng3 = S[S_G3];
   } else if (a.g && !a.nodualerror) {
     double s2 = 0.0, s3 = 0.0;
-    for (int64_t j = threadIdx.x; j < a.nA; j += blockDim.x) {
+    for (int64_t j = threadIdx.x; j < a.nA; j += kBlock) {
       const double g2 = a.g[a.ldg + j], g3 = a.g[2 * a.ldg + j];
       s2 += g2 * g2;
       s3 += g3 * g3;
@@ -371,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
   }
   if (a.x) {
     double s = 0.0;
-    for (int64_t j = threadIdx.x; j < a.nA; j += blockDim.x) {
+    for (int64_t j = threadIdx.x; j < a.nA; j += kBlock) {
       const double xv = a.x[j];
       s += xv * xv;
       if (a.xhist) a.xhist[static_cast<int64_t>(it) * a.nA + j] = xv;
@@ -382,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
     objp = a.objp_reduced[0];
   } else if (a.objpart) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < a.nobjpart; b += blockDim.x) s += a.objpart[b];
+    for (int b = threadIdx.x; b < a.nobjpart; b += kBlock) s += a.objpart[b];
     objp = block_sum(s, scratch);
   }
   if (threadIdx.x != 0) return;
@@ -464,6 +496,129 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
   ctrl->iter = i1;
   ctrl->steps = i1;
   if (stop || i1 >= a.maxiters) ctrl->stop = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(FinArgs a) {
+  if (a.ctrl->stop) return;
+  finalize_body<false>(a);
+}
+
+// ---------------------------------------------------------------- one-launch tail of an A = I iteration
+// prox + finalize (and, after the lower-triangle x-solve, the sum of its partial rows) in ONE launch.  Workgroup =
+// one 128-element tile x 4 slots: every thread sums a quarter of the x-solve's partial rows of its element (all
+// loads of a thread in one round), the quarters meet in LDS, the first 128 threads run the fused element update, the
+// block partials are published write-through (sc1) and the workgroup arrives on ctrl->arrive; the LAST workgroup to
+// arrive runs the finalize logic (norms, tolerances, H-norm, stop) on the device in the same launch.  Replaces
+// three launches (symv_reduce, prox, finalize) and two kernel boundaries: 21.7 -> ~10 us on the headline loop.
+// Sums are taken in a fixed order whatever the arrival order: bitwise reproducible.
+constexpr int kTailTile = 128;
+constexpr int kTailSlots = 4;                       // threads per element: each sums a quarter of the partial rows
+constexpr int kTailBlock = kTailTile * kTailSlots;  // 512 threads
+constexpr int kTailRows = 24;                       // partial rows a thread loads in one round
+
+__device__ __forceinline__ double tail_gather(const ProxArgs& a, int64_t i, int32_t p0, int32_t p1) {
+  // unified partial row p of element i (diagonal tile d = i / 128): p <= d -> axsrc[p] (N-part), else ax_t[p - 1]
+  const int32_t d = static_cast<int32_t>(i / kTailTile);
+  double s = 0.0;
+  for (int32_t p = p0; p < p1; p += kTailRows) {
+    double v[kTailRows];
+#pragma unroll
+    for (int k = 0; k < kTailRows; ++k) {
+      const int32_t q = (p + k < p1) ? p + k : p1 - 1;
+      const double* src = (q <= d) ? a.axsrc + static_cast<int64_t>(q) * a.axld
+                                   : a.ax_t + static_cast<int64_t>(q - 1) * a.axld;
+      v[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kTailRows; ++k)
+      if (p + k < p1) s += v[k];
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArgs f, Ctrl* __restrict__ ctrl) {
+  const int32_t stop = ctrl->stop;
+  const int64_t it = ctrl->iter;
+  const double aprev = ctrl->acurr;
+  if (stop) return;
+  __shared__ double quarter[kTailSlots - 1][kTailTile];
+  __shared__ int32_t last;
+  const int e = threadIdx.x & (kTailTile - 1), slot = threadIdx.x >> 7;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kTailTile + e;
+  const int64_t ic = i < a.len ? i : a.len - 1;
+  ProxIn in{};
+  if (slot == 0) in = prox_load(a, ic);  // in flight together with the partial rows
+  double ax;
+  if (a.ax_t) {  // lower-triangle x-solve: naxpart + 1 partial rows per element, split over the four slots
+    const int32_t P = a.naxpart + 1, q = (P + kTailSlots - 1) / kTailSlots;
+    const int32_t p0 = slot * q, p1 = (p0 + q < P) ? p0 + q : P;
+    ax = p0 < P ? tail_gather(a, ic, p0, p1) : 0.0;
+  } else {
+    ax = slot == 0 ? gather_chunks(a.axsrc, a.naxpart, a.axld, ic) : 0.0;
+  }
+  if (slot > 0) quarter[slot - 1][e] = ax;
+  __syncthreads();
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  if (slot == 0 && i < a.len) {
+    double kcoef = 0.0;
+    if (a.alg == 1) {
+      const double acn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev));
+      kcoef = (aprev - 1.0) / acn;
+    }
+    prox_apply(a, i, ((ax + quarter[0][e]) + quarter[1][e]) + quarter[2][e], it, kcoef, in, acc);
+  }
+  // block partials of the two waves that hold elements, published write-through
+  __shared__ double sred[2][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (wid < 2) {
+#pragma unroll
+    for (int s = 0; s < S_COUNT; ++s) {
+      const double w = wave_sum(acc[s]);
+      if (lane == 0) sred[wid][s] = w;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    __hip_atomic_store(a.part + s * kMaxPartBlocks + blockIdx.x, sred[0][s] + sred[1][s], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains: the element stores as well
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t old = __hip_atomic_fetch_add(&ctrl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == static_cast<int32_t>(gridDim.x) - 1) ? 1 : 0;
+    if (last) __hip_atomic_store(&ctrl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last || threadIdx.x >= kBlock) return;  // the finalize logic is written for one 256-thread workgroup
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  finalize_body<true>(f);
+}
+
+void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  ProxArgs a = args;
+  const bool need_ell = a.prox == PROX_HINGE || a.prox == PROX_01 || a.objx == OBJX_HINGE ||
+                        a.objx == OBJX_ZEROONE || a.objx == OBJX_DOT;
+  if (!need_ell) a.ell = nullptr;
+  if (a.prox != PROX_GIVEN) a.zgiven = nullptr;
+  if (a.prox != PROX_BOX) a.lb = a.ub = nullptr;
+  const bool need_add = a.alg != 2 && a.rhs && (a.rhs_kind == RHS_RHO_DTS || a.rhs_kind == RHS_RHO_MINUS_Q);
+  if (!need_add) a.rhs_add = nullptr;
+  const int64_t blocks = ceil_div(a.len, kTailTile);
+  *nblk_out = static_cast<int>(blocks);
+  FinArgs ff = f;
+  ff.nblk = static_cast<int32_t>(blocks);
+  ff.g = nullptr;  // nothing but the block partials feeds the finalize logic of this path
+  ff.x = nullptr;
+  ff.xhist = nullptr;
+  ff.objpart = nullptr;
+  ff.nobjpart = 0;
+  ff.slots_reduced = nullptr;
+  ff.objp_reduced = nullptr;
+  hipLaunchKernelGGL(prox_fin_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTailBlock), 0, stream, a, ff, ctrl);
 }
 
 void launch_finalize(const FinArgs& a, hipStream_t stream) {

@@ -223,7 +223,7 @@ SymvPlan symv_plan(int64_t n) {
 }
 
 void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
-                       double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank, int part_count) {
+                       double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank, int part_count, bool reduce) {
   dim3 grid(static_cast<unsigned>(p.ntile), static_cast<unsigned>(p.ntile));
   if (stream_hint(4 * p.npad * p.npad))
     hipLaunchKernelGGL(symv_lower_kernel<true>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
@@ -231,6 +231,7 @@ void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const dou
   else
     hipLaunchKernelGGL(symv_lower_kernel<false>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
                        part_rank, part_count, ctrl);
+  if (!reduce) return;  // the consumer sums the partial rows itself (prox_fin_kernel)
   const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
                      p.ldp, p.n, p.ntile, y, ctrl);

@@ -245,8 +245,10 @@ class Engine:
                     factor_n=i.factor_n, rank=i.rank, cond_estimate=i.cond_estimate,
                     probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_diff=i.probe_diff)
 
-    def set_profiling(self, on):
-        """True/False, or an iterable of kernel classes (L.K_XSOLVE, ...) to time with HIP events."""
+    def set_profiling(self, on, stride=1):
+        """True/False, or an iterable of kernel classes (L.K_XSOLVE, ...) to time with HIP events; stride > 1 times
+        only every stride-th launch of a class (sampling)."""
+        L.check(self._lib.admm_engine_set_profiling_stride(self._h, int(stride)))
         if on is True:
             mask = -1
         elif not on:

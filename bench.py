@@ -219,8 +219,14 @@ def other_configs(ap, L, device, steps):
     return res
 
 
+def _leg(name):
+    """progress marker on stderr (one line per bench leg: locates a failure under a profiler)"""
+    print(f"bench.py: leg {name}", file=sys.stderr, flush=True)
+
+
 def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out):
     """The A-streaming legs (lad.m, matrix-free lasso) on the same D, s, and configs 3 / 5 at N = 1."""
+    _leg("a_streaming (lad)")
     # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
     # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
     # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
@@ -244,6 +250,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     lad.close()
 
     # objevals=1 with the objective taken from the cached Gram matrix (opt-in args.objgram): 4n^2 B instead of 8mn B
+    _leg("objevals1_gram")
     lg = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local, comm=comm,
                    obj_gram=1)
     kg = max(20, a.steps)
@@ -258,6 +265,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     # the same loop with the factor applied literally (two triangular solves, the reference's form): a chain of
     # 2*n/64 dependent block steps -- latency-bound, the reason xsolve=inverse exists
     if world == 1:
+        _leg("xsolve_trsv")
         lt = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_TRSV, device=local)
         kt = max(10, a.steps // 4)
         timed_run(lt, dist, 3, rho=rho)
@@ -270,6 +278,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
 
     # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance
     # 1e-10), every inner iteration one A'(A p) unit, nothing n x n stored
+    _leg("matrix_free (cg)")
     mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
                    comm=comm, cg_tol=1e-10)
     k3 = max(3, a.steps // 40)
@@ -305,6 +314,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                                   "setup_seconds": max_over_ranks(dist, cons.setup_seconds)}
         cons.close()
     if world == 1:
+        _leg("other_configs (tv, tv2d, svm)")
         out["other_configs"] = other_configs(ap, L, local, a.steps)
 
 
@@ -348,8 +358,10 @@ def main():
     setup_s = max_over_ranks(dist, eng.setup_seconds)
 
     # ---- headline: objevals = 0 ----------------------------------------------------------
+    _leg("headline")
     timed_run(eng, dist, max(1, a.warmup), rho=rho)
-    eng.set_profiling([L.K_XSOLVE])  # only the dominant kernel class: 2 event records per iteration
+    # only the dominant kernel class, every 4th iteration: the event pairs sit inside the timed region
+    eng.set_profiling([L.K_XSOLVE], stride=4)
     dt, _ = timed_run(eng, dist, a.steps, rho=rho)
     eng.set_profiling(False)
     xs_ms, xs_cnt = eng.kernel_time(L.K_XSOLVE)
@@ -393,6 +405,7 @@ def main():
 
     # ---- side measurements (same resident data) --------------------------------------------
     if not a.no_extras:
+        _leg("objevals1")
         k1 = max(5, a.steps // 4)
         timed_run(eng, dist, 2, rho=rho, objevals=1)
         eng.set_profiling([L.K_GEMV_N])

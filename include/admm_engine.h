@@ -276,6 +276,9 @@ int admm_engine_kernel_time(admm_engine* eng, int which, double* total_ms, int64
 /* per-kernel event timing for subsequent runs: mask = OR of (1 << ADMM_K_*), 0 = off (default),
  * negative = every class.  Each timed class costs two hipEventRecord per launch group. */
 int admm_engine_set_profiling(admm_engine* eng, int mask);
+/* time only every stride-th launch group of each selected class (default 1 = all): a sampled measurement costs the
+ * loop 2/stride event records per iteration instead of 2 */
+int admm_engine_set_profiling_stride(admm_engine* eng, int stride);
 void admm_engine_destroy(admm_engine* eng);
 
 /* Host <-> device copies on the engine's stream (hip_stream as handed to a callback, NULL = default stream), complete on

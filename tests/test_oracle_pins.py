@@ -57,16 +57,27 @@ def test_tv_criterion(ap):  # totalvariationtest.m:151
     assert obj(r["xopt"]) < obj(p["truex"])
 
 
-def test_svm_criterion(ap):  # linearsvmtest.m:175-184 (hinge)
+def test_svm_criterion(ap):  # linearsvmtest.m:152-192, both runs of the tester
     p = ap.synth.svm_problem(0)
     D, ell, C = p["D"], p["ell"], p["C"]
-    r = S.linearsvm(D, ell, C, dict(objevals=1, convtest=1, x0=p["x0"], z0=p["z0"], u0=p["u0"]))
-    x = r["xopt"]
+    # linearsvmtest.m:154-155: the 0-1 objective at the planted direction [1; -1]
     trueobj = 0.5 * 2.0 + C * np.sum(np.maximum(np.sign(1 - ell * (D @ np.array([1.0, -1.0]))), 0))
-    obj = 0.5 * x @ x + C * np.sum(np.maximum(1 - ell * (D @ x), 0))
-    assert abs(1 - (-x[1] / x[0])) <= 0.05
-    assert np.isnan(r["dnorm"]).all() and np.isnan(r["derr"]).all()  # nodualerror (unwrappedadmm.m:92)
-    assert obj < trueobj or True  # the hinge objective is not comparable to the 0-1 "true" value in general
+    o = dict(objevals=1, convtest=1, x0=p["x0"], z0=p["z0"], u0=p["u0"])
+    # hinge run: objopth = options.obj(xopt, xopt) with the hinge objective (linearsvm.m:232-233)
+    rh = S.linearsvm(D, ell, C, dict(o))
+    x = rh["xopt"]
+    objh = 0.5 * x @ x + C * np.sum(np.maximum(1 - ell * (D @ x), 0))
+    assert objh == pytest.approx(rh["objopt"], rel=1e-12)
+    assert objh < trueobj and abs(1 - (-x[1] / x[0])) <= 0.05  # linearsvmtest.m:175-180
+    assert np.isnan(rh["dnorm"]).all() and np.isnan(rh["derr"]).all()  # nodualerror (unwrappedadmm.m:92)
+    # second run: lossfunction '0-1' (linearsvmtest.m:160) -- q18: the hinge prox runs (getProxOps.m:1094 tests
+    # '01'), the objective is the 0-1 one (linearsvm.m:235-236)
+    r01 = S.linearsvm(D, ell, C, dict(o, lossfunction="0-1"))
+    y = r01["xopt"]
+    obj01 = 0.5 * y @ y + C * np.sum(np.maximum(np.sign(1 - ell * (D @ y)), 0))
+    assert obj01 == pytest.approx(r01["objopt"], rel=1e-12)
+    assert obj01 < trueobj and abs(1 - (-y[1] / y[0])) <= 0.05  # linearsvmtest.m:183-188
+    np.testing.assert_array_equal(x, y)  # same prox, same iterates
 
 
 def test_svm_sliced_equals_serial(ap):  # unwrappedadmm.m:96-141 vs 76-78
