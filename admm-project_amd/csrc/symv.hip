@@ -14,6 +14,9 @@
 // loads are issued before the reduction of the current one.
 // Partials (npart per 128-column group, tpart per 128-row wave chunk) are added by a second small
 // kernel in a fixed order: bitwise reproducible, no float atomics.
+// (r2: 8-column panels -- 16 loads in flight, a three-level reduce-scatter ending in row_half_mirror -- measured
+// slower than this 4-column form: 78.4 vs 76.5 us event-timed per pass.  A pure N-part pass over the same tiles,
+// tri_step_kernel in trsv.hip, streams at 6.0 TB/s, so the T-part's cross-lane work is what holds this kernel at 5.4.)
 #include "kernels.h"
 
 namespace admm {
