@@ -28,7 +28,8 @@ FAST_OFF, FAST_STRONG, FAST_WEAK = 0, 1, 2
 
 # fetch fields
 (F_XOPT, F_ZOPT, F_UOPT, F_XVALS, F_ZVALS, F_UVALS, F_PNORM, F_DNORM, F_PERR, F_DERR, F_OBJEVALS, F_HNORMSQ,
- F_AVALS, F_DVALS, F_RESTARTED, F_VVALS, F_UHATVALS, F_ZCONSENSUS, F_FACTOR, F_CG_ITERS) = range(1, 21)
+ F_AVALS, F_DVALS, F_RESTARTED, F_VVALS, F_UHATVALS, F_ZCONSENSUS, F_FACTOR, F_CG_ITERS, F_CONS_X,
+ F_CONS_U) = range(1, 23)
 
 K_XSOLVE, K_GEMV_N, K_GEMV_T, K_PROX, K_FINALIZE, K_COUNT = 0, 1, 2, 3, 4, 5
 COMM_ID_BYTES = 128
@@ -128,6 +129,10 @@ _SIGNATURES = {
     "admm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "admm_comm_allreduce_sum": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
     "admm_comm_destroy": (None, [C.c_void_p]),
+    "admm_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "admm_engine_create_all": (C.c_int, [C.c_int, C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
+    "admm_engine_run_all": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(Options), C.c_int,
+                                      C.POINTER(RunSummary)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -61,8 +61,8 @@ struct ConsArgs {
 
 void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, const double* Dts, double* y,
                      const Ctrl* ctrl, hipStream_t stream);
-void launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
-                     const Ctrl* ctrl, hipStream_t stream);
+int launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
+                    const double* center, double* qpart, const Ctrl* ctrl, hipStream_t stream);
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 
 }  // namespace admm

@@ -26,29 +26,49 @@ void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, co
 }
 
 // sums[0][i] = sum_k x_k[i], sums[1][i] = sum_k u_k[i]   (getProxOps.m:1281-1284, slice order)
+// qpart (sharded runs, else null): block partials of q = sum_k ||x_k - c||^2 about the PREVIOUS mean c = xaveprev,
+// which every rank knows before the exchange.  With it lassonorms' first value (getProxOps.m:1338-1340)
+//     sum_k ||x_k - xave||^2 = q - N*||xave - c||^2
+// needs no second collective: q travels in the tail of the vector all-reduce, and ||xave - c||^2 is the dual
+// residual sum every rank computes anyway.  Both terms shrink together as the iteration converges, so the
+// subtraction loses about a digit (the naive sum ||x_k||^2 - N||xave||^2 would lose all of them).
 __global__ __launch_bounds__(kBlock) void cons_sum_kernel(int64_t n, int64_t ldn, int32_t K,
                                                           const double* __restrict__ X,
                                                           const double* __restrict__ U, double* __restrict__ sums,
+                                                          const double* __restrict__ center,
+                                                          double* __restrict__ qpart,
                                                           const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  double q = 0.0;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
     double sx = 0.0, su = 0.0;
+    const double c = qpart ? center[i] : 0.0;
     for (int32_t k = 0; k < K; ++k) {
+      const double xk = X[k * ldn + i];
       su = su + U[k * ldn + i];
-      sx = sx + X[k * ldn + i];
+      sx = sx + xk;
+      const double d = xk - c;
+      q = __builtin_fma(d, d, q);
     }
     sums[i] = sx;
     sums[ldn + i] = su;
   }
+  if (qpart) {
+    const double t = block_sum(q, scratch);
+    if (threadIdx.x == 0) qpart[blockIdx.x] = t;
+  }
 }
 
-void launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
-                     const Ctrl* ctrl, hipStream_t stream) {
+// returns the number of qpart blocks written (0 when qpart is null)
+int launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
+                    const double* center, double* qpart, const Ctrl* ctrl, hipStream_t stream) {
   int64_t blocks = ceil_div(n, kBlock);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
   hipLaunchKernelGGL(cons_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, n, ldn, K, X, U,
-                     sums, ctrl);
+                     sums, center, qpart, ctrl);
+  return qpart ? static_cast<int>(blocks) : 0;
 }
 
 // z-update + per-slice u-update + every partial sum admm / lassonorms need:

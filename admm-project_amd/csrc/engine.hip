@@ -975,7 +975,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       const size_t K = static_cast<size_t>(desc->nslices);
       E_TRY(e->mem.alloc(&e->cX, K * e->cldn));
       E_TRY(e->mem.alloc(&e->cU, K * e->cldn));
-      E_TRY(e->mem.alloc(&e->csums, 2 * e->cldn));
+      E_TRY(e->mem.alloc(&e->csums, 2 * e->cldn + 2));  // + the packed scalar of the one-collective exchange
       E_TRY(e->mem.alloc(&e->czc, e->cldn));
       E_TRY(e->mem.alloc(&e->cxave, e->cldn));
       E_TRY(e->mem.alloc(&e->cxaveprev, e->cldn));
@@ -1092,6 +1092,17 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
       src = e->czc;
       count = e->nA;
       break;
+    case ADMM_F_CONS_X:
+    case ADMM_F_CONS_U: {
+      if (e->problem != ADMM_PROB_LASSO_CONSENSUS) return fail(ADMM_E_INVALID, "field exists only for consensus lasso");
+      const size_t K = e->cslices.size();
+      count = static_cast<size_t>(e->nA) * K;
+      if (cap < count) return fail(ADMM_E_CAPACITY, "destination too small");
+      ADMM_HIP_TRY(hipMemcpy2D(dst, e->nA * sizeof(double), field == ADMM_F_CONS_X ? e->cX : e->cU,
+                               e->cldn * sizeof(double), e->nA * sizeof(double), K, hipMemcpyDeviceToHost));
+      if (written) *written = count;
+      return ADMM_OK;
+    }
     case ADMM_F_FACTOR: {
       if (!e->F) return fail(ADMM_E_INVALID, "problem has no cached factor");
       count = static_cast<size_t>(e->nF) * e->nF;

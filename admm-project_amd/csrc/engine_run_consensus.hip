@@ -70,8 +70,14 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
           apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
         }
       }
-      launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->ctrl, e->stream);
-      if (shard) ADMM_TRY(comm_allreduce_device(e->comm, e->csums, static_cast<size_t>(2 * ldn), e->stream));  // X1
+      if (shard) {
+        // X1 + X2 in ONE collective: [sum x_k; sum u_k; q] with q = sum_k ||x_k - xave_prev||^2 (consensus.hip)
+        const int nq = launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->cxave, e->objpart, e->ctrl, e->stream);
+        launch_pack_sum(e->objpart, nq, e->csums + 2 * ldn, e->ctrl, e->stream);
+        ADMM_TRY(comm_allreduce_device(e->comm, e->csums, static_cast<size_t>(2 * ldn + 1), e->stream));
+      } else {
+        launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, nullptr, nullptr, e->ctrl, e->stream);
+      }
       int nblk = 1;
       {
         TimerScope ts(e, ADMM_K_PROX);
@@ -94,14 +100,15 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
         fa.objpart = e->cobjpart;
         fa.nobjpart = K * kMaxPartBlocks;
       }
-      if (shard) {  // X2: only sum_k ||x_k - xave||^2 and the objective are rank-local sums
-        launch_pack_slots(e->part, nblk, e->red, e->ctrl, e->stream);
-        ADMM_HIP_TRY(hipMemcpyAsync(e->red + 16, e->red + S_R2, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        if (o.objevals) launch_pack_sum(e->cobjpart, K * kMaxPartBlocks, e->red + 17, e->ctrl, e->stream);
-        ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 2, e->stream));
-        ADMM_HIP_TRY(hipMemcpyAsync(e->red + S_R2, e->red + 16, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        fa.slots_reduced = e->red;
-        if (o.objevals) fa.objp_reduced = e->red + 17;
+      if (shard) {
+        // every slot the finalize logic reads is either identical on all ranks (means, dual sums) or comes from q;
+        // only the objective 0.5*sum_k ||D_k*xave - s_k||^2 (objevals) is a rank-local sum that needs its own exchange
+        fa.cons_q = e->csums + 2 * ldn;
+        if (o.objevals) {
+          launch_pack_sum(e->cobjpart, K * kMaxPartBlocks, e->red + 17, e->ctrl, e->stream);
+          ADMM_TRY(comm_allreduce_device(e->comm, e->red + 17, 1, e->stream));
+          fa.objp_reduced = e->red + 17;
+        }
       }
       {
         TimerScope ts(e, ADMM_K_FINALIZE);

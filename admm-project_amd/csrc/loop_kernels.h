@@ -124,6 +124,8 @@ struct FinArgs {
   int32_t dual_from_slots;  // dual norms come from S_G2/S_G3 (stencil operators) instead of g
   int32_t specialnorms;     // consensus lasso: pnorm/dnorm are lassonorms' squared sums (q10)
   int32_t nslices_total;    // slicenum over all ranks
+  const double* cons_q;     // sharded consensus lasso: sum over ALL slices of ||x_k - xave_prev||^2 (consensus.hip);
+                            // lassonorms' first value is *cons_q - N*S_G2 instead of the rank-local S_R2
   // row-sharded runs: sums already reduced over blocks AND ranks (all-reduced), else null
   const double* slots_reduced;  // [16]
   const double* objp_reduced;   // [1]

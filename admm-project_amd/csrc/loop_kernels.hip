@@ -451,7 +451,8 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     }
     // options.specialnorms (admm.m:612-616) = lassonorms (getProxOps.m:1335-1343): both values are
     // SQUARED sums (q10): sum_k ||x_k - xave||^2 and N*rho^2*||xave - xaveprev||^2
-    const double pn = a.specialnorms ? S[S_R2] : sqrt(S[S_R2]);
+    double pn = a.specialnorms ? S[S_R2] : sqrt(S[S_R2]);
+    if (a.specialnorms && a.cons_q) pn = fmax(a.cons_q[0] - static_cast<double>(a.nslices_total) * S[S_G2], 0.0);
     double dn, de;
     if (a.specialnorms) {
       dn = static_cast<double>(a.nslices_total) * (a.rho * a.rho) * S[S_G2];

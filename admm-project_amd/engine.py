@@ -21,7 +21,7 @@ class Engine:
                  lam=0.0, Cval=0.0, r=0.0, rho=1.0, loss=L.LOSS_HINGE, userelax=0, xsolve=L.XSOLVE_AUTO,
                  device=0, slices=None, comm=None, nvec=None, cg_tol=None, cg_maxit=None,
                  Q=None, qz=None, D2=None, s2=None, c=None, K=None, k0=None, shape=None, obj_gram=0,
-                 Dplus=None, Dts=None):
+                 Dplus=None, Dts=None, _defer=None):
         lib = L.load()
         L.require_device()
         d = L.ProblemDesc()
@@ -122,10 +122,18 @@ class Engine:
         if comm is not None:
             d.comm = comm.handle
         self._comm = comm
+        self._lib = lib
+        if _defer is not None:  # Engine.create_all: the native call creates every rank's engine at once
+            _defer.append((self, d, keep))
+            return
         h = C.c_void_p()
         L.check(lib.admm_engine_create(C.byref(d), C.byref(h)))
+        self._attach(h, d)
+        del keep
+
+    def _attach(self, h, d):
+        problem = int(d.problem)
         self._h = h
-        self._lib = lib
         self.problem = problem
         self.m, self.n = int(d.m), int(d.n)
         # lengths of x and of z, u (admm.m: nA, nB): the A = D problems constrain D*x - z = c
@@ -137,7 +145,37 @@ class Engine:
         self._cb_keep = None
         self._cb_error = None
         self._relax = 1.0
-        del keep
+
+    # ------------------------------------------------------------------ one process, several ranks
+    @classmethod
+    def create_all(cls, problem, per_rank_kwargs):
+        """One engine per rank of a ``parallel.LocalGroup`` in THIS process (admm_engine_create_all): each dict holds
+        that rank's rows and its ``comm``.  The native call runs the blocking per-rank creates on threads of its own."""
+        pending = []
+        engines = [cls(problem, _defer=pending, **kw) for kw in per_rank_kwargs]
+        n = len(engines)
+        descs = (L.ProblemDesc * n)(*[d for _, d, _ in pending])
+        handles = (C.c_void_p * n)()
+        L.check(L.load().admm_engine_create_all(n, descs, handles))
+        for (eng, d, _), h in zip(pending, handles):
+            eng._attach(C.c_void_p(h), d)
+        return engines
+
+    @staticmethod
+    def run_all(engines, **kw):
+        """The same run on every rank's engine (admm_engine_run_all); x0 / z0 / u0 may be per-rank lists."""
+        n = len(engines)
+        opts = (L.Options * n)()
+        keep = []
+        for r, eng in enumerate(engines):
+            kr = {k: (v[r] if k in ("x0", "z0", "u0") and isinstance(v, (list, tuple)) else v) for k, v in kw.items()}
+            opts[r] = eng._options(keep, **kr)
+        handles = (C.c_void_p * n)(*[e._h for e in engines])
+        sums = (L.RunSummary * n)()
+        L.check(L.load().admm_engine_run_all(n, handles, opts, 1, sums))
+        for r, eng in enumerate(engines):
+            eng.last = sums[r]
+        return list(sums)
 
     # ------------------------------------------------------------------ caller-supplied prox operators
     def set_callbacks(self, xmin=None, zmin=None, obj=None):
@@ -269,6 +307,26 @@ class Engine:
             convtol=1e-10, stopcond="standard", nodualerror=0, abstol=1e-5, reltol=1e-3, Hnormtol=1e-6,
             restart=0.999, dvaltol=1e-8, record_history=1, check_every=0, x0=None, z0=None, u0=None,
             stale_factor_ok=0):
+        keep = []
+        o = self._options(keep, rho=rho, maxiters=maxiters, domaxiters=domaxiters, relax=relax, fast=fast,
+                          objevals=objevals, convtest=convtest, convtol=convtol, stopcond=stopcond,
+                          nodualerror=nodualerror, abstol=abstol, reltol=reltol, Hnormtol=Hnormtol, restart=restart,
+                          dvaltol=dvaltol, record_history=record_history, check_every=check_every, x0=x0, z0=z0, u0=u0,
+                          stale_factor_ok=stale_factor_ok)
+        s = L.RunSummary()
+        self._cb_error = None
+        rc = self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s))
+        if rc != L.OK and self._cb_error is not None:  # a Python prox callback raised: surface ITS exception
+            exc, self._cb_error = self._cb_error, None
+            raise exc
+        L.check(rc)
+        self.last = s
+        return s
+
+    def _options(self, keep, *, rho=1.0, maxiters=1000, domaxiters=0, relax=1.0, fast=L.FAST_OFF, objevals=0,
+                 convtest=0, convtol=1e-10, stopcond="standard", nodualerror=0, abstol=1e-5, reltol=1e-3,
+                 Hnormtol=1e-6, restart=0.999, dvaltol=1e-8, record_history=1, check_every=0, x0=None, z0=None,
+                 u0=None, stale_factor_ok=0):
         o = L.Options()
         self._lib.admm_options_default(C.byref(o))
         o.rho, o.relax, o.abstol, o.reltol = float(rho), float(relax), float(abstol), float(reltol)
@@ -283,22 +341,13 @@ class Engine:
         o.record_history = int(bool(record_history))
         o.check_every = int(check_every)
         o.stale_factor_ok = int(bool(stale_factor_ok))
-        keep = []
         for name, val in (("x0", x0), ("z0", z0), ("u0", u0)):
             if val is not None:
                 a = _f64(val).reshape(-1)
                 keep.append(a)
                 setattr(o, name, L.as_dp(a))
-        s = L.RunSummary()
         self._relax = float(relax)
-        self._cb_error = None
-        rc = self._lib.admm_engine_run(self._h, C.byref(o), C.byref(s))
-        if rc != L.OK and self._cb_error is not None:  # a Python prox callback raised: surface ITS exception
-            exc, self._cb_error = self._cb_error, None
-            raise exc
-        L.check(rc)
-        self.last = s
-        return s
+        return o
 
     def fetch(self, field, count, shape=None):
         out = np.empty(int(count), dtype=np.float64)

@@ -21,7 +21,7 @@ import numpy as np
 from . import _lib as L
 from .errorcheck import rank_rows
 
-__all__ = ["Comm", "unique_id", "init_from_torch", "my_rows", "gather_rows"]
+__all__ = ["Comm", "LocalGroup", "unique_id", "init_from_torch", "my_rows", "gather_rows"]
 
 
 def unique_id():
@@ -59,6 +59,58 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+class LocalGroup:
+    """``nranks`` communicators of one group inside THIS process (admm_comm_init_all): the single-process deployment,
+    one host driving several GPUs as a MATLAB session with the MEX gateway does (the reference opens its pool from
+    one session: admm.m:347-356).  ``devices[r]`` is rank r's HIP device; with the ``shm`` transport the same device
+    may serve several ranks (how a one-GPU box rehearses 8 ranks).  Use with ``Engine.create_all`` / ``Engine.run_all``
+    or run the ordinary per-rank solvers on threads with ``on_ranks``."""
+
+    def __init__(self, nranks, devices=None, transport="shm"):
+        devices = list(devices) if devices is not None else [0] * int(nranks)
+        if len(devices) != int(nranks):
+            raise ValueError("one device per rank")
+        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM}[transport]
+        dev = (C.c_int * int(nranks))(*devices)
+        hs = (C.c_void_p * int(nranks))()
+        L.check(L.load().admm_comm_init_all(int(nranks), dev, tr, hs))
+        self.comms = []
+        for r in range(int(nranks)):
+            c = Comm.__new__(Comm)
+            c.handle = C.c_void_p(hs[r])
+            c.rank, c.nranks, c.device, c.transport = r, int(nranks), int(devices[r]), transport
+            self.comms.append(c)
+        self.nranks = int(nranks)
+
+    def on_ranks(self, fn):
+        """fn(rank, comm) on one Python thread per rank (the ctypes calls release the GIL and block inside the
+        collectives, as the native *_all entry points do); returns the results in rank order."""
+        import threading
+
+        out, err = [None] * self.nranks, [None] * self.nranks
+
+        def body(r):
+            try:
+                out[r] = fn(r, self.comms[r])
+            except BaseException as exc:  # noqa: BLE001 -- reported to the caller below
+                err[r] = exc
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.nranks)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        for c in self.comms:
+            c.close()
+        self.comms = []
 
 
 def init_from_torch(dist, device=0, transport="rccl"):

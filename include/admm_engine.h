@@ -221,7 +221,9 @@ enum {
   ADMM_F_VVALS = 16, ADMM_F_UHATVALS = 17,
   ADMM_F_ZCONSENSUS = 18, /* consensus lasso: the true consensus z (the z handed to admm is 0, q9) */
   ADMM_F_FACTOR = 19,     /* n x n (or m x m, fat lasso) lower Cholesky factor */
-  ADMM_F_CG_ITERS = 20    /* ADMM_XSOLVE_CG: inner iterations used per x-update */
+  ADMM_F_CG_ITERS = 20,   /* ADMM_XSOLVE_CG: inner iterations used per x-update */
+  ADMM_F_CONS_X = 21,     /* consensus lasso: the local slices' x_k, n x K column-major (closure state xi{k}, getProxOps.m:1247) */
+  ADMM_F_CONS_U = 22      /* consensus lasso: the local slices' u_k (closure state ui{k}, getProxOps.m:1296) */
 };
 
 /* ---- library ---------------------------------------------------------------- */
@@ -321,6 +323,19 @@ int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int 
 int admm_comm_info(admm_comm* comm, int* rank, int* nranks, int* transport);
 int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count); /* host convenience/test */
 void admm_comm_destroy(admm_comm* comm);
+
+/* One host process driving several GPUs (a MATLAB session with a MEX gateway; the reference opens its pool from one
+ * session: admm.m:347-356, unwrappedadmm.m:47).  The engines are the per-rank engines above; these calls run every
+ * rank's create / run on a host thread of its own (each blocks inside its collectives) and join them.
+ *   comm_init_all : nranks communicators of one group inside this process, comms[r] on devices[r] (the same device
+ *                   may appear more than once with ADMM_COMM_SHM)
+ *   create_all    : descs[r].comm = comms[r], descs[r].device = devices[r], each with its rows (slicemaker order)
+ *   run_all       : opts[0] for every rank (opts_per_rank = 0) or opts[r]; summaries may be NULL
+ * On failure the message of the first failing rank is the caller's admm_last_error(). */
+int admm_comm_init_all(int nranks, const int* devices, int transport, admm_comm** comms);
+int admm_engine_create_all(int nranks, const admm_problem_desc* descs, admm_engine** engines);
+int admm_engine_run_all(int nranks, admm_engine* const* engines, const admm_options* opts, int opts_per_rank,
+                        admm_run_summary* summaries);
 
 #ifdef __cplusplus
 }

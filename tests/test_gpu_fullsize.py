@@ -154,3 +154,51 @@ def test_tv2d_4096x4096_identities(gpu, xsolve):
     assert _rel(zv, _soft(uv0 + dv, lam / rho)) < 1e-11
     assert r["objopt"] == pytest.approx(0.5 * np.sum((X - img) ** 2) + lam * (np.abs(dv).sum() + np.abs(dh).sum()),
                                         rel=1e-10)
+
+
+def test_consensus_lasso_config4_full_size_as_8_local_slices(gpu, big):
+    """BASELINE config 4 at full size -- D 100000 x 10000 split by slicemaker(0, 8, 100000) into 8 slices of
+    12500 x 10000 (lasso.m:196-208) -- as 8 LOCAL slices of one engine on one GPU.  Checked through the identities
+    of getProxOps.m:1217-1343 with the per-slice closure state (x_k, u_k) fetched from the device: two runs of i and
+    i + 1 iterations (the loop is deterministic) give (u_k, z) before and (x_k, u_k, z) after iteration i + 1."""
+    L = gpu._lib
+    D, s, lam, rho = big["D"], big["s"], big["lam"], 1.0
+    m, n = D.shape
+    K = 8
+    sl = gpu.errorcheck.slicemaker(0, K, m)
+    assert list(sl) == [12500] * 8
+    eng = gpu.Engine(L.PROB_LASSO_CONSENSUS, D=D, s=s, lam=lam, rho=rho, slices=sl, xsolve=L.XSOLVE_AUTO)
+    try:
+        assert eng.info()["xsolve_used"] == "inverse"
+        i = 4
+        kw = dict(rho=rho, domaxiters=1, stopcond="both", objevals=1)
+        eng.run(maxiters=i, **kw)
+        U0 = eng.fetch(L.F_CONS_U, n * K, (n, K))
+        z0 = eng.fetch(L.F_ZCONSENSUS, n)
+        xbar0 = eng.fetch(L.F_XOPT, n)
+        eng.run(maxiters=i + 1, **kw)
+        X1 = eng.fetch(L.F_CONS_X, n * K, (n, K))
+        U1 = eng.fetch(L.F_CONS_U, n * K, (n, K))
+        z1 = eng.fetch(L.F_ZCONSENSUS, n)
+        xbar1 = eng.fetch(L.F_XOPT, n)
+        ubar1 = eng.fetch(L.F_UOPT, n)
+        pn = eng.fetch(L.F_PNORM, i + 1)
+        dn = eng.fetch(L.F_DNORM, i + 1)
+        obj = eng.fetch(L.F_OBJEVALS, i + 1)
+        assert np.all(eng.fetch(L.F_ZOPT, n) == 0.0)  # q9: the z handed back to admm
+    finally:
+        eng.close()
+    r0 = 0
+    for k in range(K):  # x_k = (D_k'D_k + rho I) \\ (rho (z - u_k) + D_k's_k)   getProxOps.m:1240-1247
+        Dk, sk = D[r0:r0 + sl[k]], s[r0:r0 + sl[k]]
+        lhs = Dk.T @ (Dk @ X1[:, k]) + rho * X1[:, k]
+        rhs = rho * (z0 - U0[:, k]) + Dk.T @ sk
+        assert _rel(lhs, rhs) < RTOL, k
+        r0 += sl[k]
+    assert _rel(xbar1, X1.mean(axis=1)) < 1e-12                                  # getProxOps.m:1259
+    assert _rel(z1, _soft(U0.mean(axis=1) + xbar1, lam / (rho * K))) < 1e-11     # 1286-1292, q11
+    assert _rel(U1, U0 + X1 - z1[:, None]) < 1e-12                               # 1296-1298
+    assert _rel(ubar1, U1.mean(axis=1)) < 1e-12                                  # altu, 1312-1326
+    assert pn[i] == pytest.approx(np.sum((X1 - xbar1[:, None]) ** 2), rel=1e-8)  # lassonorms, squared (q10)
+    assert dn[i] == pytest.approx(K * rho ** 2 * np.sum((xbar1 - xbar0) ** 2), rel=1e-8)
+    assert obj[i] == pytest.approx(0.5 * np.sum((D @ xbar1 - s) ** 2), rel=1e-10)  # lasso.m:227 with z = 0 (q9)
