@@ -39,6 +39,7 @@ struct ConsSlice {
   GemvNPlan planN{};
   GemvTPlan planT{};
   SliceFactor fac;
+  bool fat = false;         // rows < columns: fac factors D_k D_k'/rho + I (order m), applied through the Woodbury form
 };
 
 struct ConsArgs {

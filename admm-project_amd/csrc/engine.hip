@@ -947,8 +947,6 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       for (int32_t k = 0; k < desc->nslices; ++k) {
         ConsSlice& sl = e->cslices[k];
         sl.m = desc->slices[k];
-        if (sl.m < n)  // q12: the reference's fat-slice branch indexes the wrong diagonal; not reproduced
-          return bail(fail(ADMM_E_UNSUPPORTED, "consensus lasso needs tall slices (rows per slice >= columns), see q12"));
         E_TRY(upload_matrix(e->mem, &sl.D, &sl.ld, desc->D + r0, sl.m, n, ldsrc, mk, e->stream));
         E_TRY(upload(e->mem, &sl.s, desc->s + r0, sl.m, mk, e->stream));
         sl.planN = gemv_n_plan(sl.m, n, sl.ld);
@@ -959,17 +957,37 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       }
       E_TRY(e->mem.alloc(&e->partDN, e->planDN.part_elems()));
       E_TRY(e->mem.alloc(&e->partDT, e->planDT.part_elems(1)));
+      int64_t fat_rows = 0;
       for (int32_t k = 0; k < desc->nslices; ++k) {
         ConsSlice& sl = e->cslices[k];
         E_TRY(e->mem.alloc(&sl.Dts, round_up(n, 2)));
         launch_gemv_t(sl.planT, sl.D, sl.s, nullptr, nullptr, 1, e->partDT, nullptr, e->stream);
         launch_sum_partials_t(sl.planT, e->partDT, 1, sl.Dts, round_up(n, 2), nullptr, e->stream);
         double* W = nullptr;
-        E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
-        E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
-        launch_gemm(1, 0, n, n, sl.m, 1.0, sl.D, sl.ld, sl.D, sl.ld, 0.0, W, ld, true, e->stream);
-        launch_add_diag(W, n, ld, desc->rho, e->stream);
-        E_TRY(build_slice_factor(e, sl.fac, W, n, ld, e->xsolve_requested, nullptr, mk));
+        if (sl.m >= n) {  // getProxOps.m:424, 429-435: chol(D_k'D_k + rho I)
+          E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * n));
+          E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * n, e->stream));
+          launch_gemm(1, 0, n, n, sl.m, 1.0, sl.D, sl.ld, sl.D, sl.ld, 0.0, W, ld, true, e->stream);
+          launch_add_diag(W, n, ld, desc->rho, e->stream);
+          E_TRY(build_slice_factor(e, sl.fac, W, n, ld, e->xsolve_requested, nullptr, mk));
+        } else {
+          // fat slice (rows < columns).  q12, documented deviation: the reference's branch (getProxOps.m:426-430,
+          // 1251) shifts the wrong entries of D_k D_k' and is exact for no rho; the engine applies the serial
+          // solver's form, chol(D_k D_k'/rho + I) with x = y/rho - D_k'(U\(L\(D_k y)))/rho^2 (lasso.m:172,
+          // getProxOps.m:1204) = the Woodbury identity of (D_k'D_k + rho I)^-1 y
+          sl.fat = true;
+          const int64_t ldf = round_up(sl.m, 16);
+          E_TRY(e->mem.alloc(&W, static_cast<size_t>(ldf) * sl.m));
+          E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ldf * sl.m, e->stream));
+          launch_gemm(0, 1, sl.m, sl.m, n, 1.0 / desc->rho, sl.D, sl.ld, sl.D, sl.ld, 0.0, W, ldf, true, e->stream);
+          launch_add_diag(W, sl.m, ldf, 1.0, e->stream);
+          E_TRY(build_slice_factor(e, sl.fac, W, sl.m, ldf, e->xsolve_requested, nullptr, mk));
+          if (sl.m > fat_rows) fat_rows = sl.m;
+        }
+      }
+      if (fat_rows > 0) {
+        E_TRY(e->mem.alloc(&e->tmpA, round_up(fat_rows, 2)));
+        E_TRY(e->mem.alloc(&e->tmpB, round_up(fat_rows, 2)));
       }
       e->cldn = round_up(n, 2);
       const size_t K = static_cast<size_t>(desc->nslices);

@@ -67,7 +67,16 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
         for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
           ConsSlice& sl = e->cslices[k];
           launch_cons_rhs(n, o.rho, e->czc, e->cU + k * ldn, sl.Dts, e->cy, e->ctrl, e->stream);
-          apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
+          if (!sl.fat) {
+            apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
+          } else {  // x_k = y/rho - D_k'(U\(L\(D_k y)))/rho^2   (getProxOps.m:1204 form, q12)
+            launch_gemv_n(sl.planN, sl.D, e->cy, e->partDN, e->ctrl, e->stream);
+            launch_sum_partials(e->partDN, sl.planN.nchunk, sl.planN.ldy, sl.m, e->tmpA, e->ctrl, e->stream);
+            apply_slice_factor(e, sl.fac, e->tmpA, e->tmpB);
+            launch_gemv_t(sl.planT, sl.D, e->tmpB, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
+            launch_combine(e->partDT, sl.planT.nchunk, sl.planT.ldg, -1.0 / (o.rho * o.rho), e->cy, 1.0 / o.rho, nullptr,
+                           e->cX + k * ldn, n, e->ctrl, e->stream);
+          }
         }
       }
       if (shard) {

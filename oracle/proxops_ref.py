@@ -185,8 +185,18 @@ def _consensus_lasso(args):
     ui = [np.zeros(n) for _ in range(N)]
     DtDi, Li = [None] * N, [None] * N
 
+    # q12 (documented deviation): the reference's fat-slice branch adds rho along stride n+1 of an mi x mi matrix
+    # (not its diagonal) and then applies the /rho^2 formula that belongs to chol(D*D'/rho + I) (lasso.m:172,
+    # getProxOps.m:1204).  args["fatformula"] = "serial" selects that serial, correct form for fat slices -- the
+    # Woodbury identity of (Di'Di + rho I)^-1 -- which is what the engine implements; the default restates the
+    # reference literally.
+    serial_fat = args.get("fatformula", "literal") == "serial"
+
     def refactor(k, rho):
         mi = Di[k].shape[0]
+        if serial_fat and mi < n:
+            Li[k] = sla.cholesky(DtDi[k] / rho + np.eye(mi), lower=True)  # lasso.m:172
+            return
         P = np.array(DtDi[k], order="F", copy=True)
         # 430 / 1232: Pi(1:n+1:end) = DtDi(1:n+1:end) + rho -- stride n+1 in
         # column-major linear indexing even when the matrix is mi x mi (q12).

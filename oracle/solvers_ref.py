@@ -88,6 +88,8 @@ def lasso(D, s, lam, options=None, workers=1):
         slices = slicemaker(slices, workers, m)
         args = dict(slices=slices, D=D, s=s, rho=rho, parallel=1)
         args["lambda"] = lam
+        if "fatformula" in options:  # q12: "serial" = the corrected fat-slice formula (see proxops_ref)
+            args["fatformula"] = options["fatformula"]
         minx, minz, extra = getproxops("LASSO", args)
         options["altu"] = extra["altu"]
         options["specialnorms"] = extra["specialnorms"]

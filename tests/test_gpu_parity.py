@@ -437,10 +437,38 @@ def test_matrix_free_cg_matches_factor_path(gpu, solver, opts):
     assert 0 < got["cg_iters_total"] <= 60 * got["steps"]
 
 
-def test_consensus_lasso_rejects_fat_slices(gpu):
-    p = gpu.synth.lasso_problem(1, 120, 64)
-    with pytest.raises(gpu.AdmmError):  # q12: 4 slices of 30 rows < 64 columns
-        gpu.lasso(p["D"], p["s"], p["lam"], dict(parallel="both", workers=4))
+@pytest.mark.parametrize("rho", [1.0, 2.5])
+@pytest.mark.parametrize("rows,workers", [(120, 4), (150, 2), (200, 3)])
+def test_consensus_lasso_fat_slices_serial_formula(gpu, rows, workers, rho):
+    """q12 (documented deviation): slices with fewer rows than columns.  The reference's branch
+    (getProxOps.m:426-430, 1251) shifts the wrong entries of D_k D_k'; the engine applies the serial solver's
+    form chol(D_k D_k'/rho + I), x = y/rho - D_k'(U\\(L\\(D_k y)))/rho^2 (lasso.m:172, getProxOps.m:1204) and is
+    compared with the oracle branch that does the same (fatformula='serial').  (200, 3): 67/67/66-row slices of a
+    64-column matrix are tall -- mixed with nothing here, but 150/2 = 75 > 64 is tall too: only 120/4 = 30 is fat;
+    the other two cases pin that the tall path is untouched by the flag."""
+    p = gpu.synth.lasso_problem(1, rows, 64)
+    o = dict(objevals=1, parallel="both", rho=rho)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, workers=workers))
+    ref = S.lasso(p["D"], p["s"], p["lam"], dict(o, slices=0, fatformula="serial"), workers=workers)
+    _compare(got, ref, keys=("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq"))
+    # and against the mathematically identical tall formula on the same slices: (D_k'D_k + rho I) x_k = y_k
+    assert got["steps"] == ref["steps"]
+
+
+def test_consensus_lasso_mixed_fat_and_tall_slices(gpu):
+    """explicit slice sizes (errorcheck.m:263-265): one fat slice (20 rows) next to tall ones"""
+    p = gpu.synth.lasso_problem(2, 220, 48)
+    sl = [100, 20, 100]
+    args = dict(slices=np.array(sl, dtype=float), D=p["D"], s=p["s"], rho=1.0, parallel=1)
+    args["lambda"] = p["lam"]
+    minx, minz, extra = gpu.getproxops("LASSO", args)
+    opts = dict(A=1, At=1, m=48, nA=48, nB=48, B=-1, c=0, stopcond="both", altu=extra["altu"],
+                specialnorms=extra["specialnorms"])
+    got = gpu.admm(minx, minz, dict(opts))
+    from oracle import admm as ref_admm, getproxops as ref_getproxops
+    rx, rz, rextra = ref_getproxops("LASSO", dict(args, slices=sl, fatformula="serial"))
+    ref = ref_admm(rx, rz, dict(opts, altu=rextra["altu"], specialnorms=rextra["specialnorms"]))
+    _compare(got, ref, keys=("xvals", "uvals", "pnorm", "dnorm", "Hnormsq"))
 
 
 def test_precomputed_factor_is_used(gpu):
