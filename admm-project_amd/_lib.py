@@ -58,6 +58,7 @@ class ProblemDesc(C.Structure):
 # caller-supplied prox operators / objective (device pointers as integers; see admm_engine.h)
 PROX_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                             C.c_int64, C.c_void_p)
+OPERATOR_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p)
 OBJ_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 
@@ -108,6 +109,7 @@ _SIGNATURES = {
     "admm_engine_create": (C.c_int, [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),
     "admm_engine_set_callbacks": (C.c_int, [C.c_void_p, PROX_CALLBACK, C.c_void_p, PROX_CALLBACK, C.c_void_p,
                                             OBJ_CALLBACK, C.c_void_p]),
+    "admm_engine_set_operators": (C.c_int, [C.c_void_p, OPERATOR_CALLBACK, C.c_void_p, OPERATOR_CALLBACK, C.c_void_p]),
     "admm_engine_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary)]),
     "admm_engine_fetch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "admm_engine_info": (C.c_int, [C.c_void_p, C.POINTER(EngineInfo)]),

@@ -253,6 +253,8 @@ def _check_constraint(options, prob):
     if exp["A"] == 1:
         if not (np.isscalar(A) and float(A) == 1.0):
             raise ValueError(f"{prob.kind}: constraint matrix A must be the scalar 1")
+    elif callable(A) and prob.kind == "generic":
+        pass  # function-handle operators (admm.m:117-158): sizes were taken from options.nA / nB
     else:
         if np.isscalar(A) or tuple(A.shape) != (exp["nB"], exp["nA"]):
             raise ValueError(f"{prob.kind}: constraint matrix A must be the data matrix D")
@@ -307,9 +309,30 @@ def _generic_problem(options):
                 raise ValueError("Given vector c does not match the problem size")
         eng = Engine(L.PROB_LAD, D=Am, s=cvec, xsolve=L.XSOLVE_CALLBACK, device=int(options.get("device", 0)))
         return _Problem("generic", eng, dict(A="D", c="s", nA=n, nB=m))
+    if callable(A):
+        # options.A / options.At as function handles (admm.m:117-158): no matrix exists; A(x) and At(v) are device
+        # callbacks like the prox operators, everything else of the loop stays in the fused kernels
+        At = options.get("At")
+        if not callable(At):
+            raise ValueError("options.A is a function handle: options.At must be one too (admm.m:139-158)")
+        nA, nB = int(options.get("nA", 0)), int(options.get("nB", 0) or options.get("m", 0))
+        if nA <= 0 or nB <= 0:
+            raise ValueError("function-handle operators need the sizes options.nA and options.nB (or m)")
+        c = options.get("c", 0.0)
+        if np.isscalar(c):
+            if float(c) != 0.0:
+                raise NotImplementedError("scalar non-zero c is not supported")
+            cvec = np.zeros(nB)
+        else:
+            cvec = np.asarray(c, dtype=np.float64).reshape(-1)
+            if cvec.size != nB:
+                raise ValueError("Given vector c does not match the problem size")
+        eng = Engine(L.PROB_LAD, s=cvec, shape=(nB, nA), xsolve=L.XSOLVE_CALLBACK, device=int(options.get("device", 0)))
+        eng.set_operators(A, At)
+        return _Problem("generic", eng, dict(A="D", c="s", nA=nA, nB=nB))
     if not (np.isscalar(A) and float(A) == 1.0):
-        raise NotImplementedError("caller-supplied prox handles run with A = 1 or a constraint matrix A; function "
-                                  "handles for A / At are not engine-native")
+        raise NotImplementedError("caller-supplied prox handles run with A = 1, a constraint matrix A, or function "
+                                  "handles A / At")
     c = options.get("c", 0.0)
     n = int(options.get("nA", 0) or options.get("nB", 0) or options.get("m", 0))
     cvec = None

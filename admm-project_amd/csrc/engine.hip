@@ -630,6 +630,21 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     case ADMM_PROB_HUBERFIT:
     case ADMM_PROB_LINEARSVM: {
       const bool svm = desc->problem == ADMM_PROB_LINEARSVM;
+      if (!desc->D && xs == ADMM_XSOLVE_CALLBACK && desc->problem == ADMM_PROB_LAD && m > 0 && n > 0) {
+        // options.A / options.At are function handles (admm.m:117-158): no matrix, both operators are callbacks
+        if (!desc->s) return bail(fail(ADMM_E_INVALID, "the operator form needs the constraint vector c (as s)"));
+        if (sharded) return bail(fail(ADMM_E_UNSUPPORTED, "operator callbacks are not supported on row-sharded engines"));
+        e->a_identity = false;
+        e->nA = n;
+        e->len = m;
+        e->len_global = m;
+        e->rhs_kind = RHS_T1;
+        e->prox = PROX_SOFT;
+        E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
+        e->c = e->s;
+        E_TRY(e->mem.alloc(&e->axbuf, round_up(m, 2)));
+        break;
+      }
       if (!desc->D || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "problem needs D (m x n)"));
       if (!svm && !desc->s) return bail(fail(ADMM_E_INVALID, "LAD/Huber need the signal vector s"));
       if (svm && !desc->ell) return bail(fail(ADMM_E_INVALID, "linear SVM needs the label vector ell"));

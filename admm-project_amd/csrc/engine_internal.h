@@ -153,6 +153,9 @@ struct admm_engine {
   double* s2 = nullptr;
   GemvNPlan planD2N{};
   double* partD2N = nullptr;
+  admm_operator_callback acb = nullptr, atcb = nullptr;  // options.A / options.At as function handles (no D)
+  void *auser = nullptr, *atuser = nullptr;
+  double* axbuf = nullptr;  // A(x) when A is a callback
   admm_prox_callback xcb = nullptr, zcb = nullptr;
   admm_obj_callback ocb = nullptr;
   void *xuser = nullptr, *zuser = nullptr, *ouser = nullptr;

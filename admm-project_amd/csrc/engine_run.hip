@@ -205,6 +205,19 @@ int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xus
   return ADMM_OK;
 }
 
+int admm_engine_set_operators(admm_engine* e, admm_operator_callback A, void* Auser, admm_operator_callback At,
+                              void* Atuser) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  if (e->D || e->a_identity || e->xsolve != ADMM_XSOLVE_CALLBACK)
+    return fail(ADMM_E_UNSUPPORTED, "operator callbacks belong to an engine created without a matrix "
+                                    "(ADMM_PROB_LAD, ADMM_XSOLVE_CALLBACK, desc.D = NULL)");
+  e->acb = A;
+  e->auser = Auser;
+  e->atcb = At;
+  e->atuser = Atuser;
+  return ADMM_OK;
+}
+
 int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* summary) {
   if (!e || !opts) return fail(ADMM_E_INVALID, "engine/options is NULL");
   if (opts->struct_size != static_cast<int32_t>(sizeof(admm_options)))
@@ -223,6 +236,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     return fail(ADMM_E_INVALID, "options.rho differs from the rho the cached slice factors were built for");
   if (e->xsolve == ADMM_XSOLVE_CALLBACK && !e->xcb)
     return fail(ADMM_E_INVALID, "this engine was created with xsolve=callback: set the xminf callback before running");
+  if (!e->a_identity && !e->D && e->axbuf && (!e->acb || !e->atcb))
+    return fail(ADMM_E_INVALID, "this engine has no constraint matrix: set the A and At operator callbacks "
+                                "(admm_engine_set_operators) before running");
   if (o.relax != 1.0 && (e->problem == ADMM_PROB_LINEARSVM))
     return fail(ADMM_E_INVALID,
                 "relaxation with the linear SVM prox is a dimension error in the reference (getProxOps.m:1088)");
@@ -465,9 +481,15 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // D'*[t1, z - zprev, u] in one pass over D (getProxOps.m:1514; admm.m:624, 654).  With the caller's pseudo-inverse
   // (args.Dplus, linearsvm.m:185-186) row 0 is Dplus*t1 = the x-update itself (getProxOps.m:1067) and only the two
   // dual-residual products still stream D.
+  int op_rc = ADMM_OK;
   auto transposed_products = [&](int nrhs) {
     TimerScope ts(e, ADMM_K_GEMV_T);
-    if (e->DplusT) {
+    if (e->atcb && !e->D) {  // options.At as a function handle (admm.m:165-167): one call per right-hand side
+      const double* vecs[3] = {e->rhs, e->dz, e->u};
+      for (int r = 0; r < nrhs && op_rc == ADMM_OK; ++r)
+        if (e->atcb(e->atuser, vecs[r], len, e->g + r * e->ldg, nA, static_cast<void*>(e->stream)) != 0)
+          op_rc = fail(ADMM_E_INVALID, "the At operator callback reported a failure");
+    } else if (e->DplusT) {
       launch_gemv_t(e->planDT, e->DplusT, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
       launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
       if (nrhs > 1) {
@@ -481,6 +503,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   };
   if (!e->a_identity) {
     transposed_products(1);
+    ADMM_TRY(op_rc);
     if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
   }
   // One iteration = a fixed sequence of launches with iteration-independent arguments (the iteration
@@ -506,7 +529,14 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       int32_t naxpart;
       int64_t axld;
       ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld, &axt, fuse_tail));
-      if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
+      if (!e->a_identity && !e->D) {  // Ax = A(x) with options.A a function handle (admm.m:117-120, 535)
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        if (e->acb(e->auser, e->x, nA, e->axbuf, len, static_cast<void*>(e->stream)) != 0)
+          return fail(ADMM_E_INVALID, "the A operator callback reported a failure");
+        axsrc = e->axbuf;
+        naxpart = 1;
+        axld = 0;
+      } else if (!e->a_identity) {  // Ax = D*x (admm.m:535), summed inside the prox kernel
         TimerScope ts(e, ADMM_K_GEMV_N);
         launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
         axsrc = e->partDN;
@@ -570,6 +600,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       }
       if (!e->a_identity) {  // D'*[c+zx-ux, z-zprev, u]  (getProxOps.m:1514; admm.m:624, 654) in ONE pass
         transposed_products(nrhs_dual);
+        ADMM_TRY(op_rc);
         if (shard_rows) {
           // ONE all-reduce per iteration: d = sum_g D_g'(...) (unwrappedadmm.m:135-137) for up to
           // three right-hand sides plus the 16 residual/objective partial sums (X3 + X6)

@@ -54,7 +54,7 @@ class Engine:
                 d.m = int(nvec)
             d.n = int(nvec)
         if shape is not None:  # 2-D total variation: the image is shape[0] x shape[1], column-major in s
-            d.m, d.n = int(shape[0]), int(shape[1])
+            d.m, d.n = int(shape[0]), int(shape[1])  # (also the m x n of an operator-form engine without a matrix)
         if Q is not None:  # model problem: QtQ, Qts and the optional objective data (getProxOps.m:83-89)
             Qm = _f64(Q)
             keep.append(Qm)
@@ -250,6 +250,41 @@ class Engine:
         keep = (wrap_prox(xmin, "xminf"), wrap_prox(zmin, "zming"), wrap_obj(obj))
         L.check(self._lib.admm_engine_set_callbacks(self._h, keep[0], None, keep[1], None, keep[2], None))
         self._cb_keep = keep  # the C side holds raw pointers to these thunks
+
+    def set_operators(self, A, At):
+        """options.A / options.At as function handles (admm.m:117-158) for an engine created without a matrix:
+        callables on DEVICE tensors, ``A(x) -> nB elements``, ``At(v) -> nA elements`` (zero-copy torch views, the
+        engine's HIP stream), exactly like the prox callbacks."""
+        import torch  # device memory / stream plumbing only
+
+        dev = torch.device("cuda", self.device)
+
+        class _View:
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                                 "version": 2}
+
+        def wrap(fn, what):
+            def cb(_user, vin, nin, out, nout, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        res = fn(torch.as_tensor(_View(vin, nin), device=dev))
+                        if not (isinstance(res, torch.Tensor) and res.is_cuda):
+                            raise TypeError(f"options.{what} must return a CUDA tensor: host arrays would need a CPU "
+                                            "path, which this package does not have")
+                        if res.numel() != nout:
+                            raise ValueError(f"options.{what} returned {res.numel()} elements, expected {nout}")
+                        torch.as_tensor(_View(out, nout), device=dev).copy_(res.to(torch.float64).reshape(-1))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
+                    self._cb_error = exc
+                    return 1
+
+            return L.OPERATOR_CALLBACK(cb)
+
+        keep = (wrap(A, "A"), wrap(At, "At"))
+        L.check(self._lib.admm_engine_set_operators(self._h, keep[0], None, keep[1], None))
+        self._op_keep = keep
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):

@@ -109,6 +109,10 @@ typedef int (*admm_prox_callback)(void* user, const double* x, const double* z, 
                                   double* out, int64_t nout, void* hip_stream);
 typedef int (*admm_obj_callback)(void* user, const double* x, int64_t nA, const double* z, int64_t nB, double* out,
                                  void* hip_stream);
+/* Caller-supplied constraint operators: options.A / options.At as function handles (admm.m:117-158).
+ *   out[nout] = A(in[nin])  or  At(in[nin]);  device pointers, enqueue on hip_stream, non-zero return aborts the run */
+typedef int (*admm_operator_callback)(void* user, const double* in, int64_t nin, double* out, int64_t nout,
+                                      void* hip_stream);
 typedef struct admm_comm admm_comm;     /* opaque RCCL communicator wrapper */
 
 /*
@@ -249,6 +253,11 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out);
  * ADMM_PROB_MODEL created without Gram data REQUIRES the corresponding callback. */
 int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* xuser, admm_prox_callback zmin,
                               void* zuser, admm_obj_callback obj, void* objuser);
+/* options.A / options.At as function handles: an engine created as ADMM_PROB_LAD with ADMM_XSOLVE_CALLBACK and
+ * desc.D = NULL (desc.m = rows of A = length of z, u, c; desc.n = length of x; desc.s = c) has no matrix at all --
+ * A*x, At*(.) of the dual residual / tolerance (admm.m:535, 624, 654) are these callbacks, both required; B = -1. */
+int admm_engine_set_operators(admm_engine* eng, admm_operator_callback A, void* Auser, admm_operator_callback At,
+                              void* Atuser);
 int admm_engine_run(admm_engine* eng, const admm_options* opts, admm_run_summary* summary);
 int admm_engine_fetch(admm_engine* eng, int field, double* dst, size_t cap, size_t* written);
 /* what create() decided about the x-update factor (first slice for consensus lasso) */

@@ -184,7 +184,7 @@ def test_host_handles_are_rejected(gpu):
         gpu.admm(lambda x, z, u, r: np.zeros(16), lambda x, z, u, r: np.zeros(16), o)
     with pytest.raises(NotImplementedError, match="B = -1"):
         gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, B=np.eye(16)))
-    with pytest.raises(NotImplementedError, match="function handles for A"):
+    with pytest.raises(ValueError, match="options.At must be one too"):  # admm.m:139-158: A and At come together
         gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=lambda v: v))
     p = gpu.synth.tv_problem(0, 64)
     minx, _mz, _ = gpu.getproxops("totalvariation", {"s": p["s"], "lambda": 1.0})
@@ -436,3 +436,61 @@ def test_generic_handles_with_constraint_matrix(gpu, rows, cols, opts):
         orf["obj"] = lambda x, z: 0.5 * eps * np.sum(x * x) + np.sum(np.abs(z))
     got, ref = gpu.admm(xt, zt, og), A.admm(xn, zn, orf)
     _compare(got, ref, tol=1e-7)
+
+
+@pytest.mark.parametrize("opts", [dict(objevals=1), dict(relax=1.3), dict(fast=1, fasttype="strong"),
+                                  dict(nodualerror=1, stopcond="both")])
+def test_generic_handles_with_function_handle_operators(gpu, opts):
+    """a2 (admm.m:117-158): options.A and options.At are FUNCTION HANDLES -- here a matrix-free operator (first
+    differences followed by a diagonal scaling) and its adjoint, as device callables; both prox handles are the
+    caller's too.  Compared with the oracle running the same handles in NumPy, and with the engine given the
+    equivalent dense matrix."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 90
+    rng = np.random.default_rng(17)
+    w = 0.5 + rng.random(n - 1)
+    cvec = 0.1 * rng.standard_normal(n - 1)
+    sig = np.cumsum(rng.standard_normal(n))
+    tw, tc, tsig = (torch.tensor(a, device=dev) for a in (w, cvec, sig))
+
+    def A_t(x):
+        return tw * (x[1:] - x[:-1])
+
+    def At_t(v):
+        out = torch.zeros(n, dtype=torch.float64, device=dev)
+        out[1:] += tw * v
+        out[:-1] -= tw * v
+        return out
+
+    A_n = lambda x: w * (x[1:] - x[:-1])
+
+    def At_n(v):
+        out = np.zeros(n)
+        out[1:] += w * v
+        out[:-1] -= w * v
+        return out
+
+    Amat = np.zeros((n - 1, n))
+    for i in range(n - 1):
+        Amat[i, i], Amat[i, i + 1] = -w[i], w[i]
+    rho = 1.0
+    Minv = np.linalg.inv(np.eye(n) + rho * Amat.T @ Amat)
+    tMinv = torch.tensor(Minv, device=dev)
+    relaxed = opts.get("relax", 1.0) != 1.0
+    soft_t = lambda v, t: torch.sign(v) * torch.clamp(torch.abs(v) - t, min=0.0)
+    soft_n = lambda v, t: np.sign(v) * np.maximum(np.abs(v) - t, 0.0)
+    xt = lambda _x, z, u, r_: tMinv @ (tsig + r_ * At_t(z + tc - u))
+    xn = lambda _x, z, u, r_: Minv @ (sig + r_ * At_n(z + cvec - u))
+    zt = lambda x, _z, u, r_: soft_t((x if relaxed else A_t(x)) + u - tc, 0.7 / r_)
+    zn = lambda x, _z, u, r_: soft_n((x if relaxed else A_n(x)) + u - cvec, 0.7 / r_)
+    o = dict(B=-1, c=cvec, m=n - 1, nA=n, nB=n - 1, maxiters=80, **opts)
+    og, orf, om = dict(o, A=A_t, At=At_t), dict(o, A=A_n, At=At_n), dict(o, A=Amat, At=Amat.T)
+    if opts.get("objevals"):
+        og["obj"] = om["obj"] = lambda x, z: 0.5 * torch.sum((x - tsig) ** 2) + 0.7 * torch.sum(torch.abs(z))
+        orf["obj"] = lambda x, z: 0.5 * np.sum((x - sig) ** 2) + 0.7 * np.sum(np.abs(z))
+    got, ref, mat = gpu.admm(xt, zt, og), A.admm(xn, zn, orf), gpu.admm(xt, zt, om)
+    _compare(got, ref, tol=1e-7)
+    _compare(got, mat, tol=1e-9)
+    with pytest.raises(ValueError, match="options.At must be one too"):
+        gpu.admm(xt, zt, dict(o, A=A_t, At=Amat.T))
