@@ -85,8 +85,11 @@ def test_admm_handle_validation(ap):
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=-1, c=0, m=4, nA=4, nB=4))
     with pytest.raises(NotImplementedError, match="B = -1"):
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=np.eye(4), c=0, m=4, nA=4, nB=4))
-    with pytest.raises(NotImplementedError, match="function handles for A"):
+    with pytest.raises(ValueError, match="options.At must be one too"):  # admm.m:139-158
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=lambda v: v, B=-1, c=0, m=4, nA=4, nB=4))
+    with pytest.raises(ap.AdmmError, match="no HIP device"):  # function-handle operators also need the device
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z,
+                dict(A=lambda v: v, At=lambda v: v, B=-1, c=0, m=4, nA=4, nB=4))
     with pytest.raises(TypeError):
         ap.admm(None, None, "not a struct")
     with pytest.raises(TypeError, match="not a function handle"):
