@@ -98,6 +98,13 @@ static int ensure_sy_buffers(admm_engine* e, const SymvPlan& plan) {
   return ADMM_OK;
 }
 
+// leading dimension of a tile-padded symmetric matrix: ADMM_SYMV_LD_ALIGN (doubles, default 1 = npad) is an experiment knob
+static int64_t symv_ld(int64_t npad) {
+  int64_t a = 1;
+  if (const char* f = std::getenv("ADMM_SYMV_LD_ALIGN")) a = std::atoll(f);
+  return a > 1 ? round_up(npad, a) : npad;
+}
+
 // f.Minv (tile-padded, zeros outside n x n) = X' X with X = inv(L): the explicit inverse of L L'
 static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
   const int64_t n = f.n, ld = f.ld;
@@ -105,10 +112,10 @@ static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
   ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
   int rc = trtri_lower_from_diag(f.F, n, ld, f.dinv, X, ld, e->stream);
   f.planSy = symv_plan(n);
-  f.ldM = f.planSy.npad;
-  if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM);
+  f.ldM = symv_ld(f.planSy.npad);
+  if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.planSy.npad);
   if (rc == ADMM_OK) {
-    (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream);
+    (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.planSy.npad, e->stream);
     launch_gemm(1, 0, n, n, n, 1.0, X, ld, X, ld, 0.0, f.Minv, f.ldM, true, e->stream);
     launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
   }
@@ -352,9 +359,9 @@ int factorize_pinv(admm_engine* e, double* W, int64_t n, int64_t ld) {
   ADMM_HIP_TRY(hipMemcpyAsync(lam, lh.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
   launch_scale_cols(V, ldv, n, lam, e->stream);  // V <- V diag(lambda^-1/2)
   f.planSy = symv_plan(n);
-  f.ldM = f.planSy.npad;
-  ADMM_TRY(e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.ldM));
-  ADMM_HIP_TRY(hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.ldM, e->stream));
+  f.ldM = symv_ld(f.planSy.npad);
+  ADMM_TRY(e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.planSy.npad));
+  ADMM_HIP_TRY(hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.planSy.npad, e->stream));
   launch_gemm(0, 1, n, n, n, 1.0, V, ldv, V, ldv, 0.0, f.Minv, f.ldM, true, e->stream);
   launch_symmetrize_lower(f.Minv, n, f.ldM, e->stream);
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));

@@ -520,7 +520,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // A = I iterations whose finalize depends on nothing but the prox kernel's partial sums end in ONE launch
   // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
   const bool obj_kernels = o.objevals && (obj_lasso_gemv || obj_qp_gemv || obj_model_gemv || e->ocb);
-  const bool fuse_tail = e->a_identity && alg != 2 && !split_z && !sharded && !obj_kernels &&
+  // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
+  // without it the finalize logic needs none of the D' products that follow the prox kernel
+  const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && !sharded && !obj_kernels &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   auto enqueue_iteration = [&]() -> int {
     {
@@ -581,11 +583,17 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         pa.naxpart = naxpart;
         pa.axld = axld;
         pa.x_out = e->a_identity ? e->x : nullptr;
-        if (fuse_tail) {  // z/u update + finalize in one launch: the iteration ends here
+        if (fuse_tail) {  // z/u update + finalize in one launch
           launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream);
-          return ADMM_OK;
+          if (e->a_identity) return ADMM_OK;  // the iteration ends here
+        } else {
+          launch_prox(pa, e->ctrl, &nblk, e->stream);
         }
-        launch_prox(pa, e->ctrl, &nblk, e->stream);
+      }
+      if (fuse_tail) {  // A = D: only the next x-update's right-hand side D'*(c + z - u) is left to do
+        transposed_products(1);
+        ADMM_TRY(op_rc);
+        return ADMM_OK;
       }
       fa.nblk = nblk;
       const bool shard_rows = sharded && !e->a_identity;  // z, u and the residual sums are row-local

@@ -351,6 +351,16 @@ void launch_initial_rhs(int64_t len, int rhs_kind, double rho, const double* zx,
 // ---------------------------------------------------------------- finalize
 // COHERENT: called by the last workgroup of the prox kernel to arrive (prox_fin_kernel): the block partials were
 // published write-through by other compute units during this launch and are read past the L1 (sc1 loads).
+// sum over the kBlock threads that run finalize_body (four waves, whatever the launch's block size); result in thread 0
+__device__ __forceinline__ double fin_block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  return threadIdx.x == 0 ? ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3] : 0.0;
+}
+
 // Exactly kBlock threads (the first four waves of the calling workgroup) take part.
 template <bool COHERENT>
 __device__ __forceinline__ void finalize_body(const FinArgs& a) {
@@ -398,8 +408,8 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       s2 += g2 * g2;
       s3 += g3 * g3;
     }
-    ng2 = block_sum(s2, scratch);
-    ng3 = block_sum(s3, scratch);
+    ng2 = fin_block_sum(s2, scratch);
+    ng3 = fin_block_sum(s3, scratch);
   }
   if (a.x) {
     double s = 0.0;
@@ -408,14 +418,14 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       s += xv * xv;
       if (a.xhist) a.xhist[static_cast<int64_t>(it) * a.nA + j] = xv;
     }
-    nx2 = block_sum(s, scratch);
+    nx2 = fin_block_sum(s, scratch);
   }
   if (a.objp_reduced) {
     objp = a.objp_reduced[0];
   } else if (a.objpart) {
     double s = 0.0;
     for (int b = threadIdx.x; b < a.nobjpart; b += kBlock) s += a.objpart[b];
-    objp = block_sum(s, scratch);
+    objp = fin_block_sum(s, scratch);
   }
   if (threadIdx.x != 0) return;
   const double Mlen = static_cast<double>(a.len_global > 0 ? a.len_global : a.len);
@@ -526,8 +536,8 @@ __device__ __forceinline__ double tail_gather(const ProxArgs& a, int64_t i, int3
 #pragma unroll
     for (int k = 0; k < kTailRows; ++k) {
       const int32_t q = (p + k < p1) ? p + k : p1 - 1;
-      const double* src = (q <= d) ? a.axsrc + static_cast<int64_t>(q) * a.axld
-                                   : a.ax_t + static_cast<int64_t>(q - 1) * a.axld;
+      const double* src = (!a.ax_t || q <= d) ? a.axsrc + static_cast<int64_t>(q) * a.axld
+                                               : a.ax_t + static_cast<int64_t>(q - 1) * a.axld;
       v[k] = src[i];
     }
 #pragma unroll
@@ -550,12 +560,11 @@ __global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArg
   ProxIn in{};
   if (slot == 0) in = prox_load(a, ic);  // in flight together with the partial rows
   double ax;
-  if (a.ax_t) {  // lower-triangle x-solve: naxpart + 1 partial rows per element, split over the four slots
-    const int32_t P = a.naxpart + 1, q = (P + kTailSlots - 1) / kTailSlots;
+  {  // partial rows of this element, split over the four slots: naxpart + 1 rows after the lower-triangle x-solve
+     // (N-part rows up to the diagonal tile, T-part rows beyond), naxpart chunk rows of a column-chunked GEMV otherwise
+    const int32_t P = a.ax_t ? a.naxpart + 1 : a.naxpart, q = (P + kTailSlots - 1) / kTailSlots;
     const int32_t p0 = slot * q, p1 = (p0 + q < P) ? p0 + q : P;
     ax = p0 < P ? tail_gather(a, ic, p0, p1) : 0.0;
-  } else {
-    ax = slot == 0 ? gather_chunks(a.axsrc, a.naxpart, a.axld, ic) : 0.0;
   }
   if (slot > 0) quarter[slot - 1][e] = ax;
   __syncthreads();
@@ -612,9 +621,7 @@ void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nb
   *nblk_out = static_cast<int>(blocks);
   FinArgs ff = f;
   ff.nblk = static_cast<int32_t>(blocks);
-  ff.g = nullptr;  // nothing but the block partials feeds the finalize logic of this path
-  ff.x = nullptr;
-  ff.xhist = nullptr;
+  ff.g = nullptr;  // nothing but the block partials (and, for A = D, the x of this iteration) feeds the finalize logic
   ff.objpart = nullptr;
   ff.nobjpart = 0;
   ff.slots_reduced = nullptr;
