@@ -215,10 +215,25 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   // one fused launch per iteration (8 vector passes) when the halo is small; the three-kernel form otherwise
   const bool tv_fused = tv_fused_ok(ta) && std::getenv("ADMM_HIP_TV_UNFUSED") == nullptr;
   double* tv_part = nullptr;  // per-tile partials of the fused kernel (one column per tile)
+  bool tv_one_launch = false;
   if (tv_fused) {
-    ta.part_stride = round_up(ceil_div(e->n, ta.ftile), 2);
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * S_COUNT * ta.part_stride));
+    const int64_t ntiles = ceil_div(e->n, ta.ftile);
+    ta.part_stride = round_up(ntiles, 2);
+    const int64_t ngroups = ceil_div(ntiles, kTvGroup);
+    // One launch per iteration (tile partials -> group partials -> finalize inside the fused kernel, tv.hip) is
+    // implemented and tested but NOT the default: at n = 4096^2 it measured 0.2419-0.2421 ms per iteration against
+    // 0.2405 with the two small launches (tv_pack + finalize) behind the fused kernel, on the same box -- the drain
+    // and the two arrival hops at the end of 8600 tiles cost what the two launches cost.  ADMM_HIP_TV_ONE_LAUNCH=1.
+    tv_one_launch = ngroups <= kMaxPartBlocks && std::getenv("ADMM_HIP_TV_ONE_LAUNCH") != nullptr;
+    const size_t extra = tv_one_launch ? static_cast<size_t>(S_COUNT) * kMaxPartBlocks + (ngroups + 2) / 2 + 1 : 0;
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * (S_COUNT * ta.part_stride + extra)));
     ta.part = tv_part;
+    if (tv_one_launch) {
+      ta.gpart = tv_part + S_COUNT * ta.part_stride;
+      ta.gcount = reinterpret_cast<int32_t*>(ta.gpart + static_cast<size_t>(S_COUNT) * kMaxPartBlocks);
+      ta.ngroups = static_cast<int32_t>(ngroups);
+      ADMM_HIP_TRY(hipMemsetAsync(ta.gcount, 0, sizeof(int32_t) * (ngroups + 1), e->stream));
+    }
   }
   struct DevFree {
     void* p;
@@ -355,7 +370,9 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
         TimerScope ts(e, ADMM_K_XSOLVE);
         ta.yin = a_cur ? e->tv_y : e->tv_y2;
         ta.yout = a_cur ? e->tv_y2 : e->tv_y;
-        launch_tv_fused(ta, e->red, e->ctrl, e->stream);
+        fa.nblk = nblk;
+        launch_tv_fused(ta, fa, e->red, e->ctrl, e->stream);
+        if (tv_one_launch) continue;  // the launch ended the iteration itself
         fa.slots_reduced = e->red;
       } else {
         {

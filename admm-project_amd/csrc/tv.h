@@ -1,5 +1,6 @@
 // tv.h -- argument block and launchers of the 1-D total-variation kernels (tv.hip).
 #pragma once
+#include "loop_kernels.h"
 #include <vector>
 
 #include "common.h"
@@ -32,7 +33,14 @@ struct TvArgs {
   int64_t part_stride;     // fused kernel: part is [S_COUNT][part_stride], one column per tile
   int32_t skip_x;          // fused kernel: do not store x (no history wanted): the engine materialises the final x
                            // with one backward sweep of the surviving y after the loop -- 7 vector passes instead of 8
+  // one-launch iteration: the tile partials are summed and the finalize logic runs inside the fused kernel.  Groups
+  // of kTvGroup consecutive tiles: the last tile of a group to arrive sums the group's partials into gpart
+  // ([S_COUNT][kMaxPartBlocks], one column per group), the last GROUP to arrive runs finalize_body on them.
+  int32_t* gcount;         // [ngroups + 1] arrival counters (zero between launches); null = two extra launches instead
+  double* gpart;
+  int32_t ngroups;
 };
+constexpr int kTvGroup = 64;
 
 // pivots of I + rho*D'D and the launch geometry for a given rho
 int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, int* halo, int* elems, int* tile);
@@ -51,7 +59,8 @@ void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, 
 void launch_tv_relax_z(const double* ax, const double* zp, const double* u, int64_t n, double relax, double t,
                        double* zgiven, const Ctrl* ctrl, hipStream_t stream);
 bool tv_fused_ok(const TvArgs& a);
-// slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced)
-void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream);
+// slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced); with a.gcount set the
+// launch ends the iteration itself (fin = the finalize arguments) and slots16 is unused
+void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const Ctrl* ctrl, hipStream_t stream);
 
 }  // namespace admm

@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "tv.h"
+#include "finalize_device.h"
 
 namespace admm {
 
@@ -334,8 +335,9 @@ __device__ __forceinline__ void tv_block_scan(double* __restrict__ lds, int coun
 // costs 40 more VGPRs: 3 workgroups per CU instead of 4 and 0.2390 against 0.2331 ms per iteration on the same box,
 // 2 workgroups 0.3165.  Residency, not the number of dependent load rounds inside a workgroup, carries this kernel.)
 template <int E, bool NTS>
-__global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, const Ctrl* __restrict__ ctrl) {
+__global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
+  __shared__ int32_t tail_group, tail_all;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int kCap = E * kBlock;
   double* __restrict__ L1 = lds;                        // y/b -> x (backward positions)
@@ -508,7 +510,9 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, const Ctr
     __syncthreads();
     if (threadIdx.x < S_COUNT) {
       const int s = threadIdx.x;
-      a.part[s * a.part_stride + blockIdx.x] = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+      const double t = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
+      if (a.gcount) __hip_atomic_store(a.part + s * a.part_stride + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.part[s * a.part_stride + blockIdx.x] = t;
     }
     // ---- 3. forward scan of the next iteration's right-hand side, owned store
     tv_block_scan<E>(L2, fcount, [&](int q) { return tv_coef<false>(a, f0 + q, n, rho, cstar); }, wA, wB);
@@ -525,6 +529,61 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, const Ctr
       }
     }
   }
+  if (!a.gcount) return;
+  // ---- 4. tail of the one-launch iteration.  This tile's partials were published write-through in step 2; once the
+  // wave that stored them has drained, the tile arrives at its group.  (Arriving mid-kernel, right after step 2, was
+  // measured slower -- 0.2446 against 0.2349 ms per iteration with the two extra launches: the drain of the z/u
+  // stores then stalls wave 0 in front of the barriers of step 3's scan, in every tile.)  The last tile to arrive
+  // implies every tile has started and read ctrl at its top, so the finalize logic may advance ctrl.
+  if (wid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      const int32_t g = static_cast<int32_t>(blockIdx.x) / kTvGroup;
+      const int32_t ntiles = static_cast<int32_t>(gridDim.x);
+      const int32_t gsize = (ntiles - g * kTvGroup < kTvGroup) ? ntiles - g * kTvGroup : kTvGroup;
+      const int32_t old = __hip_atomic_fetch_add(a.gcount + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tail_group = (old == gsize - 1) ? 1 : 0;
+      if (tail_group) __hip_atomic_store(a.gcount + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!tail_group) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {  // this workgroup arrived last in its group: the group's partials, tile order, 16 lanes per slot
+    const int32_t g = static_cast<int32_t>(blockIdx.x) / kTvGroup;
+    const int32_t t0 = g * kTvGroup;
+    const int32_t ntiles = static_cast<int32_t>(gridDim.x);
+    const int32_t gsize = (ntiles - t0 < kTvGroup) ? ntiles - t0 : kTvGroup;
+    const int slot = tid >> 4, sub = tid & 15;
+    double v = 0.0;
+    if (slot < S_COUNT) {
+      const double* __restrict__ ps = a.part + slot * a.part_stride + t0;
+      double w[kTvGroup / 16];
+#pragma unroll
+      for (int k = 0; k < kTvGroup / 16; ++k) {
+        const int b = sub + 16 * k;
+        w[k] = __hip_atomic_load(ps + (b < gsize ? b : gsize - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int k = 0; k < kTvGroup / 16; ++k)
+        if (sub + 16 * k < gsize) v += w[k];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (slot < S_COUNT && sub == 0)
+      __hip_atomic_store(a.gpart + slot * kMaxPartBlocks + g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int32_t old = __hip_atomic_fetch_add(a.gcount + a.ngroups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tail_all = (old == a.ngroups - 1) ? 1 : 0;
+      if (tail_all) __hip_atomic_store(a.gcount + a.ngroups, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+  if (!tail_all) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  finalize_body<true>(fin);  // fin.part = gpart, fin.nblk = ngroups
 }
 
 // out16[s] = sum over the tiles of part[s][.], one workgroup per slot, fixed order
@@ -626,14 +685,21 @@ void launch_tv_dual(const double* dz, const double* u, int64_t n, double* part, 
 
 bool tv_fused_ok(const TvArgs& a) { return a.elems == 8 && a.ftile >= 512; }
 
-void launch_tv_fused(const TvArgs& a, double* slots16, const Ctrl* ctrl, hipStream_t stream) {
+void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const Ctrl* ctrl, hipStream_t stream) {
   const int64_t ntiles = ceil_div(a.n, a.ftile);
   constexpr int kCap = 8 * kBlock;
   const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> 4) + 1) * sizeof(double);
   // streaming stores once the eight vectors of an iteration cannot stay cache-resident: +7 % at n = 4096^2
   const bool nts = stream_hint(8 * 8 * a.n);
-  if (nts) hipLaunchKernelGGL((tv_fused_kernel<8, true>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, ctrl);
-  else hipLaunchKernelGGL((tv_fused_kernel<8, false>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, ctrl);
+  FinArgs f = fin;
+  if (a.gcount) {  // one-launch iteration: the finalize logic reads the group partials
+    f.part = a.gpart;
+    f.nblk = a.ngroups;
+    f.slots_reduced = nullptr;
+  }
+  if (nts) hipLaunchKernelGGL((tv_fused_kernel<8, true>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, f, ctrl);
+  else hipLaunchKernelGGL((tv_fused_kernel<8, false>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, f, ctrl);
+  if (a.gcount) return;
   hipLaunchKernelGGL(tv_pack_kernel, dim3(S_COUNT), dim3(kBlock), 0, stream, a.part, a.part_stride,
                      static_cast<int32_t>(ntiles), slots16, ctrl);
 }

@@ -272,6 +272,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                                       "transpose reduction over the row shards",
                           "iters_per_s": k2 / dt2, "ms_per_step": dt2 / k2 * 1e3,
                           "AtAx_unit_ms": pair_ms, "AtAx_GBs_per_gpu": gbs, "AtAx_frac": gbs / HBM_PEAK_GBS,
+                          "AtAx_traffic_bytes": out.get("_pmc_pair"),
                           "gemv_n_avg_ms": gn_ms / max(1, gn_cnt), "gemv_t_avg_ms": gt_ms / max(1, gt_cnt),
                           "setup_seconds": max_over_ranks(dist, lad.setup_seconds)}
     lad.close()
@@ -408,22 +409,33 @@ def main():
     dt_plain, _ = timed_run(eng, dist, a.steps, rho=rho)
     if a.xsolve == "inverse":
         alg_bytes = 8.0 * n * (n + 1) / 2  # lower triangle of the symmetric inverse, read once
-        kname = "symv_lower_kernel (+ symv_reduce): x = inv(D'D+rho I) * y from the lower triangle only"
+        kname = "symv_lower_kernel: x = inv(D'D+rho I) * y from the lower triangle only (its partial rows are summed by the one-launch tail prox_fin_kernel)"
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "tri_step_kernel x 2K + tri_fold (x = L'\\(L\\y), blocked substitution, K coarse blocks)"
-    # HBM bytes per x-solve from the committed PMC passes (profiles/r1_traffic.json; bench.py cannot
-    # run rocprofv3 on itself): valid for the default problem size and the symmetric-half kernel only
+    # HBM bytes per launch from the committed PMC passes of this same script (profiles/r2_traffic.json, produced by
+    # profiles/collect.sh + summarize.py; bench.py cannot run rocprofv3 on itself): valid for the default size
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if a.xsolve == "inverse" and n == 10000 and os.path.exists(tfile):
-        with open(tfile) as fh:
-            tj = json.load(fh)
-        try:
-            traffic = sum(tj[k]["fetch_bytes_per_launch"] + tj[k]["write_bytes_per_launch"]
-                          for k in ("admm::symv_lower_kernel<true>", "admm::symv_reduce_kernel"))
-        except KeyError:
-            traffic = None
+    tj = {}
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        tfile = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tfile):
+            with open(tfile) as fh:
+                tj = json.load(fh)
+            break
+
+    def pmc_bytes(*prefixes):
+        tot = 0.0
+        for pre in prefixes:
+            hit = [v for k, v in tj.items() if k.startswith(pre) and isinstance(v, dict)]
+            if not hit:
+                return None
+            tot += hit[0].get("fetch_bytes_per_launch", 0.0) + hit[0].get("write_bytes_per_launch", 0.0)
+        return tot
+
+    if n == 10000 and m == 100000:
+        traffic = (pmc_bytes("void admm::symv_lower_kernel<true>") if a.xsolve == "inverse"
+                   else None)
     xs_avg_ms = xs_ms / max(1, xs_cnt)
     achieved = alg_bytes / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
     out = {
@@ -476,6 +488,8 @@ def main():
         factor = eng.fetch(L.F_FACTOR, n * n, (n, n))
     eng.close()
 
+    if n == 10000 and m == 100000 and world == 1:  # PMC bytes of one D*x + one D'*[3 rhs] launch
+        out["_pmc_pair"] = pmc_bytes("void admm::gemv_n_kernel", "void admm::gemv_t_kernel<3")
     if not a.no_extras:
         try:
             side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
@@ -484,6 +498,7 @@ def main():
 
     if not a.no_cpu_baseline and world == 1 and rank == 0:
         out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
+    out.pop("_pmc_pair", None)
     if rank == 0:
         print(json.dumps(out))
     if comm is not None:

@@ -2,7 +2,9 @@
 # Collects the evidence of one round on the GPU box (run from the repo root through gpurun):
 #   bash profiles/collect.sh r1k
 # 1. the default bench line, 2. rocprofv3 --kernel-trace --stats of the same command, 3. separate PMC passes
-# (FETCH_SIZE / WRITE_SIZE, kernel-trace only) of the headline loop and of the two TV configurations.
+# (FETCH_SIZE / WRITE_SIZE, kernel-trace only) of the FULL bench (every leg: headline, objevals, lad, trsv, cg,
+# TV, SVM, consensus) -- r1 had to pass --no-extras here because the counter mode crashed on long unsynchronised
+# launch runs; the loops now poll after every batch (engine_run.hip) and the full bench profiles cleanly.
 set -o pipefail
 tag=${1:-rXX}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -16,10 +18,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 for ctr in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $ctr | cut -d_ -f1 | tr 'A-Z' 'a-z')
   timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/prof_${tag}_${lc}" -- \
-    python3 "$root/bench.py" --steps 20 --warmup 2 --no-extras --no-cpu-baseline > "$out/prof_${tag}_${lc}.log" 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/prof_${tag}_tv2d_${lc}" -- \
-    python3 "$root/profiles/tv2d_bench.py" 4096 auto 20 > "$out/prof_${tag}_tv2d_${lc}.log" 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/prof_${tag}_tv_${lc}" -- \
-    python3 "$root/profiles/tv_bench.py" 16777216 20 > "$out/prof_${tag}_tv_${lc}.log" 2>&1 || exit 1
+    python3 "$root/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$out/prof_${tag}_${lc}.log" 2>&1 || exit 1
 done
 echo collected

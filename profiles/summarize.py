@@ -47,6 +47,33 @@ def main():
                          f"{sum(vals) / len(vals) * 1024 * mult / 1e6:.2f} |")
     open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    # per-kernel bytes per launch (largest grid of each kernel = the full-size legs) + average duration from the
+    # stats pass: what bench.py copies into roofline.traffic and DESIGN.md's kernel table cites
+    import json
+    dur = {row["Name"]: float(row["AverageNs"]) / 1e3 for row in csv.DictReader(open(ks))}
+    traffic = {}
+    for d, mult, key in ((fetch, 2.0, "fetch_bytes_per_launch"), (write, 1.0, "write_bytes_per_launch")):
+        by_kernel = collections.defaultdict(dict)
+        for (name, _ctr, grid), vals in pmc(d).items():
+            by_kernel[name][int(grid)] = vals
+        for name, grids in by_kernel.items():
+            g = max(grids, key=lambda k: sum(grids[k]) / len(grids[k]))  # the launches that move the most bytes
+            vals = grids[g]
+            t = traffic.setdefault(name, {})
+            t[key] = sum(vals) / len(vals) * 1024 * mult
+            t[key.replace("bytes_per_launch", "launches_sampled")] = len(vals)
+            t.setdefault("grid", g)
+    for name, t in traffic.items():
+        if name in dur:
+            t["avg_us_all_launches"] = dur[name]
+    keep = {k: v for k, v in traffic.items() if k.startswith(("void admm::", "admm::")) and
+            v.get("fetch_bytes_per_launch", 0) + v.get("write_bytes_per_launch", 0) > 1e5}
+    keep["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of the FULL "
+                     "bench.py --steps 20 --warmup 2 --no-cpu-baseline on MI355X; FETCH_SIZE[KB]*1024*2 (gfx950 "
+                     "wide-read correction, MI355X_MICROARCH.md), WRITE_SIZE[KB]*1024; per kernel the grid with the "
+                     "largest traffic (the 100000x10000 / 4096^2 legs); avg_us_all_launches from --kernel-trace --stats "
+                     "mixes every grid of that kernel")
+    json.dump(keep, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -597,3 +597,15 @@ def test_golden_fixture(gpu, path):
     for k in HIST:
         if k in ref:
             _close(k, got[k], ref[k], tol)
+
+
+def test_total_variation_one_launch_iteration(gpu, monkeypatch):
+    """the opt-in form of the fused TV iteration whose reduction tree and finalize logic run inside the one kernel
+    (last tile of a group sums the group, last group finalizes): same iterates and histories as the oracle"""
+    monkeypatch.setenv("ADMM_HIP_TV_ONE_LAUNCH", "1")
+    for n in (200, 5000, 300011):
+        p = gpu.synth.tv_problem(3, n)
+        o = dict(objevals=1, maxiters=40)
+        got = gpu.totalvariation(p["s"], p["lam"], dict(o))
+        ref = S.totalvariation(p["s"], p["lam"], dict(o))
+        _compare(got, ref)
