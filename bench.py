@@ -162,8 +162,8 @@ def other_configs(ap, L, device, steps):
     n = 4096 * 4096
     p = ap.synth.tv_problem(seed=1, n=n)
     tv = ap.Engine(L.PROB_TOTALVARIATION, s=p["s"], lam=1.0, nvec=n, device=device)
-    k = max(20, steps // 2)
-    tv.run(maxiters=5, domaxiters=1, record_history=0)
+    k = max(300, steps)  # 0.07 s of steady state (a 20-iteration timing is mostly ramp-up)
+    tv.run(maxiters=20, domaxiters=1, record_history=0)
     t0 = time.perf_counter()
     s = tv.run(maxiters=k, domaxiters=1, record_history=0)
     dt = time.perf_counter() - t0
@@ -184,7 +184,7 @@ def other_configs(ap, L, device, steps):
     img += rng.standard_normal((hw, hw))
     npix = hw * hw
     flat = np.asfortranarray(img).reshape(-1, order="F")
-    for tag, xs, k2 in (("", L.XSOLVE_AUTO, max(50, steps)), ("_cg", L.XSOLVE_CG, max(5, steps // 20))):
+    for tag, xs, k2 in (("", L.XSOLVE_AUTO, max(200, steps)), ("_cg", L.XSOLVE_CG, max(10, steps // 20))):
         tv2 = ap.Engine(L.PROB_TV2D, s=flat, lam=1.0, shape=(hw, hw), xsolve=xs, device=device)
         tv2.run(maxiters=2, domaxiters=1, record_history=0)
         t0 = time.perf_counter()
@@ -214,7 +214,7 @@ def consensus_config4(ap, L, p, rho, device, steps):
     m = p["D"].shape[0]
     sl = ap.errorcheck.slicemaker(0, 8, m)
     cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, slices=sl, device=device)
-    k = max(10, steps // 4)
+    k = max(50, steps // 4)
     cons.run(maxiters=3, domaxiters=1, record_history=0, rho=rho, stopcond="both")
     t0 = time.perf_counter()
     s = cons.run(maxiters=k, domaxiters=1, record_history=0, rho=rho, stopcond="both")
@@ -258,7 +258,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     # exactly one D*x and one D'*[3 rhs] pass per iteration = the "A'(Ax-b)" unit, 16mn bytes,
     # row-sharded with ONE all-reduce per iteration when N > 1 (unwrappedadmm.m:96-141).
     lad = ap.Engine(L.PROB_LAD, D=p["D"], s=p["s"], xsolve=xs, device=local, comm=comm)
-    k2 = max(5, a.steps // 4)
+    k2 = max(40, a.steps // 4)
     timed_run(lad, dist, 2)
     lad.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
     dt2, _ = timed_run(lad, dist, k2)
@@ -281,7 +281,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     _leg("objevals1_gram")
     lg = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local, comm=comm,
                    obj_gram=1)
-    kg = max(20, a.steps)
+    kg = max(100, a.steps)
     timed_run(lg, dist, 5, rho=rho, objevals=1)
     dtg, _ = timed_run(lg, dist, kg, rho=rho, objevals=1)
     out["objevals1_gram"] = {"iters_per_s": kg / dtg, "ms_per_step": dtg / kg * 1e3,
@@ -295,7 +295,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     if world == 1:
         _leg("xsolve_trsv")
         lt = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_TRSV, device=local)
-        kt = max(10, a.steps // 4)
+        kt = max(100, a.steps // 2)
         timed_run(lt, dist, 3, rho=rho)
         dtt, _ = timed_run(lt, dist, kt, rho=rho)
         out["xsolve_trsv"] = {"iters_per_s": kt / dtt, "ms_per_step": dtt / kt * 1e3,
@@ -311,7 +311,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
     _leg("matrix_free (cg)")
     mf = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_CG, device=local,
                    comm=comm, cg_tol=1e-10)
-    k3 = max(3, a.steps // 40)
+    k3 = max(10, a.steps // 40)
     timed_run(mf, dist, 1, rho=rho)
     mf.set_profiling([L.K_GEMV_N, L.K_GEMV_T])
     dt3, _ = timed_run(mf, dist, k3, rho=rho)
@@ -335,7 +335,7 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
         # factor chol(D_k'D_k + rho I) per rank, ONE all-reduce of [sum x_k; sum u_k] (2n doubles) per iteration
         cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local,
                          comm=comm, slices=[hi - lo])
-        k4 = max(5, a.steps // 4)
+        k4 = max(50, a.steps // 4)
         timed_run(cons, dist, 2, rho=rho, stopcond="both")
         dt4, _ = timed_run(cons, dist, k4, rho=rho, stopcond="both")
         out["consensus_lasso"] = {"workload": f"consensus lasso, {world} row slices of {hi - lo} x {n}, one per GPU",
@@ -469,7 +469,7 @@ def main():
     # ---- side measurements (same resident data) --------------------------------------------
     if not a.no_extras:
         _leg("objevals1")
-        k1 = max(5, a.steps // 4)
+        k1 = max(50, a.steps // 4)
         timed_run(eng, dist, 2, rho=rho, objevals=1)
         eng.set_profiling([L.K_GEMV_N])
         dt1, _ = timed_run(eng, dist, k1, rho=rho, objevals=1)

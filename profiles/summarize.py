@@ -57,8 +57,9 @@ def main():
         for (name, _ctr, grid), vals in pmc(d).items():
             by_kernel[name][int(grid)] = vals
         for name, grids in by_kernel.items():
-            g = max(grids, key=lambda k: sum(grids[k]) / len(grids[k]))  # the launches that move the most bytes
-            vals = grids[g]
+            g = max(grids, key=lambda k: max(grids[k]))  # the launches that move the most bytes
+            top = max(grids[g])
+            vals = [v for v in grids[g] if v >= 0.5 * top]  # launches enqueued past a stop / CG convergence are no-ops
             t = traffic.setdefault(name, {})
             t[key] = sum(vals) / len(vals) * 1024 * mult
             t[key.replace("bytes_per_launch", "launches_sampled")] = len(vals)
