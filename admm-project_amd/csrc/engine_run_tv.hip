@@ -175,8 +175,6 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   ExtrapArgs& xa = rs.xa;
   (void)alg; (void)len; (void)pa; (void)xa;
 
-  if (o.relax != 1.0 && alg != 0)
-    return fail(ADMM_E_UNSUPPORTED, "relaxation together with fast ADMM is not implemented for total variation");
   std::vector<double> prefix;
   double bstar = 0.0;
   int halo = 0, elems = 0, tile = 0;
@@ -292,7 +290,8 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
           pa.naxpart = 1;
           pa.axld = 0;
           if (tv_relaxed) {
-            launch_tv_relax_z(e->tmpA, e->z, e->u, e->n, o.relax, pa.t, e->zext, e->ctrl, e->stream);
+            // admm.m:517-523: Axhat from z_prev; zming(Axhat, z, u | uhat, rho) -- fast ADMM hands it uhat
+            launch_tv_relax_z(e->tmpA, e->z, alg ? e->uhat : e->u, e->n, o.relax, pa.t, e->zext, e->ctrl, e->stream);
             pa.prox = PROX_GIVEN;
             pa.zgiven = e->zext;
           }

@@ -68,7 +68,10 @@ def test_lasso_tall(gpu, rows, cols, seed, xsolve):
 
 @pytest.mark.parametrize("opts", [dict(relax=1.5, objevals=1, maxiters=8, domaxiters=1),
                                   dict(relax=0.6, rho=2.0, maxiters=8, domaxiters=1),
-                                  dict(relax=1.8, maxiters=6, domaxiters=1, record_history=0)])
+                                  dict(relax=1.8, maxiters=6, domaxiters=1, record_history=0),
+                                  # relaxation combined with fast / accelerated ADMM (admm.m:515-532 with 563-600)
+                                  dict(relax=1.3, fast=1, fasttype="strong", maxiters=8, domaxiters=1),
+                                  dict(relax=0.7, fast=1, fasttype="weak", objevals=1, maxiters=8, domaxiters=1)])
 @pytest.mark.parametrize("n", [128, 5001])
 def test_total_variation_relaxed(gpu, n, opts):
     """a10 with the TV closures: the reference hands Axhat to a z-closure that applies D to it (getProxOps.m:199),
@@ -386,8 +389,6 @@ def test_total_variation_second_run_and_errors(gpu):
     np.testing.assert_array_equal(a["zopt"], b["zopt"])
     np.testing.assert_array_equal(a["zopt"], a["zvals"][:, -1])
     np.testing.assert_array_equal(a["uopt"], a["uvals"][:, -1])
-    with pytest.raises(gpu.AdmmError):
-        gpu.admm(minx, minz, dict(base, relax=1.5, fast=1))  # relaxation + fast ADMM: not implemented for TV
     c = gpu.admm(minx, minz, dict(base, fast=1, maxiters=7, domaxiters=1))  # fast ADMM: the unfused TV path
     assert c["steps"] == 7 and "avals" in c
 
