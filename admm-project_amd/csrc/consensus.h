@@ -58,10 +58,17 @@ struct ConsArgs {
   double* zhist;            // zeros (q9)
   double* uhist;            // ubar
   double* part;             // [S_COUNT][kMaxPartBlocks]
+  const double* Dts;        // [K][ldn] D_k'*s_k of the local slices
+  double* Y;                // [K][ldn] right-hand sides of the NEXT x-update, y_k = rho*(z - u_k) + D_k's_k
+                            // (getProxOps.m:1240), written by the update kernel: no per-slice rhs launches
 };
 
 void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, const double* Dts, double* y,
                      const Ctrl* ctrl, hipStream_t stream);
+// the same from the x-solves' partial rows (slices with an explicit inverse of order >= kSymvHalfMin): also writes X
+int launch_cons_gather_sum(int64_t n, int64_t ldn, int32_t K, const double* npart, const double* tpart, int64_t pstride,
+                           int64_t ldp, int32_t ntile, double* X, const double* U, double* sums, const double* center,
+                           double* qpart, const Ctrl* ctrl, hipStream_t stream);
 int launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
                     const double* center, double* qpart, const Ctrl* ctrl, hipStream_t stream);
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);

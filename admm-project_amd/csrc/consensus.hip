@@ -61,6 +61,75 @@ __global__ __launch_bounds__(kBlock) void cons_sum_kernel(int64_t n, int64_t ldn
   }
 }
 
+// The same sums straight from the partial rows the lower-triangle x-solves left behind (symv.hip): x_k[i] is
+// assembled here -- ntile + 1 rows per slice, split over the four slots of a 512-thread workgroup, all loads of a
+// round issued together -- and stored for the update kernel, so the K symv_reduce launches (and their boundaries)
+// disappear.  npart / tpart: [K][pstride] with rows of ldp elements.
+constexpr int kCgTile = 128, kCgSlots = 4, kCgRows = 20;
+__global__ __launch_bounds__(kCgTile* kCgSlots) void cons_gather_sum_kernel(
+    int64_t n, int64_t ldn, int32_t K, const double* __restrict__ npart, const double* __restrict__ tpart,
+    int64_t pstride, int64_t ldp, int32_t ntile, double* __restrict__ X, const double* __restrict__ U,
+    double* __restrict__ sums, const double* __restrict__ center, double* __restrict__ qpart,
+    const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double part[kCgSlots - 1][kCgTile];
+  __shared__ double scratch[kCgTile * kCgSlots / 64];
+  const int e = threadIdx.x & (kCgTile - 1), slot = threadIdx.x >> 7;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kCgTile + e;
+  const int64_t ic = i < n ? i : n - 1;
+  const int32_t d = static_cast<int32_t>(ic / kCgTile);
+  const int32_t P = ntile + 1, per = (P + kCgSlots - 1) / kCgSlots;
+  const int32_t p0 = slot * per, p1 = (p0 + per < P) ? p0 + per : P;
+  double sx = 0.0, su = 0.0, q = 0.0;
+  const double c = (qpart && slot == 0) ? center[ic] : 0.0;
+  for (int32_t k = 0; k < K; ++k) {
+    const double* __restrict__ nk = npart + static_cast<int64_t>(k) * pstride;
+    const double* __restrict__ tk = tpart + static_cast<int64_t>(k) * pstride;
+    double s = 0.0;
+    for (int32_t p = p0; p < p1; p += kCgRows) {
+      double v[kCgRows];
+#pragma unroll
+      for (int r = 0; r < kCgRows; ++r) {
+        const int32_t pq = (p + r < p1) ? p + r : p1 - 1;
+        const double* src = (pq <= d) ? nk + static_cast<int64_t>(pq) * ldp : tk + static_cast<int64_t>(pq - 1) * ldp;
+        v[r] = src[ic];
+      }
+#pragma unroll
+      for (int r = 0; r < kCgRows; ++r)
+        if (p + r < p1) s += v[r];
+    }
+    if (p0 >= P) s = 0.0;
+    __syncthreads();  // part[] of the previous slice has been consumed
+    if (slot > 0) part[slot - 1][e] = s;
+    __syncthreads();
+    if (slot == 0 && i < n) {
+      const double xk = ((s + part[0][e]) + part[1][e]) + part[2][e];
+      X[k * ldn + i] = xk;
+      su = su + U[k * ldn + i];
+      sx = sx + xk;
+      const double dd = xk - c;
+      q = __builtin_fma(dd, dd, q);
+    }
+  }
+  if (slot == 0 && i < n) {
+    sums[i] = sx;
+    sums[ldn + i] = su;
+  }
+  if (qpart) {
+    const double t = block_sum(q, scratch);
+    if (threadIdx.x == 0) qpart[blockIdx.x] = t;
+  }
+}
+
+int launch_cons_gather_sum(int64_t n, int64_t ldn, int32_t K, const double* npart, const double* tpart, int64_t pstride,
+                           int64_t ldp, int32_t ntile, double* X, const double* U, double* sums, const double* center,
+                           double* qpart, const Ctrl* ctrl, hipStream_t stream) {
+  const int64_t blocks = ceil_div(n, kCgTile);
+  hipLaunchKernelGGL(cons_gather_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kCgTile * kCgSlots), 0, stream, n,
+                     ldn, K, npart, tpart, pstride, ldp, ntile, X, U, sums, center, qpart, ctrl);
+  return qpart ? static_cast<int>(blocks) : 0;
+}
+
 // returns the number of qpart blocks written (0 when qpart is null)
 int launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
                     const double* center, double* qpart, const Ctrl* ctrl, hipStream_t stream) {
@@ -93,7 +162,9 @@ __global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const C
     double dev = 0.0;
     for (int32_t k = 0; k < a.K; ++k) {
       const double xk = a.X[k * a.ldn + i];
-      a.U[k * a.ldn + i] = a.U[k * a.ldn + i] + (xk - z);
+      const double uk = a.U[k * a.ldn + i] + (xk - z);
+      a.U[k * a.ldn + i] = uk;
+      a.Y[k * a.ldn + i] = a.rho * (z - uk) + a.Dts[k * a.ldn + i];  // the next x-update's y_k (getProxOps.m:1240)
       const double d = xk - xave;
       dev += d * d;
     }

@@ -1021,6 +1021,25 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(e->mem.alloc(&e->cxaveprev, e->cldn));
       E_TRY(e->mem.alloc(&e->cubar, e->cldn));
       E_TRY(e->mem.alloc(&e->cy, e->cldn));
+      {  // every slice applies an explicit inverse through the lower-triangle kernel: keep one set of partial rows per
+         // slice, summed by the exchange kernel itself (launch_cons_gather_sum) instead of K symv_reduce launches
+        bool all_half = n >= kSymvHalfMin;
+        for (const ConsSlice& sl : e->cslices) all_half = all_half && !sl.fat && sl.fac.mode == ADMM_XSOLVE_INVERSE;
+        if (all_half && K * kMaxPartBlocks >= K && ceil_div(n, 128) <= kMaxPartBlocks) {
+          const SymvPlan& pl = e->cslices[0].fac.planSy;
+          e->cpstride = static_cast<int64_t>(pl.npart_elems());
+          E_TRY(e->mem.alloc(&e->csyN, K * static_cast<size_t>(e->cpstride)));
+          E_TRY(e->mem.alloc(&e->csyT, K * static_cast<size_t>(e->cpstride)));
+          E_HIP(hipMemsetAsync(e->csyN, 0, sizeof(double) * K * e->cpstride, e->stream));
+          E_HIP(hipMemsetAsync(e->csyT, 0, sizeof(double) * K * e->cpstride, e->stream));
+        }
+      }
+      E_TRY(e->mem.alloc(&e->cY, K * e->cldn));
+      E_TRY(e->mem.alloc(&e->cDts, K * e->cldn));
+      E_HIP(hipMemsetAsync(e->cDts, 0, sizeof(double) * K * e->cldn, e->stream));
+      for (int32_t k = 0; k < desc->nslices; ++k)
+        E_HIP(hipMemcpyAsync(e->cDts + k * e->cldn, e->cslices[k].Dts, sizeof(double) * n, hipMemcpyDeviceToDevice,
+                             e->stream));
       E_TRY(e->mem.alloc(&e->cobjpart, K * kMaxPartBlocks));
       break;
     }

@@ -30,6 +30,8 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
   ADMM_HIP_TRY(hipMemsetAsync(e->cxaveprev, 0, sizeof(double) * ldn, e->stream));
   ADMM_HIP_TRY(hipMemcpyAsync(e->cubar, e->u, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
   ADMM_HIP_TRY(hipMemsetAsync(e->cobjpart, 0, sizeof(double) * K * kMaxPartBlocks, e->stream));
+  // y_k of the first x-update: rho*(z - u_k) + D_k's_k with z = u_k = 0; every later one comes from the update kernel
+  ADMM_HIP_TRY(hipMemcpyAsync(e->cY, e->cDts, sizeof(double) * K * ldn, hipMemcpyDeviceToDevice, e->stream));
   ConsArgs ca{};
   ca.n = n;
   ca.ldn = ldn;
@@ -48,6 +50,8 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
   ca.zhist = e->zhist;
   ca.uhist = e->uhist;
   ca.part = e->part;
+  ca.Dts = e->cDts;
+  ca.Y = e->cY;
   fa.specialnorms = 1;
   fa.nslices_total = e->cons_total;
   fa.g = nullptr;
@@ -66,24 +70,33 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
         TimerScope ts(e, ADMM_K_XSOLVE);
         for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
           ConsSlice& sl = e->cslices[k];
-          launch_cons_rhs(n, o.rho, e->czc, e->cU + k * ldn, sl.Dts, e->cy, e->ctrl, e->stream);
-          if (!sl.fat) {
-            apply_slice_factor(e, sl.fac, e->cy, e->cX + k * ldn);
+          const double* yk = e->cY + k * ldn;  // rho*(z - u_k) + D_k's_k, left by the previous update kernel
+          if (e->csyN) {  // leave the partial rows: the exchange kernel assembles x_k
+            launch_symv_lower(sl.fac.planSy, sl.fac.Minv, sl.fac.ldM, yk, e->csyN + k * e->cpstride,
+                              e->csyT + k * e->cpstride, nullptr, e->ctrl, e->stream, 0, 1, false);
+          } else if (!sl.fat) {
+            apply_slice_factor(e, sl.fac, yk, e->cX + k * ldn);
           } else {  // x_k = y/rho - D_k'(U\(L\(D_k y)))/rho^2   (getProxOps.m:1204 form, q12)
-            launch_gemv_n(sl.planN, sl.D, e->cy, e->partDN, e->ctrl, e->stream);
+            launch_gemv_n(sl.planN, sl.D, yk, e->partDN, e->ctrl, e->stream);
             launch_sum_partials(e->partDN, sl.planN.nchunk, sl.planN.ldy, sl.m, e->tmpA, e->ctrl, e->stream);
             apply_slice_factor(e, sl.fac, e->tmpA, e->tmpB);
             launch_gemv_t(sl.planT, sl.D, e->tmpB, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
-            launch_combine(e->partDT, sl.planT.nchunk, sl.planT.ldg, -1.0 / (o.rho * o.rho), e->cy, 1.0 / o.rho, nullptr,
+            launch_combine(e->partDT, sl.planT.nchunk, sl.planT.ldg, -1.0 / (o.rho * o.rho), yk, 1.0 / o.rho, nullptr,
                            e->cX + k * ldn, n, e->ctrl, e->stream);
           }
         }
       }
+      const SymvPlan* gp = e->csyN ? &e->cslices[0].fac.planSy : nullptr;
       if (shard) {
         // X1 + X2 in ONE collective: [sum x_k; sum u_k; q] with q = sum_k ||x_k - xave_prev||^2 (consensus.hip)
-        const int nq = launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->cxave, e->objpart, e->ctrl, e->stream);
+        const int nq = gp ? launch_cons_gather_sum(n, ldn, K, e->csyN, e->csyT, e->cpstride, gp->ldp, gp->ntile, e->cX,
+                                                   e->cU, e->csums, e->cxave, e->objpart, e->ctrl, e->stream)
+                          : launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, e->cxave, e->objpart, e->ctrl, e->stream);
         launch_pack_sum(e->objpart, nq, e->csums + 2 * ldn, e->ctrl, e->stream);
         ADMM_TRY(comm_allreduce_device(e->comm, e->csums, static_cast<size_t>(2 * ldn + 1), e->stream));
+      } else if (gp) {
+        launch_cons_gather_sum(n, ldn, K, e->csyN, e->csyT, e->cpstride, gp->ldp, gp->ntile, e->cX, e->cU, e->csums,
+                               nullptr, nullptr, e->ctrl, e->stream);
       } else {
         launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, nullptr, nullptr, e->ctrl, e->stream);
       }

@@ -610,3 +610,14 @@ def test_total_variation_one_launch_iteration(gpu, monkeypatch):
         got = gpu.totalvariation(p["s"], p["lam"], dict(o))
         ref = S.totalvariation(p["s"], p["lam"], dict(o))
         _compare(got, ref)
+
+
+def test_consensus_lasso_partial_row_gather_path(gpu):
+    """n >= 1536: every slice's x-solve is the lower-triangle kernel and the exchange kernel assembles x_k from its
+    partial rows (no symv_reduce launches); 3 slices, against the 3-slice oracle"""
+    p = gpu.synth.lasso_problem(7, 3 * 1700, 1600)
+    o = dict(objevals=1, parallel="both", maxiters=25)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, workers=3, xsolve="inverse"))
+    ref = S.lasso(p["D"], p["s"], p["lam"], dict(o, slices=0), workers=3)
+    _compare(got, ref, keys=("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq"))
+    assert got["engine_info"]["xsolve_used"] == "inverse"
