@@ -63,8 +63,6 @@ struct ConsArgs {
                             // (getProxOps.m:1240), written by the update kernel: no per-slice rhs launches
 };
 
-void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, const double* Dts, double* y,
-                     const Ctrl* ctrl, hipStream_t stream);
 // the same from the x-solves' partial rows (slices with an explicit inverse of order >= kSymvHalfMin): also writes X
 int launch_cons_gather_sum(int64_t n, int64_t ldn, int32_t K, const double* npart, const double* tpart, int64_t pstride,
                            int64_t ldp, int32_t ntile, double* X, const double* U, double* sums, const double* center,

@@ -6,25 +6,6 @@
 
 namespace admm {
 
-// y_k = rho*(z - u_k) + Dts_k      getProxOps.m:1240
-__global__ __launch_bounds__(kBlock) void cons_rhs_kernel(int64_t n, double rho, const double* __restrict__ z,
-                                                          const double* __restrict__ u,
-                                                          const double* __restrict__ Dts, double* __restrict__ y,
-                                                          const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * kBlock)
-    y[i] = rho * (z[i] - u[i]) + Dts[i];
-}
-
-void launch_cons_rhs(int64_t n, double rho, const double* z, const double* u, const double* Dts, double* y,
-                     const Ctrl* ctrl, hipStream_t stream) {
-  int64_t blocks = ceil_div(n, kBlock);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cons_rhs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, n, rho, z, u, Dts,
-                     y, ctrl);
-}
-
 // sums[0][i] = sum_k x_k[i], sums[1][i] = sum_k u_k[i]   (getProxOps.m:1281-1284, slice order)
 // qpart (sharded runs, else null): block partials of q = sum_k ||x_k - c||^2 about the PREVIOUS mean c = xaveprev,
 // which every rank knows before the exchange.  With it lassonorms' first value (getProxOps.m:1338-1340)

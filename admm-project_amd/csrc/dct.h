@@ -28,6 +28,10 @@ void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t 
 // frequency i) -> DCT-II along W, divide by 1 + rho*(lamH[i] + lamW[k]), DCT-III back
 void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const DctTables& th, const DctTables& tw,
                            const Ctrl* ctrl, hipStream_t stream);
+// the same on the untransposed image img (H x W, column-major), row pairs read and written at stride H: replaces
+// transpose -> rows_solve -> transpose
+void launch_dct_rows_solve_strided(double* img, int64_t H, int64_t W, double rho, const DctTables& th,
+                                   const DctTables& tw, const Ctrl* ctrl, hipStream_t stream);
 // dst (cols x rows, column-major) = src (rows x cols, column-major) transposed
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
                       hipStream_t stream);

@@ -249,6 +249,70 @@ __global__ __launch_bounds__(kBlock) void dct_rows_solve_kernel(double* __restri
 }
 
 // 64 x 64 tiles through LDS (65-double pitch: conflict-free both ways); fully coalesced on both sides
+// The same solve on the image where it lies (H x W, column-major): the workgroup of row pair (i, i+1) reads, for every
+// column j, the 16 bytes img[i..i+1, j] -- already the complex pair (a_j, b_j) the joint FFT wants -- at stride H,
+// and writes them back the same way: no transposed copy of the image, two passes over it instead of six.  The access
+// is 16 bytes per 8H-byte stride; what keeps it off HBM is that the 8 workgroups sharing a 128-byte line run at the
+// same time on ONE XCD (row pairs are dealt to the XCDs in contiguous ranges: workgroup b -> XCD b mod 8 under
+// round-robin placement, speed only) and that the image (134 MB at 4096^2) sits in the 256 MB Infinity Cache right
+// after the column pass wrote it.
+__global__ __launch_bounds__(kBlock) void dct_rows_solve_strided_kernel(double* __restrict__ img, int64_t H, double rho,
+                                                                        const double* __restrict__ lamH, DctTables t,
+                                                                        const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int n = t.n, p = t.log2n;
+  const unsigned npairs = gridDim.x;
+  // contiguous ranges of row pairs per XCD (npairs is a power of two >= 8 here; smaller images fall back below)
+  const unsigned b = blockIdx.x;
+  const unsigned pair = (npairs >= 8) ? (b & 7u) * (npairs >> 3) + (b >> 3) : b;
+  double* __restrict__ base = img + 2 * static_cast<int64_t>(pair);
+  // Makhoul order: x[2k] -> v[k], x[2k+1] -> v[n-1-k]; all loads of a thread are independent
+#pragma unroll 8
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const admm_double2 v = load2<false>(base + static_cast<int64_t>(j) * H);
+    const int k = j >> 1;
+    zs[swz((j & 1) ? n - 1 - k : k)] = c64{v.x, v.y};
+  }
+  __syncthreads();
+  fft_network<false>(zs, n, p, t.tw);
+  const double la = lamH[2 * pair], lb = lamH[2 * pair + 1];
+  const double* __restrict__ lam = t.lam;
+#pragma unroll 2
+  for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
+    if (k == 0) {
+      const c64 z0 = zs[0];
+      zs[0] = c64{z0.x / (1.0 + rho * la), z0.y / (1.0 + rho * lb)};  // lam[0] = 0
+    } else if (k == (n >> 1)) {
+      const c64 h = zs[1];
+      zs[1] = c64{h.x / (1.0 + rho * (la + lam[k])), h.y / (1.0 + rho * (lb + lam[k]))};
+    } else {
+      const int rk = swz(bitrev(k, p)), rn = swz(bitrev(n - k, p));
+      const c64 ck = t.c4[k];
+      double xak, xan, xbk, xbn;
+      spectrum_to_dct(zs[rk], zs[rn], ck, xak, xan, xbk, xbn);
+      const double lk = lam[k], ln = lam[n - k];
+      xak /= 1.0 + rho * (la + lk);
+      xan /= 1.0 + rho * (la + ln);
+      xbk /= 1.0 + rho * (lb + lk);
+      xbn /= 1.0 + rho * (lb + ln);
+      c64 zk, zn;
+      dct_to_spectrum(xak, xan, xbk, xbn, ck, zk, zn);
+      zs[rk] = zk;
+      zs[rn] = zn;
+    }
+  }
+  __syncthreads();
+  fft_network<true>(zs, n, p, t.tw);
+  const double scale = 1.0 / static_cast<double>(n);
+#pragma unroll 8
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int k = j >> 1;
+    const c64 v = zs[swz((j & 1) ? n - 1 - k : k)];
+    store2<false>(base + static_cast<int64_t>(j) * H, admm_double2{v.x * scale, v.y * scale});
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void transpose_kernel(const double* __restrict__ src, double* __restrict__ dst,
                                                            int64_t rows, int64_t cols, const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
@@ -311,6 +375,14 @@ void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const Dc
   dct_allow_lds(dct_rows_solve_kernel, dct_lds_bytes(tw.n));
   hipLaunchKernelGGL(dct_rows_solve_kernel, dim3(static_cast<unsigned>(H / 2)), dim3(kBlock), dct_lds_bytes(tw.n),
                      stream, t, W, rho, th.lam, tw, ctrl);
+}
+
+void launch_dct_rows_solve_strided(double* img, int64_t H, int64_t W, double rho, const DctTables& th,
+                                   const DctTables& tw, const Ctrl* ctrl, hipStream_t stream) {
+  (void)W;
+  dct_allow_lds(dct_rows_solve_strided_kernel, dct_lds_bytes(tw.n));
+  hipLaunchKernelGGL(dct_rows_solve_strided_kernel, dim3(static_cast<unsigned>(H / 2)), dim3(kBlock),
+                     dct_lds_bytes(tw.n), stream, img, H, rho, th.lam, tw, ctrl);
 }
 
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,

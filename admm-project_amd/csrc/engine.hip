@@ -98,13 +98,6 @@ static int ensure_sy_buffers(admm_engine* e, const SymvPlan& plan) {
   return ADMM_OK;
 }
 
-// leading dimension of a tile-padded symmetric matrix: ADMM_SYMV_LD_ALIGN (doubles, default 1 = npad) is an experiment knob
-static int64_t symv_ld(int64_t npad) {
-  int64_t a = 1;
-  if (const char* f = std::getenv("ADMM_SYMV_LD_ALIGN")) a = std::atoll(f);
-  return a > 1 ? round_up(npad, a) : npad;
-}
-
 // f.Minv (tile-padded, zeros outside n x n) = X' X with X = inv(L): the explicit inverse of L L'
 static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
   const int64_t n = f.n, ld = f.ld;
@@ -112,7 +105,7 @@ static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
   ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
   int rc = trtri_lower_from_diag(f.F, n, ld, f.dinv, X, ld, e->stream);
   f.planSy = symv_plan(n);
-  f.ldM = symv_ld(f.planSy.npad);
+  f.ldM = f.planSy.npad;  // (4 / 8 / 16 KiB-aligned columns were measured: no effect on the lower-triangle kernel)
   if (rc == ADMM_OK) rc = e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.planSy.npad);
   if (rc == ADMM_OK) {
     (void)hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.planSy.npad, e->stream);
@@ -359,7 +352,7 @@ int factorize_pinv(admm_engine* e, double* W, int64_t n, int64_t ld) {
   ADMM_HIP_TRY(hipMemcpyAsync(lam, lh.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
   launch_scale_cols(V, ldv, n, lam, e->stream);  // V <- V diag(lambda^-1/2)
   f.planSy = symv_plan(n);
-  f.ldM = symv_ld(f.planSy.npad);
+  f.ldM = f.planSy.npad;  // (4 / 8 / 16 KiB-aligned columns were measured: no effect on the lower-triangle kernel)
   ADMM_TRY(e->mem.alloc(&f.Minv, static_cast<size_t>(f.ldM) * f.planSy.npad));
   ADMM_HIP_TRY(hipMemsetAsync(f.Minv, 0, sizeof(double) * f.ldM * f.planSy.npad, e->stream));
   launch_gemm(0, 1, n, n, n, 1.0, V, ldv, V, ldv, 0.0, f.Minv, f.ldM, true, e->stream);
@@ -1020,7 +1013,6 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       E_TRY(e->mem.alloc(&e->cxave, e->cldn));
       E_TRY(e->mem.alloc(&e->cxaveprev, e->cldn));
       E_TRY(e->mem.alloc(&e->cubar, e->cldn));
-      E_TRY(e->mem.alloc(&e->cy, e->cldn));
       {  // every slice applies an explicit inverse through the lower-triangle kernel: keep one set of partial rows per
          // slice, summed by the exchange kernel itself (launch_cons_gather_sum) instead of K symv_reduce launches
         bool all_half = n >= kSymvHalfMin;

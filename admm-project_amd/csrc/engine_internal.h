@@ -140,7 +140,7 @@ struct admm_engine {
   std::vector<ConsSlice> cslices;
   int32_t cons_total = 0;  // slicenum over all ranks
   double *cX = nullptr, *cU = nullptr, *csums = nullptr, *czc = nullptr, *cxave = nullptr, *cxaveprev = nullptr,
-         *cubar = nullptr, *cy = nullptr, *cobjpart = nullptr, *cDts = nullptr, *cY = nullptr;
+         *cubar = nullptr, *cobjpart = nullptr, *cDts = nullptr, *cY = nullptr;
   double *csyN = nullptr, *csyT = nullptr;  // per-slice partial rows of the lower-triangle x-solves ([K][cpstride])
   int64_t cpstride = 0;
   int64_t cldn = 0;

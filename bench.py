@@ -197,9 +197,9 @@ def other_configs(ap, L, device, steps):
             gb = (23.0 + 10.0 * inner) * 8.0 * npix / 1e9
             extra = {"x_update": "cg", "cg_inner_iters_per_step": inner, "cg_tol": 1e-11}
         else:
-            # fused z/u/dual/rhs pass 6N read + 5N written; spectral solve: five in-place passes (column DCT,
-            # transpose, row DCT + scale + inverse, transpose, column inverse) = 10N
-            gb = 21.0 * 8.0 * npix / 1e9
+            # fused z/u/dual/rhs pass 6N read + 5N written; spectral solve: three in-place passes (column DCT, row
+            # DCT + scale + inverse on row pairs at stride H, column inverse) = 6N   (round 1: five passes, 10N)
+            gb = 17.0 * 8.0 * npix / 1e9
             extra = {"x_update": "dct"}
         res["totalvariation2d_4096x4096" + tag] = dict(
             {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3, "algorithmic_GB_per_iter": gb,
