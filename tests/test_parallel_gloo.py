@@ -72,6 +72,15 @@ def _worker(rank, world, port, q):
         full = S.linearsvm(p["D"], p["ell"], p["C"], dict(x0=p["x0"], z0=p["z0"], u0=p["u0"]))
         checks["svm"] = (r["steps"] == full["steps"], float(np.max(np.abs(r["xvals"] - full["xvals"]))),
                          float(np.max(np.abs(r["Hnormsq"] - full["Hnormsq"]) / np.maximum(full["Hnormsq"], 1e-12))))
+        # --- consensus lasso with ONE packed exchange per iteration == the 4-slice oracle (2 local slices per rank)
+        p = ap.synth.lasso_problem(1, 256, 64)
+        lo4, hi4 = parallel.my_rows(256, rank, world)
+        r = parallel_ref.sharded_consensus_lasso(p["D"][lo4:hi4], p["s"][lo4:hi4], p["lam"], [64, 64], allreduce)
+        full = S.lasso(p["D"], p["s"], p["lam"], dict(parallel="both", slices=0), workers=4)
+        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
+        checks["consensus"] = (r["steps"] == full["steps"], float(np.max(np.abs(r["xvals"] - full["xvals"]))),
+                               float(np.max(np.abs(r["uvals"] - full["uvals"]))), rel(r["pnorm"], full["pnorm"]),
+                               rel(r["dnorm"], full["dnorm"]), rel(r["perr"], full["perr"]), rel(r["derr"], full["derr"]))
         out["checks"] = checks
 
         # --- gather of row-sharded slices
@@ -112,5 +121,9 @@ def test_two_rank_gloo():
         assert c["lad"][0] and c["lad"][1] < 1e-9 and c["lad"][2] < 1e-6 and c["lad"][3] < 1e-6 and c["lad"][4] < 1e-9
         assert c["huber"][0] and c["huber"][1] < 1e-9
         assert c["svm"][0] and c["svm"][1] < 1e-7 and c["svm"][2] < 1e-6
+        # the packed exchange: iterates to 1e-10; lassonorms' first value is a difference of two shrinking sums
+        # (q - N*||xave - c||^2): about one digit lost, far inside the 1e-6 bar
+        cc = c["consensus"]
+        assert cc[0] and cc[1] < 1e-10 and cc[2] < 1e-10 and cc[3] < 1e-8 and cc[4] < 1e-8 and cc[5] < 1e-10 and cc[6] < 1e-10
         np.testing.assert_array_equal(res[rank]["gathered"], np.arange(515.0))
         assert res[rank]["tmax"] == 2.0
