@@ -80,24 +80,6 @@ def _get(args, name):
     return args[name]
 
 
-def _reduce_kkt(P, D, s, rho):
-    """[M D'; D 0] \\ [y; s] = K*y + k0 with M = P + rho*I (P = None: rho*I), S = D inv(M) D':
-    K = inv(M) - inv(M) D' inv(S) D inv(M) (symmetric), k0 = inv(M) D' inv(S) s."""
-    n = D.shape[1]
-    if P is None:
-        Minv = np.eye(n) / rho
-    else:
-        Minv = np.linalg.inv(P + rho * np.eye(n))
-        Minv = 0.5 * (Minv + Minv.T)
-    MD = Minv @ D.T                      # n x m
-    S = D @ MD                           # m x m
-    SinvDM = np.linalg.solve(S, MD.T)    # m x n
-    K = Minv - MD @ SinvDM
-    K = 0.5 * (K + K.T)
-    k0 = MD @ np.linalg.solve(S, s)
-    return np.asfortranarray(K), k0
-
-
 def getproxops(problem, args):
     """Prox-operator factory (getProxOps.m:13-917).  ``args`` uses the reference's field names.
 
@@ -167,8 +149,8 @@ def getproxops(problem, args):
         prob = _Problem("linearsvm", eng, dict(A="D", c=0.0, nA=n, nB=m))
     elif kind == "linearprogram" or (kind == "quadraticprogram" and _get(args, "constraint") == "standard"):
         # getProxOps.m:1363 / 1410 solve [M D'; D 0] \ [rho*(z-u) - q; s] every iteration (M = rho*I for the
-        # LP, P + rho*I for the QP).  The binding reduces that KKT system ONCE (cold path, host LAPACK, like
-        # basis pursuit's projector) to x = K*y + k0; the per-iteration n x n GEMV runs on the device.
+        # LP, P + rho*I for the QP).  The engine eliminates that KKT system ONCE, on the device (create():
+        # build_kkt_map), to x = K*y + k0; the loop runs one n x n GEMV per x-update.
         D, s = _get(args, "D"), np.asarray(_get(args, "s"), dtype=np.float64).reshape(-1)
         D = np.asarray(D, dtype=np.float64)
         n = D.shape[1]
@@ -179,10 +161,9 @@ def getproxops(problem, args):
         r0 = float(args.get("r", 0.0))
 
         def build(rho_):
-            K, k0 = _reduce_kkt(P, D, s, rho_)
             if lp:
-                return Engine(L.PROB_LINEARPROGRAM, q=q, K=K, k0=k0, rho=rho_, device=dev)
-            return Engine(L.PROB_QP_STANDARD, P=P, q=q, K=K, k0=k0, rho=rho_, r=r0, device=dev)
+                return Engine(L.PROB_LINEARPROGRAM, D=D, s=s, q=q, rho=rho_, device=dev)
+            return Engine(L.PROB_QP_STANDARD, D=D, s=s, P=P, q=q, rho=rho_, r=r0, device=dev)
 
         prob = _Problem(kind, build(rho), dict(A=1, c=0.0, nA=n, nB=n), rebuild=build, rho=rho)
     elif kind == "quadraticprogram":
@@ -206,9 +187,14 @@ def getproxops(problem, args):
                      shape=(H, W), xsolve=xs, device=dev, **cg)
         prob = _Problem("totalvariation2d", eng, dict(A="D", c=0.0, nA=H * W, nB=2 * H * W))
     elif kind == "basispursuit":
-        P, q = _get(args, "P"), _get(args, "q")
-        n = P.shape[0]
-        eng = Engine(L.PROB_BASISPURSUIT, P=P, q=q, device=dev)
+        if "P" in args:  # getProxOps.m:137-138: the projector and offset computed by the caller (basispursuit.m:116-120)
+            P, q = _get(args, "P"), _get(args, "q")
+            n = P.shape[0]
+            eng = Engine(L.PROB_BASISPURSUIT, P=P, q=q, device=dev)
+        else:            # engine-side: the same two from D and s, on the device (create(): build_bp_projector)
+            D = np.asarray(_get(args, "D"), dtype=np.float64)
+            n = D.shape[1]
+            eng = Engine(L.PROB_BASISPURSUIT, D=D, s=_get(args, "s"), device=dev)
         prob = _Problem("basispursuit", eng, dict(A=1, c=0.0, nA=n, nB=n))
     elif kind == "model":
         # getProxOps.m:83-89: the Gram data; engine-side extension: args.P/Q/r/s (the matrices

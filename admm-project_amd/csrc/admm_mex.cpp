@@ -195,15 +195,20 @@ void describe(const std::string& p, const mxArray* args, const mxArray* handles,
     d.r = opt_scalar(handles, "r", opt_scalar(args, "r", 0.0));
     ds.nA = ds.nB = d.n;
   } else if (p == "quadraticprogram" || p == "linearprogram") {
-    // getProxOps.m:1363 / 1410: the (n+m) x (n+m) KKT solve, reduced once by matlab/getproxops.m to x = K*y + k0
+    // getProxOps.m:1363 / 1410 solve the (n+m) x (n+m) KKT system in every x-update; the engine eliminates the
+    // multiplier once, on the device, from args.D / args.s for args.rho (a caller may also hand in the map: args.K, k0)
     const mxArray* K = field(args, "K");
-    if (!is_dense_double(K)) mexErrMsgIdAndTxt("admm:arg", "args.K / args.k0 (reduced KKT map) are missing");
     const bool qp = p == "quadraticprogram";
     d.problem = qp ? ADMM_PROB_QP_STANDARD : ADMM_PROB_LINEARPROGRAM;
-    d.D = nullptr;
-    d.K = mxGetPr(K);
-    d.k0 = opt_vec(args, "k0");
-    d.m = d.n = static_cast<int64_t>(mxGetN(K));
+    if (is_dense_double(K)) {
+      d.D = nullptr;
+      d.K = mxGetPr(K);
+      d.k0 = opt_vec(args, "k0");
+      d.m = d.n = static_cast<int64_t>(mxGetN(K));
+    } else {
+      if (!haveD) mexErrMsgIdAndTxt("admm:arg", "args.D must be a full real matrix");
+      d.s = opt_vec(args, "s");
+    }
     d.q = qp ? opt_vec(args, "q") : opt_vec(args, "b");
     if (qp) {
       const mxArray* P = field(args, "P");
@@ -212,13 +217,18 @@ void describe(const std::string& p, const mxArray* args, const mxArray* handles,
     }
     ds.nA = ds.nB = d.n;
   } else if (p == "basispursuit") {  // getProxOps.m:137-138
+    // args = {P, q} as basispursuit.m:116-120 forms them; with args = {D, s} the engine forms both on the device
     const mxArray* P = field(args, "P");
-    if (!is_dense_double(P)) mexErrMsgIdAndTxt("admm:arg", "args.P must be a full real matrix");
     d.problem = ADMM_PROB_BASISPURSUIT;
-    d.D = nullptr;
-    d.P = mxGetPr(P);
-    d.m = d.n = static_cast<int64_t>(mxGetN(P));
-    d.q = opt_vec(args, "q");
+    if (is_dense_double(P)) {
+      d.D = nullptr;
+      d.P = mxGetPr(P);
+      d.m = d.n = static_cast<int64_t>(mxGetN(P));
+      d.q = opt_vec(args, "q");
+    } else {
+      if (!haveD) mexErrMsgIdAndTxt("admm:arg", "args.P (or args.D and args.s) must be full real matrices");
+      d.s = opt_vec(args, "s");
+    }
     ds.nA = ds.nB = d.n;
   } else if (p == "model") {  // getProxOps.m:83-89
     d.problem = ADMM_PROB_MODEL;

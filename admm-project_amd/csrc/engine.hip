@@ -303,6 +303,123 @@ static int decide_sy_split(admm_engine* e) {
   return ADMM_OK;
 }
 
+// ---- one-time reductions some solvers do before the loop, on the device ---------------------------------------------
+// W (n x n, ld, lower triangle valid, SPD) -> its explicit inverse, full symmetric storage (tile-padded, ld *ldM).
+// W is destroyed; the result is owned by e->mem (release with mem_free_one).
+static int spd_inverse(admm_engine* e, double* W, int64_t n, int64_t ld, double** Minv, int64_t* ldM) {
+  SliceFactor f{};
+  f.F = W;
+  f.n = n;
+  f.ld = ld;
+  ADMM_TRY(e->mem.alloc(&f.dinv, static_cast<size_t>(ceil_div(n, 64)) * 64 * 64));
+  double* infod = nullptr;
+  ADMM_TRY(e->mem.alloc(&infod, 1));
+  ADMM_TRY(cholesky_lower(W, n, ld, reinterpret_cast<int32_t*>(infod), f.dinv, e->stream));
+  int32_t info = 0;
+  ADMM_HIP_TRY(hipMemcpyAsync(&info, infod, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  mem_free_one(e->mem, infod);
+  if (info != 0)
+    return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " + std::to_string(info) +
+                                    "): the constraint matrix needs full row rank");
+  ADMM_TRY(build_explicit_inverse(e, f));
+  mem_free_one(e->mem, f.dinv);
+  *Minv = f.Minv;
+  *ldM = f.ldM;
+  return ADMM_OK;
+}
+
+// out[n] = alpha * T' * v for T (m x n, ldt)
+static int scaled_tdot(admm_engine* e, const double* T, int64_t m, int64_t n, int64_t ldt, const double* v, double alpha,
+                       double* out) {
+  const GemvTPlan pt = gemv_t_plan(m, n, ldt);
+  double *part = nullptr, *tmp = nullptr;
+  ADMM_TRY(e->mem.alloc(&part, pt.part_elems(1)));
+  ADMM_TRY(e->mem.alloc(&tmp, round_up(n, 2)));
+  launch_gemv_t(pt, T, v, nullptr, nullptr, 1, part, nullptr, e->stream);
+  launch_sum_partials_t(pt, part, 1, tmp, round_up(n, 2), nullptr, e->stream);
+  launch_combine(tmp, 1, 0, alpha, nullptr, 0.0, nullptr, out, n, nullptr, e->stream);
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  mem_free_one(e->mem, part);
+  mem_free_one(e->mem, tmp);
+  return ADMM_OK;
+}
+
+// basispursuit.m:116-120: P = I - D'(DD')^-1 D, q = D'(DD')^-1 s for a fat D (m x n, m < n) -- MFMA GEMMs, the
+// Cholesky factorisation and the explicit m x m inverse on the device (the reference computes them in MATLAB)
+static int build_bp_projector(admm_engine* e, const double* D, int64_t m, int64_t n, int64_t ldD, const double* s_dev) {
+  const int64_t ldw = round_up(m, 16);
+  double *W = nullptr, *Ginv = nullptr, *X = nullptr;
+  int64_t ldG = 0;
+  ADMM_TRY(e->mem.alloc(&W, static_cast<size_t>(ldw) * m));
+  ADMM_HIP_TRY(hipMemsetAsync(W, 0, sizeof(double) * ldw * m, e->stream));
+  launch_gemm(0, 1, m, m, n, 1.0, D, ldD, D, ldD, 0.0, W, ldw, true, e->stream);  // D*D'
+  ADMM_TRY(spd_inverse(e, W, m, ldw, &Ginv, &ldG));
+  ADMM_TRY(e->mem.alloc(&X, static_cast<size_t>(ldw) * n));
+  launch_gemm(0, 0, m, n, m, 1.0, Ginv, ldG, D, ldD, 0.0, X, ldw, false, e->stream);  // (DD')^-1 D
+  e->ldP = round_up(n, 16);
+  ADMM_TRY(e->mem.alloc(&e->Pmat, static_cast<size_t>(e->ldP) * n));
+  ADMM_HIP_TRY(hipMemsetAsync(e->Pmat, 0, sizeof(double) * e->ldP * n, e->stream));
+  launch_gemm(1, 0, n, n, m, -1.0, D, ldD, X, ldw, 0.0, e->Pmat, e->ldP, false, e->stream);  // -D'(DD')^-1 D
+  launch_add_diag(e->Pmat, n, e->ldP, 1.0, e->stream);
+  ADMM_TRY(e->mem.alloc(&e->q, round_up(n, 2)));
+  ADMM_TRY(scaled_tdot(e, X, m, n, ldw, s_dev, 1.0, e->q));  // X' s
+  mem_free_one(e->mem, W);
+  mem_free_one(e->mem, Ginv);
+  mem_free_one(e->mem, X);
+  return ADMM_OK;
+}
+
+// getProxOps.m:1363 / 1410 solve [M D'; D 0] [x; nu] = [y; s] every iteration, M = rho*I (linear program) or P + rho*I
+// (standard-form QP).  Eliminating nu ONCE gives x = K*y + k0 with
+//   K = inv(M) - inv(M) D' inv(S) D inv(M),  k0 = inv(M) D' inv(S) s,  S = D inv(M) D'
+// -- built here with MFMA GEMMs and two explicit SPD inverses; the loop then runs one symmetric GEMV per x-update.
+static int build_kkt_map(admm_engine* e, const double* D, int64_t m, int64_t n, int64_t ldD, const double* s_dev,
+                         const double* P /* null: LP */, int64_t ldPm, double rho) {
+  const int64_t ldn = round_up(n, 16), ldm = round_up(m, 16);
+  double *MD = nullptr, *S = nullptr, *Sinv = nullptr, *T2 = nullptr, *Mi = nullptr;
+  int64_t ldS = 0, ldMi = 0;
+  e->ldK = ldn;
+  ADMM_TRY(e->mem.alloc(&e->Kmat, static_cast<size_t>(ldn) * n));
+  ADMM_HIP_TRY(hipMemsetAsync(e->Kmat, 0, sizeof(double) * ldn * n, e->stream));
+  ADMM_TRY(e->mem.alloc(&MD, static_cast<size_t>(ldn) * m));  // inv(M) D'  (n x m)
+  if (P) {
+    double* Mw = nullptr;
+    ADMM_TRY(e->mem.alloc(&Mw, static_cast<size_t>(ldn) * n));
+    ADMM_HIP_TRY(hipMemsetAsync(Mw, 0, sizeof(double) * ldn * n, e->stream));
+    ADMM_HIP_TRY(hipMemcpy2DAsync(Mw, ldn * sizeof(double), P, ldPm * sizeof(double), n * sizeof(double), n,
+                                  hipMemcpyDeviceToDevice, e->stream));
+    launch_add_diag(Mw, n, ldn, rho, e->stream);
+    ADMM_TRY(spd_inverse(e, Mw, n, ldn, &Mi, &ldMi));
+    mem_free_one(e->mem, Mw);
+    launch_gemm(0, 1, n, m, n, 1.0, Mi, ldMi, D, ldD, 0.0, MD, ldn, false, e->stream);
+    ADMM_HIP_TRY(hipMemcpy2DAsync(e->Kmat, ldn * sizeof(double), Mi, ldMi * sizeof(double), n * sizeof(double), n,
+                                  hipMemcpyDeviceToDevice, e->stream));  // K starts as inv(M)
+  } else {
+    // inv(M) = I / rho:  MD = D'/rho  (a transposed, scaled copy through the GEMM with the identity left out:
+    // MD(:, j) = D(j, :)'/rho is just the GEMM D' * (I/rho) -- done as a transpose-free product below)
+    double* Ieye = nullptr;
+    ADMM_TRY(e->mem.alloc(&Ieye, static_cast<size_t>(ldm) * m));
+    ADMM_HIP_TRY(hipMemsetAsync(Ieye, 0, sizeof(double) * ldm * m, e->stream));
+    launch_add_diag(Ieye, m, ldm, 1.0 / rho, e->stream);
+    launch_gemm(1, 0, n, m, m, 1.0, D, ldD, Ieye, ldm, 0.0, MD, ldn, false, e->stream);
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    mem_free_one(e->mem, Ieye);
+    launch_add_diag(e->Kmat, n, ldn, 1.0 / rho, e->stream);  // K starts as I / rho
+  }
+  ADMM_TRY(e->mem.alloc(&S, static_cast<size_t>(ldm) * m));
+  ADMM_HIP_TRY(hipMemsetAsync(S, 0, sizeof(double) * ldm * m, e->stream));
+  launch_gemm(0, 0, m, m, n, 1.0, D, ldD, MD, ldn, 0.0, S, ldm, true, e->stream);  // S = D inv(M) D'
+  ADMM_TRY(spd_inverse(e, S, m, ldm, &Sinv, &ldS));
+  ADMM_TRY(e->mem.alloc(&T2, static_cast<size_t>(ldm) * n));  // inv(S) D inv(M)  (m x n)
+  launch_gemm(0, 1, m, n, m, 1.0, Sinv, ldS, MD, ldn, 0.0, T2, ldm, false, e->stream);
+  launch_gemm(0, 0, n, n, m, -1.0, MD, ldn, T2, ldm, 1.0, e->Kmat, ldn, false, e->stream);  // K -= MD * T2
+  ADMM_TRY(e->mem.alloc(&e->k0, round_up(n, 2)));
+  ADMM_TRY(scaled_tdot(e, T2, m, n, ldm, s_dev, 1.0, e->k0));  // k0 = T2' s = inv(M) D' inv(S) s
+  for (double* p : {MD, S, Sinv, T2, Mi}) mem_free_one(e->mem, p);
+  return ADMM_OK;
+}
+
 // the engine's own x-update factor
 int factorize(admm_engine* e, double* W, int64_t nF, int64_t ld, const double* Lgiven, int memkind) {
   SliceFactor& f = e->xfac;
@@ -762,14 +879,27 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       break;
     }
     case ADMM_PROB_BASISPURSUIT: {
-      if (!desc->P || !desc->q || n <= 0) return bail(fail(ADMM_E_INVALID, "basis pursuit needs P (n x n) and q"));
+      const bool from_data = !desc->P && desc->D && desc->s && m > 0 && n > m;
+      if (!from_data && (!desc->P || !desc->q || n <= 0))
+        return bail(fail(ADMM_E_INVALID, "basis pursuit needs the projector P (n x n) and q, or a fat D (m < n) and s"));
       e->a_identity = true;
       e->nA = n;
       e->len = n;
       e->prox = PROX_SOFT;
       e->rhs_kind = RHS_DIFF;
-      E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
-      E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+      if (from_data) {  // basispursuit.m:116-120 on the device
+        double *Dd = nullptr, *sd = nullptr;
+        int64_t ldd = 0;
+        E_TRY(upload_matrix(e->mem, &Dd, &ldd, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+        E_TRY(upload(e->mem, &sd, desc->s, m, mk, e->stream));
+        E_TRY(build_bp_projector(e, Dd, m, n, ldd, sd));
+        mem_free_one(e->mem, Dd);
+        mem_free_one(e->mem, sd);
+        e->m = n;
+      } else {
+        E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
+        E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
+      }
       e->planSq = gemv_t_plan(n, n, e->ldP);
       E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
       e->xsolve = ADMM_XSOLVE_INVERSE;  // x = P*(z-u) + q is a GEMV by construction
@@ -835,23 +965,35 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     case ADMM_PROB_LINEARPROGRAM:
     case ADMM_PROB_QP_STANDARD: {
       const bool qp = desc->problem == ADMM_PROB_QP_STANDARD;
-      if (!desc->K || !desc->k0 || !desc->q || n <= 0 || (qp && !desc->P))
-        return bail(fail(ADMM_E_INVALID, qp ? "standard-form QP needs P, q and the reduced KKT map K, k0"
-                                            : "linear program needs b (as q) and the reduced KKT map K, k0"));
+      const bool from_data = !desc->K && desc->D && desc->s && m > 0 && m < n;
+      if ((!from_data && (!desc->K || !desc->k0)) || !desc->q || n <= 0 || (qp && !desc->P))
+        return bail(fail(ADMM_E_INVALID, qp ? "standard-form QP needs P, q and either the reduced KKT map K, k0 or D, s"
+                                            : "linear program needs b (as q) and either the reduced KKT map K, k0 or D, s"));
       e->a_identity = true;
       e->nA = n;
       e->len = n;
       e->prox = PROX_POS;                 // getProxOps.m:1381, 1425
       e->rhs_kind = RHS_RHO_MINUS_Q;      // y = rho*(z-u) - b   (getProxOps.m:1363, 1410)
-      E_TRY(upload_matrix(e->mem, &e->Kmat, &e->ldK, desc->K, n, n, n, mk, e->stream));
-      E_TRY(upload(e->mem, &e->k0, desc->k0, n, mk, e->stream));
+      if (qp) E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
+      if (from_data) {  // the KKT elimination on the device, for desc.rho
+        double *Dd = nullptr, *sd = nullptr;
+        int64_t ldd = 0;
+        E_TRY(upload_matrix(e->mem, &Dd, &ldd, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+        E_TRY(upload(e->mem, &sd, desc->s, m, mk, e->stream));
+        E_TRY(build_kkt_map(e, Dd, m, n, ldd, sd, qp ? e->Pmat : nullptr, e->ldP, desc->rho));
+        mem_free_one(e->mem, Dd);
+        mem_free_one(e->mem, sd);
+        e->m = n;
+      } else {
+        E_TRY(upload_matrix(e->mem, &e->Kmat, &e->ldK, desc->K, n, n, n, mk, e->stream));
+        E_TRY(upload(e->mem, &e->k0, desc->k0, n, mk, e->stream));
+      }
       E_TRY(upload(e->mem, &e->q, desc->q, n, mk, e->stream));
       e->rhs_add = e->q;
       e->ell = e->q;                      // objective b'*x (linearprogram.m:178) reads it as the dot vector
       e->planK = gemv_t_plan(n, n, e->ldK);
       E_TRY(e->mem.alloc(&e->partK, e->planK.part_elems(1)));
       if (qp) {  // the objective 1/2 x'Px + q'x + r needs P*x
-        E_TRY(upload_matrix(e->mem, &e->Pmat, &e->ldP, desc->P, n, n, n, mk, e->stream));
         e->planSq = gemv_t_plan(n, n, e->ldP);
         E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
       }

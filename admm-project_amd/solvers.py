@@ -281,8 +281,8 @@ def linearprogram(b, D, s, options=None):
 def basispursuit(D, s, options=None):
     """results = basispursuit(D, s, options)   (solvers/basispursuit.m:52-145).
 
-    The projector P = I - D'(DD')^-1 D and q = D'(DD')^-1 s (basispursuit.m:116-120) are a
-    one-time m x m solve done on the host (cold path); the per-iteration n x n GEMV and the
+    The projector P = I - D'(DD')^-1 D and q = D'(DD')^-1 s (basispursuit.m:116-120) are formed once by the
+    engine on the device (MFMA GEMMs + Cholesky + explicit m x m inverse); the per-iteration n x n GEMV and the
     shrinkage run on the device.
     """
     if not isinstance(options, dict):
@@ -299,10 +299,7 @@ def basispursuit(D, s, options=None):
     if mD != s.size:
         raise ValueError("The number of rows in matrix D must match the number of rows in signal vector s!")
     n = nD
-    DDt = D @ D.T
-    P = np.eye(n) - D.T @ np.linalg.solve(DDt, D)
-    q = D.T @ np.linalg.solve(DDt, s)
-    minx, minz, _ = getproxops("BasisPursuit", _engine_args(options, dict(P=P, q=q)))
+    minx, minz, _ = getproxops("BasisPursuit", _engine_args(options, dict(D=D, s=s)))
     options.update(A=1, B=-1, c=0, m=n, nA=n, nB=n)
     options["obj"] = _ENGINE_OBJ  # basispursuit.m:140 norm(x,1)
     results = admm(minx, minz, options)

@@ -73,10 +73,10 @@ for k = 1:numel(hooks)
 end
 
 [args, handles] = attachobjective(problem, args, options, handles);
-args = reducekkt(problem, args, options);
 
 % rho the cached factor is built for = the rho of this run (the reference's closures re-factor on
 % rho ~= rhoprev, getProxOps.m:1222-1238, 1446-1453; xminLASSO keeps the caller's factor, 1192-1206)
+% (the linear program's args carry no rho at all: the engine eliminates its KKT multiplier for this rho, on the device)
 if isfield(options, 'rho') && ~(isfield(args, 'L') || isfield(args, 'R'))
     args.rho = options.rho;
 end
@@ -224,33 +224,4 @@ if isfield(known, problem) && any(strcmp(txt, known.(problem)))
 else
     handles.obj = options.obj;
 end
-end
-
-function args = reducekkt(problem, args, options)
-% getProxOps.m:1363 (linear program) and 1410 (standard-form QP) solve
-%     [M D'; D 0] * [x; nu] = [rho*(z - u) - q; s],   M = rho*I  or  P + rho*I
-% in every iteration.  Eliminating nu once gives the affine map the device applies:
-%     x = K*y + k0,  K = inv(M) - inv(M)*D'*inv(S)*D*inv(M),  k0 = inv(M)*D'*inv(S)*s,  S = D*inv(M)*D'.
-standard = strcmp(problem, 'linearprogram') || (strcmp(problem, 'quadraticprogram') && ...
-    isfield(args, 'constraint') && strcmp(args.constraint, 'standard'));
-if ~standard
-    return;
-end
-rho = 1.0;
-if isfield(options, 'rho')
-    rho = options.rho;
-end
-D = full(args.D);
-n = size(D, 2);
-if strcmp(problem, 'linearprogram')
-    M = rho*eye(n);
-else
-    M = full(args.P) + rho*eye(n);
-end
-MiDt = M \ D';
-S = D*MiDt;
-K = inv(M) - MiDt*(S \ MiDt');
-args.K = (K + K')/2;
-args.k0 = MiDt*(S \ args.s(:));
-args.rho = rho;
 end

@@ -494,3 +494,43 @@ def test_generic_handles_with_function_handle_operators(gpu, opts):
     _compare(got, mat, tol=1e-9)
     with pytest.raises(ValueError, match="options.At must be one too"):
         gpu.admm(xt, zt, dict(o, A=A_t, At=Amat.T))
+
+
+@pytest.mark.parametrize("qp,rho", [(False, 1.0), (False, 2.5), (True, 1.0), (True, 0.3)])
+def test_device_kkt_map_matches_the_kkt_solve(gpu, qp, rho):
+    """getProxOps.m:1363 / 1410 solve [M D'; D 0] \\ [rho*(z-u) - q; s] in every x-update; create() eliminates the
+    multiplier once, on the device (build_kkt_map): the first x-update from a given (z0, u0) must equal that
+    (n+m) x (n+m) solve."""
+    p = gpu.synth.qp_standard_problem(3, 12, 40)
+    n, m = 40, 12
+    rng = np.random.default_rng(0)
+    z0, u0 = rng.standard_normal(n), rng.standard_normal(n)
+    o = dict(rho=rho, maxiters=1, domaxiters=1, z0=z0, u0=u0)
+    if qp:
+        got = gpu.quadraticprogram(p["P"], p["q"], p["r"], p["D"], p["s"], dict(o, constraint="standard"))
+        M, lin = p["P"] + rho * np.eye(n), p["q"]
+    else:
+        b = rng.standard_normal(n)
+        got = gpu.linearprogram(b, p["D"], p["s"], dict(o))
+        M, lin = rho * np.eye(n), b
+    kkt = np.block([[M, p["D"].T], [p["D"], np.zeros((m, m))]])
+    x = np.linalg.solve(kkt, np.concatenate([rho * (z0 - u0) - lin, p["s"]]))[:n]
+    np.testing.assert_allclose(got["xvals"][:, 0], x, rtol=1e-9, atol=1e-11)
+
+
+def test_basispursuit_projector_built_on_device(gpu):
+    """basispursuit.m:116-120: P = I - D'(DD')^-1 D, q = D'(DD')^-1 s formed by create() from D and s; getproxops
+    still accepts the reference's args.P / args.q"""
+    p = gpu.synth.basispursuit_problem(1, 24, 80)
+    D, sv = p["D"], p["s"]
+    o = dict(objevals=1, maxiters=200)
+    a = gpu.basispursuit(D, sv, dict(o))
+    G = D @ D.T
+    P = np.eye(80) - D.T @ np.linalg.solve(G, D)
+    q = D.T @ np.linalg.solve(G, sv)
+    minx, minz, _ = gpu.getproxops("BasisPursuit", dict(P=P, q=q))
+    b = gpu.admm(minx, minz, dict(o, A=1, B=-1, c=0, m=80, nA=80, nB=80,
+                                  obj=lambda x, z: __import__("torch").sum(__import__("torch").abs(x))))
+    assert a["steps"] == b["steps"]
+    np.testing.assert_allclose(a["xvals"], b["xvals"], rtol=0, atol=1e-10)
+    _compare(a, S.basispursuit(D, sv, dict(o)), tol=1e-8)

@@ -155,6 +155,45 @@ def test_mex_total_variation(gpu, mex):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rho", [1.0, 2.5])
+def test_mex_linear_program_and_standard_qp(gpu, mex, rho):
+    """linearprogram.m:160-180 / quadraticprogram.m:193-209: args = {D, b | P q, s, n}; the reference solves the KKT
+    system in every x-update (getProxOps.m:1363, 1410), the engine eliminates the multiplier once on the device"""
+    p = gpu.synth.lp_problem(0, 24, 72)
+    n = 72
+    options = dict(objevals=1, A=1, At=1, B=-1, c=0, m=n, nA=n, nB=n, rho=rho, maxiters=200)
+    got = mex.call("solve", "linearprogram", dict(D=p["D"], b=p["b"], s=p["s"], n=n, rho=rho), options,
+                   dict(objnative=1))
+    ref = S.linearprogram(p["b"], p["D"], p["s"], dict(objevals=1, rho=rho, maxiters=200))
+    _same(got, ref, HIST + ("objevals",), tol=1e-7)
+    q = gpu.synth.qp_standard_problem(0, 20, 64)
+    n = 64
+    options = dict(objevals=1, A=1, At=1, B=-1, c=0, m=n, nA=n, nB=n, rho=rho, maxiters=200)
+    args = dict(P=q["P"], q=q["q"], D=q["D"], s=q["s"], rho=rho, n=n, constraint="standard")
+    got = mex.call("solve", "quadraticprogram", args, options, dict(objnative=1, r=q["r"]))
+    ref = S.quadraticprogram_standard(q["P"], q["q"], q["r"], q["D"], q["s"], dict(objevals=1, rho=rho, maxiters=200))
+    _same(got, ref, HIST + ("objevals",), tol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["Pq", "Ds"])
+def test_mex_basis_pursuit(gpu, mex, form):
+    """basispursuit.m:116-140: args = {P, q} (the projector the solver forms); or {D, s}, formed on the device"""
+    p = gpu.synth.basispursuit_problem(0, 24, 72)
+    D, s = p["D"], p["s"]
+    n = 72
+    if form == "Pq":
+        DDt = D @ D.T
+        args = dict(P=np.eye(n) - D.T @ np.linalg.solve(DDt, D), q=D.T @ np.linalg.solve(DDt, s))
+    else:
+        args = dict(D=D, s=s)
+    options = dict(objevals=1, A=1, At=1, B=-1, c=0, m=n, nA=n, nB=n, maxiters=300)
+    got = mex.call("solve", "basispursuit", args, options, dict(objnative=1))
+    ref = S.basispursuit(D, s, dict(objevals=1, maxiters=300))
+    _same(got, ref, HIST + ("objevals",), tol=1e-7)
+
+
+@pytest.mark.gpu
 def test_mex_generic_admm_with_two_matlab_handles(gpu, mex):
     """results = admm(xminf, zming, options) with both operators the caller's (admm.m:24;
     examples/convergencechecking.m:125-136): the loop, u-update, residuals and stop logic on the device, the two

@@ -161,18 +161,3 @@ def test_linearprogram_criterion(ap):  # linearprogramtest.m:122-134
     Dx = p["D"] @ x
     assert np.mean(np.abs((Dx - p["s"]) / Dx)) <= 1e-3
     assert abs(r["objopt"] - float(p["b"] @ x)) <= 1e-9 * abs(r["objopt"])
-
-
-def test_kkt_reduction_matches_the_kkt_solve(ap):
-    """api._reduce_kkt: the affine map the device applies == the (n+m) x (n+m) solve of getProxOps.m:1363/1410."""
-    from admm_project_amd.api import _reduce_kkt
-    p = ap.synth.qp_standard_problem(3, 12, 40)
-    rng = np.random.default_rng(0)
-    for P, rho in ((None, 1.0), (None, 2.5), (p["P"], 1.0), (p["P"], 0.3)):
-        K, k0 = _reduce_kkt(P, p["D"], p["s"], rho)
-        n, m = 40, 12
-        M = rho * np.eye(n) if P is None else P + rho * np.eye(n)
-        kkt = np.block([[M, p["D"].T], [p["D"], np.zeros((m, m))]])
-        y = rng.standard_normal(n)
-        x = np.linalg.solve(kkt, np.concatenate([y, p["s"]]))[:n]
-        np.testing.assert_allclose(K @ y + k0, x, rtol=1e-10, atol=1e-12)
