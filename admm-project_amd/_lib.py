@@ -110,6 +110,8 @@ _SIGNATURES = {
     "admm_engine_set_callbacks": (C.c_int, [C.c_void_p, PROX_CALLBACK, C.c_void_p, PROX_CALLBACK, C.c_void_p,
                                             OBJ_CALLBACK, C.c_void_p]),
     "admm_engine_set_operators": (C.c_int, [C.c_void_p, OPERATOR_CALLBACK, C.c_void_p, OPERATOR_CALLBACK, C.c_void_p]),
+    "admm_engine_set_constraint_b": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int32,
+                                               C.c_double, OPERATOR_CALLBACK, C.c_void_p]),
     "admm_engine_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary)]),
     "admm_engine_fetch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "admm_engine_info": (C.c_int, [C.c_void_p, C.POINTER(EngineInfo)]),

@@ -8,8 +8,9 @@ x-/z-update and share one device-resident problem (data + cached factor).  When 
 receives a matching pair it runs the whole loop (admm.m:496-743) on the device through
 the C ABI.  ``options`` and ``results`` are dicts with the reference's field names.
 Caller-supplied prox handles (the reference's plain function handles, as in
-examples/convergencechecking.m, or the zming of unwrappedadmm) are supported for B = -1 with
-A = 1 or A = the library problem's data matrix: they are called with
+examples/convergencechecking.m, or the zming of unwrappedadmm) are supported next to a library
+operator (A and B then belong to that problem: B = -1) or as a pair of their own with any A / At / B
+the reference accepts (scalars, matrices, function handles; admm.m:113-245): they are called with
 zero-copy CUDA tensors of the engine's state on the engine's HIP stream and must return
 CUDA tensors; the rest of the iteration stays in the fused kernels.  There is no CPU
 fallback: a handle that returns a host array is rejected loudly.
@@ -232,6 +233,8 @@ def _check_constraint(options, prob):
     if "B" not in options:
         raise ValueError("Must specify a matrix B in constraint Ax + Bz = c!")
     B = options["B"]
+    if prob.kind == "generic":
+        return  # both handles are the caller's: A, B, c and the sizes were taken from options (_generic_problem)
     if not (np.isscalar(B) and float(B) == -1.0):
         raise ValueError("engine-native problems use B = -1 (z enters the constraint as -z)")
     exp = prob.expect
@@ -239,8 +242,6 @@ def _check_constraint(options, prob):
     if exp["A"] == 1:
         if not (np.isscalar(A) and float(A) == 1.0):
             raise ValueError(f"{prob.kind}: constraint matrix A must be the scalar 1")
-    elif callable(A) and prob.kind == "generic":
-        pass  # function-handle operators (admm.m:117-158): sizes were taken from options.nA / nB
     else:
         if np.isscalar(A) or tuple(A.shape) != (exp["nB"], exp["nA"]):
             raise ValueError(f"{prob.kind}: constraint matrix A must be the data matrix D")
@@ -263,77 +264,108 @@ _CALLBACK_KINDS = ("model", "lasso", "quadraticprogram", "linearprogram", "basis
 
 
 def _generic_problem(options):
-    """Both prox operators are the caller's handles: the state, the u-update, residuals, histories
-    and stop logic of admm.m:496-743 still run on the device; only A = 1, B = -1 (the shorthand
-    examples/convergencechecking.m:110-115 uses) is engine-native."""
+    """Both prox operators are the caller's handles: the state, the u-update, residuals, histories and stop logic of
+    admm.m:496-743 still run on the device.  A: the scalar 1 (examples/convergencechecking.m:110-115), another scalar,
+    a matrix or a function handle with At (admm.m:113-195); B: the shorthand -1, another scalar, an m x nB matrix or a
+    function handle with options.nB (admm.m:198-245)."""
     A, B = options.get("A"), options.get("B")
     if A is None:
         raise ValueError("Must specify a matrix A in constraint Ax + Bz = c!")
     if B is None:
         raise ValueError("Must specify a matrix B in constraint Ax + Bz = c!")
-    if not (np.isscalar(B) and float(B) == -1.0):
-        raise NotImplementedError("caller-supplied prox handles run with B = -1 (every solver of the reference "
-                                  "uses it); a general B is not engine-native")
     if hasattr(A, "toarray"):
         A = A.toarray()  # sparse operators (totalvariation.m:127) are streamed as dense columns
-    if not np.isscalar(A) and np.ndim(A) == 2:
+    if hasattr(B, "toarray"):
+        B = B.toarray()
+    dev = int(options.get("device", 0))
+    if callable(B) and int(options.get("nB", 0)) <= 0:  # admm.m:206-212
+        raise ValueError("Matrix B is a function handle, but no number of columns nB specified for it; cannot infer nB "
+                         "- please specify it in options struct!")
+    if not (callable(B) or np.isscalar(B) or np.ndim(B) == 2):  # admm.m:217-222
+        raise ValueError("Given B in constraint Ax + Bz = c is neither a numeric matrix nor function handle of single "
+                         "vector!")
+
+    def cvector(m):
+        c = options.get("c", 0.0)
+        if np.isscalar(c):
+            if float(c) != 0.0:
+                raise NotImplementedError("scalar non-zero c is not supported")
+            return np.zeros(m)
+        cvec = np.asarray(c, dtype=np.float64).reshape(-1)
+        if cvec.size != m:
+            raise ValueError("Given vector c does not match the problem size")
+        return cvec
+
+    if np.isscalar(A) and float(A) != 1.0:  # A = a*I as the pair of handles v -> a*v (admm.m:117-120)
+        a = float(A)
+        c = options.get("c", 0.0)
+        mm = int(options.get("m", 0)) or (0 if np.isscalar(c) else np.size(c)) or int(options.get("nA", 0))
+        A = lambda v: a * v  # noqa: E731
+        options = dict(options, A=A, At=A, nA=int(options.get("nA", 0)) or mm, m=mm)
+    if not np.isscalar(A) and not callable(A) and np.ndim(A) == 2:
         # a constraint matrix (admm.m:117-120: A(v) = A*v, At(v) = A'*v): the A = D engine of lad.m with no
         # factor at all -- both prox operators are the caller's; D*x, D'*(.), the residuals run on the device
         Am = np.asfortranarray(np.asarray(A, dtype=np.float64))
         m, n = Am.shape
         At = options.get("At")
-        if At is not None and not np.isscalar(At) and np.shape(At) != (n, m):
+        if At is not None and not np.isscalar(At) and not callable(At) and np.shape(At) != (n, m):
             raise ValueError("options.At is not the transpose of options.A")
-        c = options.get("c", 0.0)
-        if np.isscalar(c):
-            if float(c) != 0.0:
-                raise NotImplementedError("scalar non-zero c is not supported")
-            cvec = np.zeros(m)
-        else:
-            cvec = np.asarray(c, dtype=np.float64).reshape(-1)
-            if cvec.size != m:
-                raise ValueError("Given vector c does not match the problem size")
-        eng = Engine(L.PROB_LAD, D=Am, s=cvec, xsolve=L.XSOLVE_CALLBACK, device=int(options.get("device", 0)))
-        return _Problem("generic", eng, dict(A="D", c="s", nA=n, nB=m))
-    if callable(A):
+        eng = Engine(L.PROB_LAD, D=Am, s=cvector(m), xsolve=L.XSOLVE_CALLBACK, device=dev)
+        prob = _Problem("generic", eng, dict(A="D", c="s", nA=n, nB=m, m=m))
+    elif callable(A):
         # options.A / options.At as function handles (admm.m:117-158): no matrix exists; A(x) and At(v) are device
         # callbacks like the prox operators, everything else of the loop stays in the fused kernels
         At = options.get("At")
         if not callable(At):
             raise ValueError("options.A is a function handle: options.At must be one too (admm.m:139-158)")
-        nA, nB = int(options.get("nA", 0)), int(options.get("nB", 0) or options.get("m", 0))
-        if nA <= 0 or nB <= 0:
-            raise ValueError("function-handle operators need the sizes options.nA and options.nB (or m)")
+        nA = int(options.get("nA", 0))
         c = options.get("c", 0.0)
-        if np.isscalar(c):
-            if float(c) != 0.0:
-                raise NotImplementedError("scalar non-zero c is not supported")
-            cvec = np.zeros(nB)
-        else:
-            cvec = np.asarray(c, dtype=np.float64).reshape(-1)
-            if cvec.size != nB:
-                raise ValueError("Given vector c does not match the problem size")
-        eng = Engine(L.PROB_LAD, s=cvec, shape=(nB, nA), xsolve=L.XSOLVE_CALLBACK, device=int(options.get("device", 0)))
+        m = int(options.get("m", 0)) or (0 if np.isscalar(c) else np.size(c))
+        if not m and np.isscalar(B):
+            m = int(options.get("nB", 0))
+        if nA <= 0 or m <= 0:
+            raise ValueError("function-handle operators need the sizes options.nA and options.m (or nB)")
+        eng = Engine(L.PROB_LAD, s=cvector(m), shape=(m, nA), xsolve=L.XSOLVE_CALLBACK, device=dev)
         eng.set_operators(A, At)
-        return _Problem("generic", eng, dict(A="D", c="s", nA=nA, nB=nB))
-    if not (np.isscalar(A) and float(A) == 1.0):
-        raise NotImplementedError("caller-supplied prox handles run with A = 1, a constraint matrix A, or function "
-                                  "handles A / At")
-    c = options.get("c", 0.0)
-    n = int(options.get("nA", 0) or options.get("nB", 0) or options.get("m", 0))
-    cvec = None
-    if not np.isscalar(c):
-        cvec = np.asarray(c, dtype=np.float64).reshape(-1)
-        n = n or cvec.size
-        if cvec.size != n:
-            raise ValueError("Given vector c does not match the problem size")
-    elif float(c) != 0.0:
-        raise NotImplementedError("scalar non-zero c is not supported")
-    if n <= 0:
-        raise ValueError("Given vector c is scalar and no length m has been provided")
-    eng = Engine(L.PROB_MODEL, nvec=n, c=cvec, rho=float(_setopt(options, "rho", 1.0)),
-                 device=int(options.get("device", 0)))
-    return _Problem("generic", eng, dict(A=1, c=0.0, nA=n, nB=n))
+        prob = _Problem("generic", eng, dict(A="D", c="s", nA=nA, nB=m, m=m))
+    elif np.isscalar(A):
+        c = options.get("c", 0.0)
+        n = int(options.get("nA", 0) or options.get("m", 0) or (options.get("nB", 0) if np.isscalar(B) else 0))
+        cvec = None
+        if not np.isscalar(c):
+            cvec = np.asarray(c, dtype=np.float64).reshape(-1)
+            n = n or cvec.size
+            if cvec.size != n:
+                raise ValueError("Given vector c does not match the problem size")
+        elif float(c) != 0.0:
+            raise NotImplementedError("scalar non-zero c is not supported")
+        if n <= 0:
+            raise ValueError("Given vector c is scalar and no length m has been provided")
+        eng = Engine(L.PROB_MODEL, nvec=n, c=cvec, rho=float(_setopt(options, "rho", 1.0)), device=dev)
+        prob = _Problem("generic", eng, dict(A=1, c=0.0, nA=n, nB=n, m=n))
+    else:
+        raise ValueError("Given A in constraint Ax + Bz = c is neither a numeric matrix nor function handle of single "
+                         "vector!")  # admm.m:131-134
+    m = prob.expect["m"]
+    try:
+        if callable(B):  # admm.m:206-216
+            nB = int(options["nB"])
+            eng.set_constraint_b(B, nB)
+            prob.expect.update(nB=nB, B="general")
+        elif np.isscalar(B):
+            if float(B) != -1.0:
+                eng.set_constraint_b(float(B))
+                prob.expect["B"] = "general"
+        elif np.ndim(B) == 2:  # admm.m:202-204, 226-229
+            if np.shape(B)[0] != m:
+                raise ValueError("Number of rows in matrix B do not match length of column vector c in constraint "
+                                 "Ax + Bz = c")
+            eng.set_constraint_b(B)
+            prob.expect.update(nB=int(np.shape(B)[1]), B="general")
+    except BaseException:
+        eng.close()
+        raise
+    return prob
 
 
 _ADAPTIVE_KINDS = ("lasso", "lad", "huberfit", "totalvariation", "linearsvm", "quadraticprogram", "basispursuit",
@@ -348,8 +380,9 @@ def _admm_adaptive(xminf, zming, options, prob):
     current one (admm.m:678)."""
     if _setopt(options, "fast", 0):
         raise NotImplementedError("options.adaptive together with fast ADMM is not supported")
-    if prob.kind not in _ADAPTIVE_KINDS:
-        raise NotImplementedError(f"options.adaptive is not supported for the '{prob.kind}' operators")
+    if prob.kind not in _ADAPTIVE_KINDS or prob.expect.get("B") == "general":
+        raise NotImplementedError(f"options.adaptive is not supported for the '{prob.kind}' operators"
+                                  + (" with a general B" if prob.expect.get("B") == "general" else ""))
     rho = float(_setopt(options, "rho", 1.0))
     rho_H = rho
     N = _setopt(options, "maxiters", 1000)
@@ -454,7 +487,7 @@ def admm(xminf, zming, options):
             raise NotImplementedError(f"caller-supplied prox handles cannot be mixed with the '{prob.kind}' operators "
                                       "(supported: " + ", ".join(_CALLBACK_KINDS) + ")")
     else:
-        prob = _generic_problem(options)  # both handles are the caller's: admm.m:24 as is (A = 1, B = -1)
+        prob = _generic_problem(options)  # both handles are the caller's: admm.m:24 as is
     rho_run = float(_setopt(options, "rho", 1.0))
     if prob.rebuild is not None and rho_run != prob.rho and rho_run > 0:
         prob.engine.close()  # the closure's "rho ~= rhoprev" branch: new cached factor / KKT reduction
@@ -543,11 +576,12 @@ def admm(xminf, zming, options):
         stopcond = "none"  # the reference's strcmp chain silently matches nothing
     record_history = bool(options.get("record_history", 1))
     nA, nB = prob.expect["nA"], prob.expect["nB"]
+    mC = prob.expect.get("m", nB)  # length of u and c; differs from nB only under a general B (admm.m:252-254)
 
     x0 = options.get("x0")
     z0 = options.get("z0")
     u0 = options.get("u0")
-    for name, v0, ln in (("x0", x0, nA), ("z0", z0, nB), ("u0", u0, nB)):
+    for name, v0, ln in (("x0", x0, nA), ("z0", z0, nB), ("u0", u0, mC)):
         if v0 is not None and np.asarray(v0).size != ln:
             raise ValueError(f"options.{name} has the wrong length")
 
@@ -570,7 +604,7 @@ def admm(xminf, zming, options):
     results = {}
     results["x0"] = np.zeros(nA) if x0 is None else np.array(x0, dtype=np.float64).reshape(-1)
     results["z0"] = np.zeros(nB) if z0 is None else np.array(z0, dtype=np.float64).reshape(-1)
-    results["u0"] = np.zeros(nB) if u0 is None else np.array(u0, dtype=np.float64).reshape(-1)
+    results["u0"] = np.zeros(mC) if u0 is None else np.array(u0, dtype=np.float64).reshape(-1)
     use_h = convtest or stopcond in ("hnorm", "both")
     if alg == L.FAST_WEAK:
         results["dvaltol"] = _setopt(options, "dvaltol", 1e-8)
@@ -580,10 +614,10 @@ def admm(xminf, zming, options):
     if record_history:
         results["xvals"] = eng.fetch(L.F_XVALS, nA * steps, (nA, steps))
         results["zvals"] = eng.fetch(L.F_ZVALS, nB * steps, (nB, steps))
-        results["uvals"] = eng.fetch(L.F_UVALS, nB * steps, (nB, steps))
+        results["uvals"] = eng.fetch(L.F_UVALS, mC * steps, (mC, steps))
         if alg != L.FAST_OFF:
             results["vvals"] = eng.fetch(L.F_VVALS, nB * steps, (nB, steps))
-            results["uhatvals"] = eng.fetch(L.F_UHATVALS, nB * steps, (nB, steps))
+            results["uhatvals"] = eng.fetch(L.F_UHATVALS, mC * steps, (mC, steps))
     if alg != L.FAST_WEAK:  # q8: accelerated mode records no norms/tolerances (admm.m:619-640)
         for key, fld in (("pnorm", L.F_PNORM), ("dnorm", L.F_DNORM), ("perr", L.F_PERR), ("derr", L.F_DERR)):
             results[key] = eng.fetch(fld, steps)
@@ -634,7 +668,7 @@ def admm(xminf, zming, options):
         results["zconsensus"] = eng.fetch(L.F_ZCONSENSUS, nA)
     results["xopt"] = eng.fetch(L.F_XOPT, nA)
     results["zopt"] = eng.fetch(L.F_ZOPT, nB)
-    results["uopt"] = eng.fetch(L.F_UOPT, nB)
+    results["uopt"] = eng.fetch(L.F_UOPT, mC)
     if objevals:
         results["objopt"] = float(summ.objopt)
     results["runtime"] = float(summ.runtime_s)

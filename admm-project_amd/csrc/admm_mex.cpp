@@ -78,8 +78,15 @@ struct Desc {
   admm_problem_desc d;
   std::vector<double> dense_L;    // args.L stored sparse (lasso.m:175) expanded column by column
   std::vector<int64_t> slices;    // args.slices (getProxOps.m:387) as integers
-  int64_t nA = 0, nB = 0;         // lengths of x and of z, u
+  int64_t nA = 0, nB = 0;         // lengths of x and of z
+  int64_t mC = 0;                 // length of u and c; 0 = the same as nB (every problem but a generic one with a general B)
   bool a_matrix = false;          // the constraint matrix A is the data matrix (LAD shape)
+  bool a_handle = false;          // generic: options.A / options.At are function handles (handles.A / handles.At)
+  int b_kind = 0;                 // generic: 0 = the shorthand -1, 1 = another scalar, 2 = matrix, 3 = function handle
+  double b_scalar = -1.0;
+  const double* b_matrix = nullptr;
+  int64_t b_ld = 0;
+  std::vector<double> zeros;      // c = 0 for the engines that take c as a data vector
 };
 
 // a lower-triangular factor handed in as args.L / args.R: dense as is, sparse (CSC) expanded
@@ -242,19 +249,34 @@ void describe(const std::string& p, const mxArray* args, const mxArray* handles,
     d.c = opt_vec(args, "c");
     ds.nA = ds.nB = d.n;
   } else if (p == "generic") {
-    // results = admm(xminf, zming, options) with both handles the caller's (admm.m:24): A = 1 runs as the model
-    // problem without data, a constraint matrix A as the LAD shape without a factor; B = -1 in either case
+    // results = admm(xminf, zming, options) with both handles the caller's (admm.m:24).  A = 1 runs as the model
+    // problem without data; a constraint matrix A, or function handles A / At (handles.A, handles.At; admm.m:113-195),
+    // as the LAD shape without a factor.  B: the shorthand -1, another scalar, an m x nB matrix (args.B) or a function
+    // handle (handles.B with args.nB) -- admm.m:198-245.
     const mxArray* A = field(args, "A");
-    if (is_dense_double(A) && mxGetNumberOfElements(A) > 1) {
+    const bool a_fh = is_handle(field(handles, "A"));
+    if (a_fh || (is_dense_double(A) && mxGetNumberOfElements(A) > 1)) {
       d.problem = ADMM_PROB_LAD;
       d.xsolve = ADMM_XSOLVE_CALLBACK;
-      d.D = mxGetPr(A);
-      d.m = static_cast<int64_t>(mxGetM(A));
-      d.n = static_cast<int64_t>(mxGetN(A));
-      d.ldD = d.m;
+      if (a_fh) {
+        if (!is_handle(field(handles, "At")))
+          mexErrMsgIdAndTxt("admm:arg", "options.A is a function handle: options.At must be one too (admm.m:139-158)");
+        d.D = nullptr;
+        d.m = static_cast<int64_t>(opt_scalar(args, "m", 0.0));
+        d.n = static_cast<int64_t>(opt_scalar(args, "nA", opt_scalar(args, "n", 0.0)));
+        if (d.m <= 0 || d.n <= 0)
+          mexErrMsgIdAndTxt("admm:arg", "Matrix A is a function handle, but no number of columns nA (or rows m) "
+                                        "specified for it");
+        ds.a_handle = true;
+      } else {
+        d.D = mxGetPr(A);
+        d.m = static_cast<int64_t>(mxGetM(A));
+        d.n = static_cast<int64_t>(mxGetN(A));
+        d.ldD = d.m;
+      }
       d.s = opt_vec(args, "c");
-      ds.dense_L.assign(static_cast<size_t>(d.m), 0.0);
-      if (!d.s) d.s = ds.dense_L.data();  // c = 0
+      ds.zeros.assign(static_cast<size_t>(d.m), 0.0);
+      if (!d.s) d.s = ds.zeros.data();  // c = 0
       ds.nA = d.n;
       ds.nB = d.m;
       ds.a_matrix = true;
@@ -266,6 +288,28 @@ void describe(const std::string& p, const mxArray* args, const mxArray* handles,
       d.c = opt_vec(args, "c");
       ds.nA = ds.nB = d.n;
     }
+    const mxArray* B = field(args, "B");
+    if (is_handle(field(handles, "B"))) {
+      ds.b_kind = 3;
+      ds.mC = ds.nB;
+      ds.nB = static_cast<int64_t>(opt_scalar(args, "nB", 0.0));
+      if (ds.nB <= 0)
+        mexErrMsgIdAndTxt("admm:arg", "Matrix B is a function handle, but no number of columns nB specified for it; "
+                                      "cannot infer nB - please specify it in options struct!");
+    } else if (is_dense_double(B) && mxGetNumberOfElements(B) > 1) {
+      if (static_cast<int64_t>(mxGetM(B)) != ds.nB)
+        mexErrMsgIdAndTxt("admm:arg", "Number of rows in matrix B do not match length of column vector c in "
+                                      "constraint Ax + Bz = c");
+      ds.b_kind = 2;
+      ds.b_matrix = mxGetPr(B);
+      ds.b_ld = static_cast<int64_t>(mxGetM(B));
+      ds.mC = ds.nB;
+      ds.nB = static_cast<int64_t>(mxGetN(B));
+    } else if (B && opt_scalar(args, "B", -1.0) != -1.0) {
+      ds.b_kind = 1;
+      ds.b_scalar = opt_scalar(args, "B", -1.0);
+      ds.mC = ds.nB;
+    }
   } else {
     mexErrMsgIdAndTxt("admm:problem", "Invalid input for problem - given string is not a solver!");
   }
@@ -275,7 +319,7 @@ void describe(const std::string& p, const mxArray* args, const mxArray* handles,
 // The engine hands device pointers; a MATLAB handle works on host mxArrays: stage down, feval, stage up.
 struct Thunk {
   mxArray* fh = nullptr;
-  size_t nfirst = 0, nB = 0;  // length of the first argument (x or the relaxed Ax-hat) and of z, u
+  size_t nfirst = 0, nB = 0, nU = 0;  // length of the first argument (x or the relaxed Ax-hat), of z and of u
   std::string failure;
 };
 
@@ -292,7 +336,7 @@ int prox_thunk(void* user, const double* x, const double* z, const double* u, do
                void* stream) {
   Thunk* t = static_cast<Thunk*>(user);
   mxArray* rhs[5] = {t->fh, staged_vector(x, t->nfirst, stream), staged_vector(z, t->nB, stream),
-                     staged_vector(u, t->nB, stream), mxCreateDoubleScalar(rho)};
+                     staged_vector(u, t->nU, stream), mxCreateDoubleScalar(rho)};
   mxArray* lhs[1] = {nullptr};
   int rc = (rhs[1] && rhs[2] && rhs[3]) ? mexCallMATLAB(1, lhs, 5, rhs, "feval") : 1;
   if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
@@ -302,6 +346,23 @@ int prox_thunk(void* user, const double* x, const double* z, const double* u, do
   if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), static_cast<size_t>(nout) * sizeof(double), stream);
   for (int k = 1; k < 5; ++k)
     if (rhs[k]) mxDestroyArray(rhs[k]);
+  if (lhs[0]) mxDestroyArray(lhs[0]);
+  return rc;
+}
+
+// options.A / At / B as MATLAB function handles of a single vector (admm.m:117-158, 206-216)
+int op_thunk(void* user, const double* in, int64_t nin, double* out, int64_t nout, void* stream) {
+  Thunk* t = static_cast<Thunk*>(user);
+  mxArray* rhs[2] = {t->fh, staged_vector(in, static_cast<size_t>(nin), stream)};
+  mxArray* lhs[1] = {nullptr};
+  int rc = rhs[1] ? mexCallMATLAB(1, lhs, 2, rhs, "feval") : 1;
+  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
+    t->failure = "a constraint-operator handle (A, At or B) returned something that is not a full real vector of the "
+                 "expected length";
+    rc = 1;
+  }
+  if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), static_cast<size_t>(nout) * sizeof(double), stream);
+  if (rhs[1]) mxDestroyArray(rhs[1]);
   if (lhs[0]) mxDestroyArray(lhs[0]);
   return rc;
 }
@@ -373,25 +434,45 @@ void read_options(const mxArray* op, admm_options& o) {
                                                                                    : ADMM_STOP_STANDARD;
 }
 
+// a scalar or matrix B is copied into the engine once, right after create (a function-handle B is set per run)
+void attach_constraint_b(admm_engine* e, const Desc& ds) {
+  if (ds.b_kind == 1 || ds.b_kind == 2)
+    check(admm_engine_set_constraint_b(e, ds.b_matrix, ds.b_ld, ds.b_kind == 2 ? ds.nB : 0, ADMM_MEM_HOST, ds.b_scalar,
+                                       nullptr, nullptr));
+}
+
 // the loop and the whole results struct of admm.m:257-767 (options / solverruntime are added by the callers)
 mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxArray* handles) {
   if (!mxIsStruct(op)) mexErrMsgIdAndTxt("admm:arg", "Given options is not a struct! At least pass empty struct!");
   admm_options o;
   read_options(op, o);
   const size_t nA = static_cast<size_t>(ds.nA), nB = static_cast<size_t>(ds.nB);
+  const size_t nU = ds.mC ? static_cast<size_t>(ds.mC) : nB;  // u, c, A*x (admm.m:252-254: zeros(m, 1))
   size_t k0 = 0;
   o.x0 = opt_vec(op, "x0", &k0);
   if (o.x0 && k0 != nA) mexErrMsgIdAndTxt("admm:arg", "options.x0 has the wrong length");
   o.z0 = opt_vec(op, "z0", &k0);
   if (o.z0 && k0 != nB) mexErrMsgIdAndTxt("admm:arg", "options.z0 has the wrong length");
   o.u0 = opt_vec(op, "u0", &k0);
-  if (o.u0 && k0 != nB) mexErrMsgIdAndTxt("admm:arg", "options.u0 has the wrong length");
+  if (o.u0 && k0 != nU) mexErrMsgIdAndTxt("admm:arg", "options.u0 has the wrong length");
   for (const char* name : {"altu", "specialnorms"})
     if (is_handle(field(op, name)))
       mexErrMsgIdAndTxt("admm:unsupported", "options.%s as a caller-supplied handle is not engine-native", name);
 
   // caller-supplied handles replace the engine-native operators (admm.m:502, 521-530, 603-605)
-  Thunk tx, tz, tobj;
+  Thunk tx, tz, tobj, ta, tat, tb;
+  if (ds.a_handle) {  // the thunks live as long as this run; a persistent engine gets fresh ones every run
+    ta.fh = const_cast<mxArray*>(field(handles, "A"));
+    tat.fh = const_cast<mxArray*>(field(handles, "At"));
+    if (!is_handle(ta.fh) || !is_handle(tat.fh))
+      mexErrMsgIdAndTxt("admm:arg", "this engine was created for function-handle operators: pass handles.A and handles.At");
+    check(admm_engine_set_operators(e, op_thunk, &ta, op_thunk, &tat));
+  }
+  if (ds.b_kind == 3) {
+    tb.fh = const_cast<mxArray*>(field(handles, "B"));
+    if (!is_handle(tb.fh)) mexErrMsgIdAndTxt("admm:arg", "this engine was created for a function-handle B: pass handles.B");
+    check(admm_engine_set_constraint_b(e, nullptr, 0, ds.nB, ADMM_MEM_HOST, 0.0, op_thunk, &tb));
+  }
   const mxArray* fx = field(handles, "xminf");
   const mxArray* fz = field(handles, "zming");
   const mxArray* fo = field(handles, "obj");
@@ -400,11 +481,13 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
     tx.fh = const_cast<mxArray*>(fx);
     tx.nfirst = nA;
     tx.nB = nB;
+    tx.nU = nU;
   }
   if (is_handle(fz)) {
     tz.fh = const_cast<mxArray*>(fz);
-    tz.nfirst = (ds.a_matrix && !relaxed) ? nA : nB;  // zming(x, ...) or zming(Axhat, ...) (admm.m:521-530)
+    tz.nfirst = relaxed ? nU : nA;  // zming(x, ...) or zming(Axhat, ...) (admm.m:521-530)
     tz.nB = nB;
+    tz.nU = nU;
   }
   const bool obj_native = opt_scalar(handles, "objnative", 0.0) != 0.0;
   if (o.objevals && !obj_native && is_handle(fo)) {
@@ -419,7 +502,7 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
   const int rc = admm_engine_run(e, &o, &s);
   if (tx.fh || tz.fh || tobj.fh) (void)admm_engine_set_callbacks(e, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   if (rc != ADMM_OK) {
-    for (const Thunk* t : {&tx, &tz, &tobj})
+    for (const Thunk* t : {&tx, &tz, &tobj, &ta, &tat, &tb})
       if (!t->failure.empty()) mexErrMsgIdAndTxt("admm:handle", "%s", t->failure.c_str());
     check(rc);
   }
@@ -429,23 +512,23 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
   mxArray* res = mxCreateStructMatrix(1, 1, 0, nullptr);
   put(res, "x0", start_vector(op, "x0", nA));  // admm.m:257-259
   put(res, "z0", start_vector(op, "z0", nB));
-  put(res, "u0", start_vector(op, "u0", nB));
+  put(res, "u0", start_vector(op, "u0", nU));
   if (o.fast == ADMM_FAST_WEAK) put(res, "dvaltol", mxCreateDoubleScalar(o.dvaltol));  // admm.m:292
   if (use_h) put(res, "Hnormtol", mxCreateDoubleScalar(o.Hnormtol));                    // admm.m:312
   mxArray *xv = nullptr, *zv = nullptr, *uv = nullptr;
   if (o.record_history) {
     xv = fetch_matrix(e, ADMM_F_XVALS, nA, k);
     zv = fetch_matrix(e, ADMM_F_ZVALS, nB, k);
-    uv = fetch_matrix(e, ADMM_F_UVALS, nB, k);
+    uv = fetch_matrix(e, ADMM_F_UVALS, nU, k);
     if (use_h && xv && zv && uv) {  // admm.m:678-681  w = [x; z; rho*u]
-      mxArray* w = mxCreateDoubleMatrix(nA + 2 * nB, k, mxREAL);
+      mxArray* w = mxCreateDoubleMatrix(nA + nB + nU, k, mxREAL);
       double* pw = mxGetPr(w);
       for (size_t i = 0; i < k; ++i) {
-        double* col = pw + i * (nA + 2 * nB);
+        double* col = pw + i * (nA + nB + nU);
         std::memcpy(col, mxGetPr(xv) + i * nA, nA * sizeof(double));
         std::memcpy(col + nA, mxGetPr(zv) + i * nB, nB * sizeof(double));
-        const double* ui = mxGetPr(uv) + i * nB;
-        for (size_t j = 0; j < nB; ++j) col[nA + nB + j] = o.rho * ui[j];
+        const double* ui = mxGetPr(uv) + i * nU;
+        for (size_t j = 0; j < nU; ++j) col[nA + nB + j] = o.rho * ui[j];
       }
       put(res, "wvals", w);
     }
@@ -454,7 +537,7 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
     put(res, "uvals", uv);
     if (o.fast != ADMM_FAST_OFF) {
       fetch_into(res, e, "vvals", ADMM_F_VVALS, nB, k);
-      fetch_into(res, e, "uhatvals", ADMM_F_UHATVALS, nB, k);
+      fetch_into(res, e, "uhatvals", ADMM_F_UHATVALS, nU, k);
     }
   }
   if (o.fast != ADMM_FAST_WEAK) {  // q8: accelerated ADMM records no norms (admm.m:619-640)
@@ -476,7 +559,7 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
     put(res, "steps", mxCreateDoubleScalar(s.steps));
     fetch_into(res, e, "xopt", ADMM_F_XOPT, nA, 1);
     fetch_into(res, e, "zopt", ADMM_F_ZOPT, nB, 1);
-    fetch_into(res, e, "uopt", ADMM_F_UOPT, nB, 1);
+    fetch_into(res, e, "uopt", ADMM_F_UOPT, nU, 1);
     if (ds.d.problem == ADMM_PROB_LASSO_CONSENSUS) fetch_into(res, e, "zconsensus", ADMM_F_ZCONSENSUS, nA, 1);  // q9
     if (o.objevals) put(res, "objopt", mxCreateDoubleScalar(s.objopt));
     put(res, "runtime", mxCreateDoubleScalar(s.runtime_s));
@@ -541,6 +624,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     admm_engine* e = nullptr;
     check(admm_engine_create(&ds.d, &e));
     g_live.push_back(e);  // destroyed by at_exit should a handle error out of MATLAB mid-run
+    attach_constraint_b(e, ds);
     static bool registered = false;
     if (!registered) {
       mexAtExit(at_exit_all);
@@ -557,7 +641,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     Desc* ds = new Desc();
     describe(to_string(prhs[1]), prhs[2], nrhs > 3 ? prhs[3] : nullptr, *ds);
     admm_engine* e = nullptr;
-    const int rc = admm_engine_create(&ds->d, &e);
+    int rc = admm_engine_create(&ds->d, &e);
+    if (rc == ADMM_OK && (ds->b_kind == 1 || ds->b_kind == 2)) {
+      rc = admm_engine_set_constraint_b(e, ds->b_matrix, ds->b_ld, ds->b_kind == 2 ? ds->nB : 0, ADMM_MEM_HOST,
+                                        ds->b_scalar, nullptr, nullptr);
+      if (rc != ADMM_OK) admm_engine_destroy(e);
+    }
     if (rc != ADMM_OK) {
       delete ds;
       check(rc);

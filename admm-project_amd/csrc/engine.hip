@@ -38,7 +38,7 @@ int upload_matrix(DevMem& mem, double** dst, int64_t* ld_out, const double* src,
 void free_hist(admm_engine* e) {
   for (void* p : e->hist_ptrs) (void)hipFree(p);
   e->hist_ptrs.clear();
-  e->xhist = e->zhist = e->uhist = e->vhist = e->uhathist = nullptr;
+  e->xhist = e->zhist = e->uhist = e->vhist = e->uhathist = e->zthist = e->vthist = nullptr;
   e->pnorm = e->dnorm = e->perr = e->derr = e->objv = e->hnorm = e->avals = e->dvals = e->restarted = nullptr;
   e->hist_cap = 0;
 }
@@ -1257,12 +1257,21 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
   bool need_vec_hist = false, need_fast = false;
   switch (field) {
     case ADMM_F_XOPT: src = e->x; count = e->nA; break;
-    case ADMM_F_ZOPT: src = e->z; count = e->len; break;
+    case ADMM_F_ZOPT: src = e->bgen ? e->zt : e->z; count = e->bgen ? e->nBz : e->len; break;
     case ADMM_F_UOPT: src = e->u; count = e->len; break;
     case ADMM_F_XVALS: src = e->xhist; count = e->nA * steps; need_vec_hist = true; break;
-    case ADMM_F_ZVALS: src = e->zhist; count = e->len * steps; need_vec_hist = true; break;
+    case ADMM_F_ZVALS:
+      src = e->bgen ? e->zthist : e->zhist;
+      count = (e->bgen ? e->nBz : e->len) * steps;
+      need_vec_hist = true;
+      break;
     case ADMM_F_UVALS: src = e->uhist; count = e->len * steps; need_vec_hist = true; break;
-    case ADMM_F_VVALS: src = e->vhist; count = e->len * steps; need_vec_hist = true; need_fast = true; break;
+    case ADMM_F_VVALS:
+      src = e->bgen ? e->vthist : e->vhist;
+      count = (e->bgen ? e->nBz : e->len) * steps;
+      need_vec_hist = true;
+      need_fast = true;
+      break;
     case ADMM_F_UHATVALS: src = e->uhathist; count = e->len * steps; need_vec_hist = true; need_fast = true; break;
     case ADMM_F_PNORM: src = e->pnorm; count = steps; break;
     case ADMM_F_DNORM: src = e->dnorm; count = steps; break;

@@ -158,6 +158,20 @@ struct admm_engine {
   admm_operator_callback acb = nullptr, atcb = nullptr;  // options.A / options.At as function handles (no D)
   void *auser = nullptr, *atuser = nullptr;
   double* axbuf = nullptr;  // A(x) when A is a callback
+  // options.B other than the shorthand -1 (admm.m:198-245; admm_engine_set_constraint_b): the caller's z lives in a
+  // space of its own (nBz elements: zt, its previous value, the zming result, the fast-ADMM v) while the loop's "z"
+  // buffers hold w = -B*z (len elements) -- B enters admm.m:515-700 linearly, so every fused kernel runs unchanged on w
+  bool bgen = false;
+  int64_t nBz = 0;
+  double bscalar = -1.0;
+  double* Bmat = nullptr;
+  int64_t ldB = 0;
+  GemvNPlan planBN{};
+  double* partBN = nullptr;
+  admm_operator_callback bcb = nullptr;
+  void* buser = nullptr;
+  double *zt = nullptr, *ztprev = nullptr, *ztnew = nullptr, *vt = nullptr, *btmp = nullptr;
+  double *zthist = nullptr, *vthist = nullptr;
   admm_prox_callback xcb = nullptr, zcb = nullptr;
   admm_obj_callback ocb = nullptr;
   void *xuser = nullptr, *zuser = nullptr, *ouser = nullptr;

@@ -112,7 +112,8 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
   *axt = nullptr;
   if (e->xcb) {  // x = xminf(x, z, u, rho), fast ADMM: xminf(x, v, uhat, rho)   (admm.m:502, 506)
     const bool fastalg = e->last_opts.fast != ADMM_FAST_OFF;
-    if (e->xcb(e->xuser, e->x, fastalg ? e->v : e->z, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
+    const double* zarg = e->bgen ? (fastalg ? e->vt : e->zt) : (fastalg ? e->v : e->z);
+    if (e->xcb(e->xuser, e->x, zarg, fastalg ? e->uhat : e->u, e->last_opts.rho, e->xext, e->nA,
                static_cast<void*>(e->stream)) != 0)
       return fail(ADMM_E_INVALID, "the xminf callback reported a failure");
     if (e->a_identity) {
@@ -218,6 +219,67 @@ int admm_engine_set_operators(admm_engine* e, admm_operator_callback A, void* Au
   return ADMM_OK;
 }
 
+int admm_engine_set_constraint_b(admm_engine* e, const double* B, int64_t ldB, int64_t nB, int32_t memkind,
+                                 double scalar, admm_operator_callback Bop, void* Buser) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  const bool generic = (e->problem == ADMM_PROB_MODEL && !e->has_xfac && !e->has_zfac) ||
+                       (e->problem == ADMM_PROB_LAD && e->xsolve == ADMM_XSOLVE_CALLBACK);
+  if (!generic)
+    return fail(ADMM_E_UNSUPPORTED, "a general B belongs to an engine whose two prox operators are both the caller's "
+                                    "(the library's operators are written for B = -1)");
+  if (e->comm && comm_nranks(e->comm) > 1) return fail(ADMM_E_UNSUPPORTED, "a general B is not supported on row-sharded engines");
+  if (e->bgen && Bop && e->bcb && nB == e->nBz) {  // a fresh thunk for the same operator (host bindings re-create them per run)
+    e->bcb = Bop;
+    e->buser = Buser;
+    return ADMM_OK;
+  }
+  if (e->bgen) return fail(ADMM_E_INVALID, "the constraint operator B of this engine is already set");
+  const int64_t len = e->len;
+  if (!Bop && !B) {  // a scalar: B = scalar*I, z has as many elements as the constraint
+    if (nB != 0 && nB != len) return fail(ADMM_E_INVALID, "a scalar B needs nB equal to the constraint length m");
+    nB = len;
+  } else if (nB <= 0) {
+    return fail(ADMM_E_INVALID, "nB (the length of z) must be positive");
+  }
+  if (B && !Bop && ldB < len) ldB = len;
+  ADMM_HIP_TRY(hipSetDevice(e->device));
+  const int64_t np = round_up(nB, 64) + 64;  // the streaming kernels read whole 16-byte pairs
+  for (double** p : {&e->zt, &e->ztprev, &e->ztnew, &e->vt}) {
+    ADMM_TRY(e->mem.alloc(p, np));
+    ADMM_HIP_TRY(hipMemsetAsync(*p, 0, sizeof(double) * np, e->stream));
+  }
+  ADMM_TRY(e->mem.alloc(&e->btmp, round_up(len, 2)));
+  if (Bop) {
+    e->bcb = Bop;
+    e->buser = Buser;
+  } else if (B) {
+    ADMM_TRY(upload_matrix(e->mem, &e->Bmat, &e->ldB, B, len, nB, ldB, memkind, e->stream));
+    e->planBN = gemv_n_plan(len, nB, e->ldB);
+    ADMM_TRY(e->mem.alloc(&e->partBN, e->planBN.part_elems()));
+  }
+  e->bscalar = scalar;
+  e->nBz = nB;
+  e->bgen = true;
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  return ADMM_OK;
+}
+
+// w[len] = -B*z[nBz]   (admm.m:536 Bz = B(z); the loop carries w so that B = -1 is the identity)
+static int apply_b(admm_engine* e, const double* zin, double* wout) {
+  if (e->bcb) {
+    if (e->bcb(e->buser, zin, e->nBz, e->btmp, e->len, static_cast<void*>(e->stream)) != 0)
+      return fail(ADMM_E_INVALID, "the B operator callback reported a failure");
+    launch_combine(e->btmp, 1, 0, -1.0, nullptr, 0.0, nullptr, wout, e->len, e->ctrl, e->stream);
+  } else if (e->Bmat) {
+    launch_gemv_n(e->planBN, e->Bmat, zin, e->partBN, e->ctrl, e->stream);
+    launch_combine(e->partBN, e->planBN.nchunk, e->planBN.ldy, -1.0, nullptr, 0.0, nullptr, wout, e->len, e->ctrl,
+                   e->stream);
+  } else {
+    launch_combine(zin, 1, 0, -e->bscalar, nullptr, 0.0, nullptr, wout, e->len, e->ctrl, e->stream);
+  }
+  return ADMM_OK;
+}
+
 int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* summary) {
   if (!e || !opts) return fail(ADMM_E_INVALID, "engine/options is NULL");
   if (opts->struct_size != static_cast<int32_t>(sizeof(admm_options)))
@@ -251,6 +313,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     if (!e->has_zfac && !e->zcb)
       return fail(ADMM_E_INVALID, "no z-update: the model was created without QtQ/Qts and no zming callback is set");
   }
+  if (e->bgen && !(e->xcb && e->zcb))
+    return fail(ADMM_E_INVALID, "an engine with a general B needs both the xminf and the zming callback");
   e->last_opts = o;
   const int alg = o.fast;  // 0, 1 (strong), 2 (weak)
   const bool use_h = o.convtest || o.stopcond == ADMM_STOP_HNORM || o.stopcond == ADMM_STOP_BOTH;
@@ -270,6 +334,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       ADMM_TRY(hist_alloc(e, &e->vhist, static_cast<size_t>(len) * N));
       ADMM_TRY(hist_alloc(e, &e->uhathist, static_cast<size_t>(len) * N));
     }
+    if (e->bgen) {  // results.zvals / vvals hold the caller's z (nB elements), not w = -B*z
+      ADMM_TRY(hist_alloc(e, &e->zthist, static_cast<size_t>(e->nBz) * N));
+      if (alg != 0) ADMM_TRY(hist_alloc(e, &e->vthist, static_cast<size_t>(e->nBz) * N));
+    }
   }
   double** scal[] = {&e->pnorm, &e->dnorm, &e->perr, &e->derr, &e->objv, &e->hnorm, &e->avals, &e->dvals,
                      &e->restarted};
@@ -285,7 +353,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     return ADMM_OK;
   };
   ADMM_TRY(init_vec(e->x, o.x0, nA));
-  ADMM_TRY(init_vec(e->z, o.z0, len));
+  if (e->bgen) ADMM_TRY(init_vec(e->zt, o.z0, e->nBz));
+  else ADMM_TRY(init_vec(e->z, o.z0, len));
   ADMM_TRY(init_vec(e->u, o.u0, len));
   ADMM_HIP_TRY(hipMemcpyAsync(e->v, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));     // admm.m:269
   ADMM_HIP_TRY(hipMemcpyAsync(e->uhat, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));  // admm.m:270
@@ -296,6 +365,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   c0.dprev = INFINITY;
   *e->ctrl_host = c0;
   ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl, e->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, e->stream));
+  if (e->bgen) {  // w0 = -B*z0; v starts as z (admm.m:269)
+    ADMM_TRY(apply_b(e, e->zt, e->z));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->v, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->vt, e->zt, sizeof(double) * e->nBz, hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipMemcpyAsync(e->ztprev, e->zt, sizeof(double) * e->nBz, hipMemcpyDeviceToDevice, e->stream));
+  }
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   for (auto& t : e->timers) {
     t.used = 0;
@@ -566,7 +641,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           // admm.m:521-530: zming is called with x itself, or with the relaxed Axhat when relax != 1; with A = 1
           // the two have the same length (xh), with A = D the un-relaxed call passes the n-vector x
           const double* zarg = (e->a_identity || o.relax != 1.0) ? e->xh : e->x;
-          if (e->zcb(e->zuser, zarg, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
+          if (e->bgen) {  // z = zming(., z, u, rho) in the caller's own space, then w = -B*z for the fused kernel
+            if (e->zcb(e->zuser, zarg, e->zt, za.uo, o.rho, e->ztnew, e->nBz, static_cast<void*>(e->stream)) != 0)
+              return fail(ADMM_E_INVALID, "the zming callback reported a failure");
+            ADMM_TRY(apply_b(e, e->ztnew, e->zext));
+            ZStateArgs zs{e->nBz, e->zt, e->ztprev, e->vt, e->ztnew, e->zthist, e->vthist, alg, 0};
+            launch_zstate(zs, e->ctrl, e->stream);
+          } else if (e->zcb(e->zuser, zarg, e->z, za.uo, o.rho, e->zext, len, static_cast<void*>(e->stream)) != 0)
             return fail(ADMM_E_INVALID, "the zming callback reported a failure");
         } else {  // zminModel: (QtQ + rho I) \ (Qts + rho*(x + u))   getProxOps.m:1012
           apply_slice_factor(e, e->zfac, e->rz, e->zext);
@@ -605,6 +686,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         }
         launch_fast_decide(fa, e->stream);
         launch_extrapolate(xa, e->ctrl, e->stream);
+        if (e->bgen) {
+          ZStateArgs zs{e->nBz, e->zt, e->ztprev, e->vt, nullptr, nullptr, e->vthist, alg, 1};
+          launch_zstate(zs, e->ctrl, e->stream);
+        }
       }
       if (!e->a_identity) {  // D'*[c+zx-ux, z-zprev, u]  (getProxOps.m:1514; admm.m:624, 654) in ONE pass
         transposed_products(nrhs_dual);
@@ -648,7 +733,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           fa.objp_reduced = e->red + 16;
         }
       } else if (o.objevals && e->ocb) {  // objevals(i) = obj(x, z) with the caller's handle (admm.m:604)
-        if (e->ocb(e->ouser, e->x, nA, e->z, len, e->objpart, static_cast<void*>(e->stream)) != 0)
+        if (e->ocb(e->ouser, e->x, nA, e->bgen ? e->zt : e->z, e->bgen ? e->nBz : len, e->objpart,
+                   static_cast<void*>(e->stream)) != 0)
           return fail(ADMM_E_INVALID, "the objective callback reported a failure");
         fa.objpart = e->objpart;
         fa.nobjpart = 1;

@@ -179,6 +179,18 @@ void launch_residual_sq(const double* part, int32_t nchunk, int64_t ld, const do
 // objpart[block] = sum_i x_i*(0.5*(sum_c part[c][i]) + q_i)   (1/2 x'Px + q'x, quadraticprogram.m:242)
 void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const double* x, const double* q,
                          int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
+// State of the caller's z when options.B is general (the loop's z buffers hold w = -B*z): after zming returned znew,
+// zprev <- z, z <- znew, zvals(:, i) = znew and -- fast ADMM -- v = z + coef*(z - zprev) (admm.m:568, 579) or the
+// restart value zprev (admm.m:586).  phase 0: state + history (+ v for alg 1, coefficient from ctrl->acurr as the fused
+// kernel takes it); phase 1: v of accelerated ADMM after launch_fast_decide published ctrl->coef / restart_flag.
+struct ZStateArgs {
+  int64_t len;
+  double *z, *zprev, *v;
+  const double* znew;
+  double *zhist, *vhist;
+  int32_t alg, phase;
+};
+void launch_zstate(const ZStateArgs& a, const Ctrl* ctrl, hipStream_t stream);
 // x = alpha*(sum_c part[c][i]) + beta*y[i] + add[i]  (add/y nullable)
 void launch_combine(const double* part, int32_t nchunk, int64_t ld, double alpha, const double* y, double beta,
                     const double* add, double* x, int64_t len, const Ctrl* ctrl, hipStream_t stream);

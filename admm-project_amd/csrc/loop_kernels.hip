@@ -329,6 +329,45 @@ void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t strea
   hipLaunchKernelGGL(extrapolate_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
 }
 
+__global__ __launch_bounds__(kBlock) void zstate_kernel(ZStateArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  double coef = 0.0;
+  bool rst = false;
+  if (a.phase == 1) {
+    coef = ctrl->coef;
+    rst = ctrl->restart_flag != 0.0;
+  } else if (a.alg == 1) {  // admm.m:504, 567-568, as prox_kernel takes it: finalize has not advanced acurr yet
+    const double aprev = ctrl->acurr;
+    coef = (aprev - 1.0) / (0.5 * (1.0 + sqrt(1.0 + 4.0 * aprev * aprev)));
+  }
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    double zn, zp;
+    if (a.phase == 0) {
+      zn = a.znew[i];
+      zp = a.z[i];
+      a.zprev[i] = zp;
+      a.z[i] = zn;
+      if (a.zhist) a.zhist[it * a.len + i] = zn;
+      if (a.alg != 1) continue;
+    } else {
+      zn = a.z[i];
+      zp = a.zprev[i];
+    }
+    const double vn = rst ? zp : zn + coef * (zn - zp);
+    a.v[i] = vn;
+    if (a.vhist) a.vhist[it * a.len + i] = vn;
+  }
+}
+
+void launch_zstate(const ZStateArgs& a, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zstate_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
 __global__ __launch_bounds__(kBlock) void initial_rhs_kernel(int64_t len, int kind, double rho,
                                                              const double* __restrict__ zx,
                                                              const double* __restrict__ ux,

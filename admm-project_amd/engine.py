@@ -141,6 +141,7 @@ class Engine:
         self.nB = self.m if problem in (L.PROB_LAD, L.PROB_HUBERFIT, L.PROB_LINEARSVM) else self.n
         if problem == L.PROB_TV2D:
             self.nA, self.nB = self.m * self.n, 2 * self.m * self.n
+        self.mC = self.nB  # length of u, c and A*x; equals nB unless a general B was set (set_constraint_b)
         self.device = int(d.device)
         self._cb_keep = None
         self._cb_error = None
@@ -193,7 +194,7 @@ class Engine:
         import torch  # device memory / stream plumbing only
 
         dev = torch.device("cuda", self.device)
-        nA, nB = self.nA, self.nB
+        nA = self.nA
 
         class _View:  # __cuda_array_interface__ carrier: torch.as_tensor makes a zero-copy tensor of it
             def __init__(self, ptr, count):
@@ -219,8 +220,8 @@ class Engine:
                 try:
                     with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
                         # xminf gets x; zming gets x, or the relaxed Axhat (nB elements) when relax != 1 (admm.m:521-530)
-                        first = nA if (what == "xminf" or self._relax == 1.0) else nB
-                        res = fn(view(x, first), view(z, nB), view(u, nB), float(rho))
+                        first = nA if (what == "xminf" or self._relax == 1.0) else self.mC
+                        res = fn(view(x, first), view(z, self.nB), view(u, self.mC), float(rho))
                         view(out, nout).copy_(as_result(res, nout, what))
                     return 0
                 except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
@@ -285,6 +286,48 @@ class Engine:
         keep = (wrap(A, "A"), wrap(At, "At"))
         L.check(self._lib.admm_engine_set_operators(self._h, keep[0], None, keep[1], None))
         self._op_keep = keep
+
+    def set_constraint_b(self, B, nB=0):
+        """options.B other than -1 (admm.m:198-245) for an engine whose two prox operators are the caller's: a scalar,
+        an m x nB matrix (NumPy, host) or a callable on DEVICE tensors ``B(z) -> m elements`` (then ``nB`` is
+        required).  Afterwards z has nB elements; u, c and A*x keep m."""
+        none = C.cast(None, L.OPERATOR_CALLBACK)
+        if callable(B):
+            import torch  # device memory / stream plumbing only
+
+            dev = torch.device("cuda", self.device)
+
+            class _View:
+                def __init__(self, ptr, count):
+                    self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8",
+                                                     "data": (int(ptr), False), "version": 2}
+
+            def cb(_user, vin, nin, out, nout, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        res = B(torch.as_tensor(_View(vin, nin), device=dev))
+                        if not (isinstance(res, torch.Tensor) and res.is_cuda):
+                            raise TypeError("options.B must return a CUDA tensor: host arrays would need a CPU path, "
+                                            "which this package does not have")
+                        if res.numel() != nout:
+                            raise ValueError(f"options.B returned {res.numel()} elements, expected {nout}")
+                        torch.as_tensor(_View(out, nout), device=dev).copy_(res.to(torch.float64).reshape(-1))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
+                    self._cb_error = exc
+                    return 1
+
+            self._b_keep = L.OPERATOR_CALLBACK(cb)
+            L.check(self._lib.admm_engine_set_constraint_b(self._h, None, 0, int(nB), L.MEM_HOST, 0.0, self._b_keep,
+                                                           None))
+            self.nB = int(nB)
+        elif np.isscalar(B):
+            L.check(self._lib.admm_engine_set_constraint_b(self._h, None, 0, 0, L.MEM_HOST, float(B), none, None))
+        else:
+            Bm = np.asfortranarray(np.asarray(B, dtype=np.float64))
+            L.check(self._lib.admm_engine_set_constraint_b(self._h, L.as_dp(Bm), Bm.shape[0], Bm.shape[1], L.MEM_HOST,
+                                                           0.0, none, None))
+            self.nB = int(Bm.shape[1])
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):

@@ -258,6 +258,15 @@ int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* x
  * A*x, At*(.) of the dual residual / tolerance (admm.m:535, 624, 654) are these callbacks, both required; B = -1. */
 int admm_engine_set_operators(admm_engine* eng, admm_operator_callback A, void* Auser, admm_operator_callback At,
                               void* Atuser);
+/* options.B other than the shorthand -1 (admm.m:198-245): a scalar (B = NULL, Bop = NULL: B = scalar*I), an m x nB
+ * matrix (column-major, leading dimension ldB, host or device pointer per memkind = ADMM_MEM_*), or a function handle
+ * Bop(z[nB]) -> out[m].  Only for engines whose two prox operators are BOTH the caller's (ADMM_PROB_MODEL created
+ * without Gram data, or ADMM_PROB_LAD with ADMM_XSOLVE_CALLBACK): the library's own operators are written for
+ * B = -1.  Afterwards z, v and zming's result have nB elements (callbacks, options.z0, ADMM_F_ZOPT / ZVALS / VVALS);
+ * u, c and the relaxed Axhat keep m.  B enters the loop linearly (admm.m:515, 536-552, 573, 621-658, 305), so the
+ * device loop carries w = -B*z and runs the same fused kernels. */
+int admm_engine_set_constraint_b(admm_engine* eng, const double* B, int64_t ldB, int64_t nB, int32_t memkind,
+                                 double scalar, admm_operator_callback Bop, void* Buser);
 int admm_engine_run(admm_engine* eng, const admm_options* opts, admm_run_summary* summary);
 int admm_engine_fetch(admm_engine* eng, int field, double* dst, size_t cap, size_t* written);
 /* what create() decided about the x-update factor (first slice for consensus lasso) */

@@ -55,7 +55,7 @@ elseif xd           % library x-update, caller's z-update (linearprogram.m:158-1
     handles.zming = slicewrap(zming, options, 'zming');
 else                % both operators are the caller's: the generic loop (admm.m:24)
     problem = 'generic';
-    args = genericargs(options);
+    [args, handles] = genericargs(options, handles);
     handles.xminf = slicewrap(xminf, options, 'xminf');
     handles.zming = slicewrap(zming, options, 'zming');
 end
@@ -93,43 +93,88 @@ end
 
 function checkconstraint(problem, options)
 % the library operators fix the constraint of their problem (lasso.m:232-238, lad.m:140-145,
-% totalvariation.m:151-157, unwrappedadmm.m:81-86); function-handle A / At / B are not engine-native
+% totalvariation.m:151-157, unwrappedadmm.m:81-86): function-handle A / At / B or a B other than -1 only go
+% with two caller-supplied handles (the generic loop)
 names = {'A', 'At', 'B'};
 for k = 1:numel(names)
     if isfield(options, names{k}) && isa(options.(names{k}), 'function_handle')
-        error('admm:unsupported', ['options.', names{k}, ' as a function handle is not engine-native (', problem, ').']);
+        error('admm:unsupported', ['options.', names{k}, ' as a function handle needs both proximal operators ', ...
+            'to be the caller''s (', problem, ').']);
     end
 end
 if isfield(options, 'B') && isnumeric(options.B) && ~(isscalar(options.B) && options.B == -1)
-    error('admm:unsupported', 'Only B = -1 is engine-native (every reference solver uses it).');
+    error('admm:unsupported', 'The library operators are written for B = -1 (every reference solver uses it).');
 end
 end
 
-function args = genericargs(options)
-% A = 1 (or absent): x - z = c.  A a matrix: A*x - z = c with the caller's handles (admm.m:117-120).
+function [args, handles] = genericargs(options, handles)
+% admm.m:79-245: c, A / At and B of the constraint A*x + B*z = c.  Matrices and scalars travel in args, function
+% handles in handles (the gateway calls them back with host vectors); the engine runs the loop on the device.
 args = struct();
-checkconstraint('generic', options);
-if isfield(options, 'A') && isnumeric(options.A) && numel(options.A) > 1
-    args.A = full(options.A);
-    nB = size(options.A, 1);
-else
-    if isfield(options, 'A') && ~(isscalar(options.A) && options.A == 1)
-        error('admm:unsupported', 'A scalar constraint operator other than A = 1 is not engine-native.');
+if ~isfield(options, 'A')
+    error('Must specify a matrix A in constraint Ax + Bz = c!');                 % admm.m:155-157
+end
+if ~isfield(options, 'B')
+    error('Must specify a matrix B in constraint Ax + Bz = c!');                 % admm.m:241-244
+end
+m = 0;
+if isfield(options, 'm'), m = options.m; end
+if isfield(options, 'c') && isnumeric(options.c) && numel(options.c) > 1
+    m = numel(options.c);
+end
+A = options.A;
+if isa(A, 'function_handle')                                                     % admm.m:121-130, 165-178
+    if ~isfield(options, 'nA') || options.nA == 0
+        error(['Matrix A is a function handle, but no number of columns nA specified for it; cannot infer nA - ', ...
+            'please specify it in options struct!']);
     end
-    if isfield(options, 'nA')
+    if ~isfield(options, 'At') || ~isa(options.At, 'function_handle')
+        error('admm:arg', 'options.A is a function handle: options.At must be one too.');
+    end
+    if m == 0, m = numel(A(zeros(options.nA, 1))); end
+    handles.A = A;
+    handles.At = options.At;
+    args.nA = options.nA;
+    args.m = m;
+elseif isnumeric(A) && numel(A) > 1
+    args.A = full(A);
+    m = size(A, 1);
+elseif isnumeric(A) && isscalar(A) && A ~= 1                                     % a*I as the pair v -> a*v
+    if m == 0 && isfield(options, 'nA'), m = options.nA; end
+    handles.A = @(v) A*v;
+    handles.At = handles.A;
+    args.nA = m;
+    args.m = m;
+else
+    if isfield(options, 'nA') && options.nA > 0
         args.n = options.nA;
-    elseif isfield(options, 'm')
-        args.n = options.m;
+    elseif m > 0
+        args.n = m;
     elseif isfield(options, 'x0')
         args.n = numel(options.x0);
     else
         error('admm:arg', 'The generic loop needs the vector length: set options.nA (or m, or x0).');
     end
-    nB = args.n;
+    m = args.n;
+end
+B = options.B;
+if isa(B, 'function_handle')                                                     % admm.m:206-216
+    if ~isfield(options, 'nB') || options.nB == 0
+        error(['Matrix B is a function handle, but no number of columns nB specified for it; cannot infer nB - ', ...
+            'please specify it in options struct!']);
+    end
+    handles.B = B;
+    args.nB = options.nB;
+elseif isnumeric(B) && numel(B) > 1
+    args.B = full(B);
+elseif isnumeric(B) && isscalar(B)
+    args.B = B;
+else
+    error(['Given B in constraint Ax + Bz = c is neither a numeric matrix nor function handle of single vector!']);
 end
 if isfield(options, 'c') && isnumeric(options.c)
     if isscalar(options.c)
-        args.c = options.c*ones(nB, 1);                                     % admm.m:79-110
+        args.c = options.c*ones(m, 1);                                          % admm.m:79-110
     else
         args.c = options.c(:);
     end

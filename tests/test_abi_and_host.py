@@ -83,7 +83,11 @@ def test_admm_handle_validation(ap):
     # caller-supplied handles need a device (they run on CUDA tensors): on a CPU box the engine fails loudly
     with pytest.raises(ap.AdmmError, match="no HIP device"):
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=-1, c=0, m=4, nA=4, nB=4))
-    with pytest.raises(NotImplementedError, match="B = -1"):
+    with pytest.raises(ValueError, match="no number of columns nB"):  # admm.m:206-212
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=lambda v: v, c=0, m=4, nA=4))
+    with pytest.raises(ValueError, match="neither a numeric matrix nor function handle"):  # admm.m:217-222
+        ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=[1.0, 2.0], c=0, m=4, nA=4))
+    with pytest.raises(ap.AdmmError, match="no HIP device"):  # a general B is engine-native: it needs the device too
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=1, B=np.eye(4), c=0, m=4, nA=4, nB=4))
     with pytest.raises(ValueError, match="options.At must be one too"):  # admm.m:139-158
         ap.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(A=lambda v: v, B=-1, c=0, m=4, nA=4, nB=4))

@@ -182,8 +182,6 @@ def test_host_handles_are_rejected(gpu):
     o = _constraint(16, maxiters=5)
     with pytest.raises(TypeError, match="CUDA tensor"):
         gpu.admm(lambda x, z, u, r: np.zeros(16), lambda x, z, u, r: np.zeros(16), o)
-    with pytest.raises(NotImplementedError, match="B = -1"):
-        gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, B=np.eye(16)))
     with pytest.raises(ValueError, match="options.At must be one too"):  # admm.m:139-158: A and At come together
         gpu.admm(lambda x, z, u, r: x, lambda x, z, u, r: z, dict(o, A=lambda v: v))
     p = gpu.synth.tv_problem(0, 64)
@@ -494,6 +492,74 @@ def test_generic_handles_with_function_handle_operators(gpu, opts):
     _compare(got, mat, tol=1e-9)
     with pytest.raises(ValueError, match="options.At must be one too"):
         gpu.admm(xt, zt, dict(o, A=A_t, At=Amat.T))
+
+
+@pytest.mark.parametrize("akind", ["one", "matrix", "scalar"])
+@pytest.mark.parametrize("bkind", ["matrix", "handle", "scalar"])
+@pytest.mark.parametrize("opts", [dict(objevals=1), dict(relax=1.4), dict(fast=1, fasttype="strong"),
+                                  dict(fast=1, fasttype="weak", objevals=1), dict(convtest=1, stopcond="both"),
+                                  dict(nodualerror=1, z0=1, u0=1)])
+def test_generic_handles_with_a_general_B(gpu, akind, bkind, opts):
+    """a2 (admm.m:198-245): options.B as an m x nB matrix, a function handle (with options.nB) or a scalar other than
+    -1.  z then lives in a space of its own; B(z), B(zprev), B(z - v), the H-norm and every history are compared with
+    the oracle running the same handles in NumPy.  f(x) = 1/2||x - p||^2, g(z) = gam/2||z||^2 + q'z."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    m, nA = (64, 40) if akind == "matrix" else (64, 64)
+    nB = m if bkind == "scalar" else 48
+    Amat = np.asfortranarray(rng.standard_normal((m, nA)) / 6) if akind == "matrix" else np.eye(m)
+    if akind == "scalar":
+        Amat = 0.75 * Amat
+    Bmat = -2.5 * np.eye(m) if bkind == "scalar" else np.asfortranarray(rng.standard_normal((m, nB)) / 5)
+    cvec, pvec, qvec = rng.standard_normal(m), rng.standard_normal(nA), rng.standard_normal(nB)
+    gam = 0.8
+    opts = dict(opts)
+    rho = 1.0
+    Fx = np.linalg.inv(np.eye(nA) + rho * Amat.T @ Amat)
+    Fz = np.linalg.inv(gam * np.eye(nB) + rho * Bmat.T @ Bmat)
+    T = {k: torch.tensor(v, device=dev) for k, v in dict(A=Amat, B=Bmat, c=cvec, p=pvec, q=qvec, Fx=Fx, Fz=Fz).items()}
+    relaxed = opts.get("relax", 1.0) != 1.0  # admm.m:515-519: zming then receives Axhat in place of x
+    xt = lambda _x, z, u, r_: T["Fx"] @ (T["p"] - r_ * (T["A"].T @ (T["B"] @ z - T["c"] + u)))
+    xn = lambda _x, z, u, r_: Fx @ (pvec - r_ * (Amat.T @ (Bmat @ z - cvec + u)))
+    zt = lambda x, _z, u, r_: T["Fz"] @ (-T["q"] - r_ * (T["B"].T @ ((x if relaxed else T["A"] @ x) - T["c"] + u)))
+    zn = lambda x, _z, u, r_: Fz @ (-qvec - r_ * (Bmat.T @ ((x if relaxed else Amat @ x) - cvec + u)))
+    # accelerated ADMM: stop before the restart value d is rounding noise (its decisions are then knife-edge)
+    o = dict(c=cvec, m=m, nA=nA, maxiters=14 if opts.get("fasttype") == "weak" else 50, **opts)
+    if o.pop("z0", None):
+        o["z0"], o["u0"] = rng.standard_normal(nB), rng.standard_normal(m)
+    Aopt, Atopt = {"one": (1, 1), "scalar": (0.75, 0.75), "matrix": (Amat, Amat.T)}[akind]
+    og, orf = dict(o, A=Aopt, At=Atopt), dict(o, A=Aopt, At=Atopt)
+    if bkind == "matrix":
+        og["B"] = orf["B"] = Bmat
+    elif bkind == "handle":
+        og["B"], orf["B"] = (lambda z: T["B"] @ z), (lambda z: Bmat @ z)
+        og["nB"] = orf["nB"] = nB
+    else:
+        og["B"] = orf["B"] = -2.5
+        og["nB"] = orf["nB"] = nB
+    if opts.get("objevals"):
+        og["obj"] = lambda x, z: 0.5 * torch.sum((x - T["p"]) ** 2) + 0.5 * gam * torch.sum(z * z) + torch.dot(T["q"], z)
+        orf["obj"] = lambda x, z: 0.5 * np.sum((x - pvec) ** 2) + 0.5 * gam * np.sum(z * z) + qvec @ z
+    got, ref = gpu.admm(xt, zt, og), A.admm(xn, zn, orf)
+    assert got["zopt"].shape == (nB,) and got["uopt"].shape == (m,)
+    _compare(got, ref, tol=1e-7)
+
+
+def test_general_B_validation(gpu):
+    import torch
+    f = lambda x, z, u, r: x
+    with pytest.raises(ValueError, match="no number of columns nB"):
+        gpu.admm(f, f, dict(A=1, At=1, B=lambda z: z, c=0, m=8, nA=8))
+    with pytest.raises(ValueError, match="rows in matrix B"):
+        gpu.admm(f, f, dict(A=1, At=1, B=np.ones((5, 3)), c=0, m=8, nA=8))
+    p = gpu.synth.lasso_problem(0, 64, 16)
+    minx, minz, _ = gpu.getproxops("lasso", dict(D=p["D"], s=p["s"], **{"lambda": 0.1}, rho=1.0))
+    with pytest.raises(ValueError, match="B = -1"):  # the library's operators are written for B = -1
+        gpu.admm(minx, minz, dict(A=1, At=1, B=np.eye(16), c=0, m=16, nA=16, nB=16))
+    with pytest.raises(NotImplementedError, match="general B"):
+        gpu.admm(f, f, dict(A=1, At=1, B=-2.0, c=0, m=8, nA=8, nB=8, adaptive=1, convtest=1))
+    assert torch.cuda.is_available()
 
 
 @pytest.mark.parametrize("qp,rho", [(False, 1.0), (False, 2.5), (True, 1.0), (True, 0.3)])

@@ -219,6 +219,53 @@ def test_mex_generic_admm_with_two_matlab_handles(gpu, mex):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bkind", ["matrix", "handle", "scalar"])
+@pytest.mark.parametrize("akind", ["one", "matrix", "handle"])
+def test_mex_generic_admm_with_general_operators(gpu, mex, akind, bkind):
+    """admm.m:113-245: options.A / At as a matrix or function handles, options.B as an m x nB matrix, a function handle
+    (with nB) or a scalar other than -1, both proximal operators MATLAB handles: every operator the caller can hand
+    to admm() goes through the gateway (matrices in args, handles in handles as matlab/admm.m packs them)"""
+    rng = np.random.default_rng(3)
+    m, nA = (40, 40) if akind == "one" else (40, 28)
+    nB = m if bkind == "scalar" else 31
+    Am = np.eye(m) if akind == "one" else rng.standard_normal((m, nA)) / 5
+    Bm = -1.7 * np.eye(m) if bkind == "scalar" else rng.standard_normal((m, nB)) / 4
+    c, pv, qv = rng.standard_normal(m), rng.standard_normal(nA), rng.standard_normal(nB)
+    gam = 0.6
+    Fx = np.linalg.inv(np.eye(nA) + Am.T @ Am)
+    Fz = np.linalg.inv(gam * np.eye(nB) + Bm.T @ Bm)
+    xmin = lambda x, z, u, rho: Fx @ (pv - rho * (Am.T @ (Bm @ z - c + u)))
+    zmin = lambda x, z, u, rho: Fz @ (-qv - rho * (Bm.T @ (Am @ x - c + u)))
+    args, handles = dict(c=c), dict(xminf=xmin, zming=zmin)
+    ref_opts = dict(c=c, m=m, nA=nA, nB=nB, maxiters=40, convtest=1, stopcond="both")
+    if akind == "one":
+        args["n"] = m
+        ref_opts.update(A=1, At=1)
+    elif akind == "matrix":
+        args["A"] = Am
+        ref_opts.update(A=Am, At=Am.T)
+    else:
+        args.update(nA=nA, m=m)
+        handles.update(A=lambda v: Am @ v, At=lambda v: Am.T @ v)
+        ref_opts.update(A=lambda v: Am @ v, At=lambda v: Am.T @ v)
+    if bkind == "matrix":
+        args["B"] = Bm
+        ref_opts["B"] = Bm
+    elif bkind == "handle":
+        args["nB"] = nB
+        handles["B"] = lambda v: Bm @ v
+        ref_opts["B"] = lambda v: Bm @ v
+    else:
+        args["B"] = -1.7
+        ref_opts["B"] = -1.7
+    options = dict(maxiters=40, convtest=1, stopcond="both")
+    got = mex.call("solve", "generic", args, options, handles)
+    ref = ref_admm(xmin, zmin, dict(ref_opts))
+    _same(got, ref, HIST + ("Hnormsq", "wvals"), tol=1e-8)
+    assert got["zopt"].shape[0] == nB and got["uopt"].shape[0] == m
+
+
+@pytest.mark.gpu
 def test_mex_persistent_engine_create_run_destroy(gpu, mex):
     """one engine, several runs (rho sweep with options.stalefactorok as xminLASSO behaves, getProxOps.m:1192-1206)"""
     p = gpu.synth.lasso_problem(5, 256, 64)
