@@ -98,8 +98,24 @@ static int ensure_sy_buffers(admm_engine* e, const SymvPlan& plan) {
   return ADMM_OK;
 }
 
-// f.Minv (tile-padded, zeros outside n x n) = X' X with X = inv(L): the explicit inverse of L L'
-static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
+// The padded column-major inverse of a factor -> tile-packed storage (symv.hip): half the memory, and the layout the
+// lower-triangle kernel streams fastest.  Small factors (symv_small_kernel reads whole columns) stay as they are.
+static int pack_inverse(admm_engine* e, SliceFactor& f) {
+  if (f.n < kSymvHalfMin || f.planSy.packed) return ADMM_OK;
+  double* P = nullptr;
+  ADMM_TRY(e->mem.alloc(&P, symv_packed_elems(f.planSy)));
+  launch_symv_pack(f.planSy, f.Minv, f.ldM, P, e->stream);
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  mem_free_one(e->mem, f.Minv);
+  f.Minv = P;
+  f.ldM = 0;
+  f.planSy.packed = true;
+  return ADMM_OK;
+}
+
+// f.Minv (tile-padded, zeros outside n x n) = X' X with X = inv(L): the explicit inverse of L L'; pack = false keeps
+// the padded column-major square (full symmetric storage) for callers that multiply with it as a dense matrix
+static int build_explicit_inverse(admm_engine* e, SliceFactor& f, bool pack = true) {
   const int64_t n = f.n, ld = f.ld;
   double* X = nullptr;
   ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&X), sizeof(double) * ld * n));
@@ -115,6 +131,7 @@ static int build_explicit_inverse(admm_engine* e, SliceFactor& f) {
   (void)hipStreamSynchronize(e->stream);
   (void)hipFree(X);
   ADMM_TRY(rc);
+  if (pack) ADMM_TRY(pack_inverse(e, f));
   if (n >= kSymvHalfMin) ADMM_TRY(ensure_sy_buffers(e, f.planSy));
   return ADMM_OK;
 }
@@ -322,7 +339,7 @@ static int spd_inverse(admm_engine* e, double* W, int64_t n, int64_t ld, double*
   if (info != 0)
     return fail(ADMM_E_NUMERIC, "Cholesky failed: matrix must be positive definite (pivot " + std::to_string(info) +
                                     "): the constraint matrix needs full row rank");
-  ADMM_TRY(build_explicit_inverse(e, f));
+  ADMM_TRY(build_explicit_inverse(e, f, false));
   mem_free_one(e->mem, f.dinv);
   *Minv = f.Minv;
   *ldM = f.ldM;
@@ -478,6 +495,7 @@ int factorize_pinv(admm_engine* e, double* W, int64_t n, int64_t ld) {
   mem_free_one(e->mem, V);
   mem_free_one(e->mem, lam);
   mem_free_one(e->mem, rotd);
+  ADMM_TRY(pack_inverse(e, f));
   if (n >= kSymvHalfMin) ADMM_TRY(ensure_sy_buffers(e, f.planSy));
   f.mode = ADMM_XSOLVE_INVERSE;
   f.pinv = true;
@@ -701,6 +719,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
           if (desc->obj_gram && e->s) {  // keep G = D'D (before the rho shift) in the symmetric kernel's tile-padded layout
             e->planG = symv_plan(n);
+            e->planG.ncached = symv_cached_tiles(e->planG, 0);  // the x-solve's inverse owns the Infinity-Cache share
             e->ldG = e->planG.npad;
             E_TRY(e->mem.alloc(&e->Gpad, static_cast<size_t>(e->ldG) * e->ldG));
             E_HIP(hipMemsetAsync(e->Gpad, 0, sizeof(double) * e->ldG * e->ldG, e->stream));
@@ -1168,6 +1187,9 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           E_HIP(hipMemsetAsync(e->csyT, 0, sizeof(double) * K * e->cpstride, e->stream));
         }
       }
+      // the K slice inverses are each read once per iteration: they share the Infinity-Cache budget of the split policy
+      for (ConsSlice& sl : e->cslices)
+        if (sl.fac.Minv) sl.fac.planSy.ncached = symv_cached_tiles(sl.fac.planSy, kSymvCacheBytes / (K > 0 ? K : 1));
       E_TRY(e->mem.alloc(&e->cY, K * e->cldn));
       E_TRY(e->mem.alloc(&e->cDts, K * e->cldn));
       E_HIP(hipMemsetAsync(e->cDts, 0, sizeof(double) * K * e->cldn, e->stream));

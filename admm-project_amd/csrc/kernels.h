@@ -44,10 +44,20 @@ struct SymvPlan {
   int64_t n, npad;
   int64_t ldp;     // row stride of the partial arrays (= npad)
   int32_t ntile;   // 128-row wave chunks = 128-column groups: npart and tpart are [ntile][ldp]
+  bool packed;     // M is tile-packed (launch_symv_pack): lower-triangle 128x128 tiles back to back, ld unused
+  int64_t ncached; // tiles (linear index < ncached) read with default loads; the rest stream non-temporally
   size_t npart_elems() const { return static_cast<size_t>(ntile) * ldp; }
   size_t tpart_elems() const { return static_cast<size_t>(ntile) * ldp; }
 };
 SymvPlan symv_plan(int64_t n);
+// Share of a re-read symmetric matrix that can stay in the 256 MB Infinity Cache next to the rest of an iteration's
+// traffic (measured plateau 105 .. 290 MB at n = 10000, dev/symv_packed.hip)
+constexpr int64_t kSymvCacheBytes = int64_t{168} << 20;
+int64_t symv_tiles(const SymvPlan& p);          // lower-triangle tiles
+size_t symv_packed_elems(const SymvPlan& p);    // doubles of the tile-packed storage
+int64_t symv_cached_tiles(const SymvPlan& p, int64_t budget_bytes);
+// P (symv_packed_elems doubles) <- the lower-triangle tiles of the padded column-major M (npad x npad, ld)
+void launch_symv_pack(const SymvPlan& p, const double* M, int64_t ld, double* P, hipStream_t stream);
 // y = M*x for a small symmetric M (full storage, ld even, 16-byte aligned; x 16-byte aligned): one wave per column
 void launch_symv_small(const double* M, int64_t n, int64_t ld, const double* x, double* y, const Ctrl* ctrl,
                        hipStream_t stream);

@@ -14,9 +14,19 @@
 // loads are issued before the reduction of the current one.
 // Partials (npart per 128-column group, tpart per 128-row wave chunk) are added by a second small
 // kernel in a fixed order: bitwise reproducible, no float atomics.
+// Storage (r2c): the explicit inverses are kept TILE-PACKED -- only the lower-triangle tiles, each 128x128 tile
+// contiguous (column-major inside, 128 KB), tiles in row-major triangle order (SymvPlan::packed) -- half the memory of
+// the padded square, one workgroup per stored tile (no empty workgroups above the diagonal) and every wave streaming
+// one contiguous 128 KB run.  Cache policy: the first SymvPlan::ncached tiles are read with default loads, the rest
+// non-temporally.  The matrix is re-read every iteration and only ~180 MB of it can stay in the 256 MB Infinity Cache:
+// with default loads everywhere the LRU evicts every line before its reuse (5.4 TB/s), with non-temporal loads
+// everywhere nothing is kept (5.9), with the split the cacheable part is served on-die from the second pass on:
+// n = 10000 (414 MB): 73.7 us column-major / all NT -> 62.6 us packed / 160 MB cacheable (dev/symv_packed.hip).
 // (r2: 8-column panels -- 16 loads in flight, a three-level reduce-scatter ending in row_half_mirror -- measured
 // slower than this 4-column form: 78.4 vs 76.5 us event-timed per pass.  A pure N-part pass over the same tiles,
 // tri_step_kernel in trsv.hip, streams at 6.0 TB/s, so the T-part's cross-lane work is what holds this kernel at 5.4.)
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace admm {
@@ -121,37 +131,84 @@ __device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, double& n0,
   }
 }
 
-// M: npad x npad (npad = round_up(n, 128)) with ld >= npad, zero outside n x n; x: n elements.
-template <bool NT>
+// tile t of the lower triangle in row-major order (0,0), (1,0), (1,1), (2,0), ... -> (bi, bj)
+__device__ __forceinline__ void tri_decode(unsigned t, unsigned& bi, unsigned& bj) {
+  unsigned r = static_cast<unsigned>((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while (r * (r + 1u) / 2u > t) --r;
+  while ((r + 1u) * (r + 2u) / 2u <= t) ++r;
+  bi = r;
+  bj = t - r * (r + 1u) / 2u;
+}
+
+// PACKED = false: M is npad x npad (npad = round_up(n, 128)) column-major with ld >= npad, zero outside n x n; grid
+// (ntile, ntile).  PACKED = true: M holds the lower-triangle tiles back to back (symv_pack_kernel); grid = their count.
+// x: n elements.  Tiles with linear index < ncached use default loads, the others non-temporal ones.
+template <bool PACKED>
 __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
                                                            const double* __restrict__ x, double* __restrict__ npart,
                                                            double* __restrict__ tpart, int64_t ldp,
-                                                           int32_t part_rank, int32_t part_count,
+                                                           int32_t part_rank, int32_t part_count, uint32_t ncached,
                                                            const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
-  if (blockIdx.x < blockIdx.y) return;  // tile strictly above the diagonal
+  unsigned bi, bj, lin;
+  if (PACKED) {
+    lin = blockIdx.x;
+    tri_decode(lin, bi, bj);
+  } else {
+    bi = blockIdx.x;
+    bj = blockIdx.y;
+    if (bi < bj) return;  // tile strictly above the diagonal
+    lin = bi * (bi + 1u) / 2u + bj;
+  }
   // multi-GPU: the lower-triangle tiles are dealt round-robin to the ranks; the slots of the tiles a rank
   // does not own stay at their initial zero and the partial results are summed by one all-reduce of n doubles
-  if (part_count > 1 &&
-      static_cast<int32_t>((blockIdx.x * (blockIdx.x + 1u) / 2u + blockIdx.y) % static_cast<unsigned>(part_count)) !=
-          part_rank)
-    return;
+  if (part_count > 1 && static_cast<int32_t>(lin % static_cast<unsigned>(part_count)) != part_rank) return;
   const int lane = threadIdx.x & 63;
-  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * kSyTile;  // wave's first row
-  const int64_t c0 = static_cast<int64_t>(blockIdx.y) * kSyTile;
+  const int64_t w0 = static_cast<int64_t>(bi) * kSyTile;  // wave's first row
+  const int64_t c0 = static_cast<int64_t>(bj) * kSyTile;
+  const int64_t gr = w0 + 2 * lane;  // this lane's row pair
   SyLane s;
-  s.M = M;
-  s.x = x;
-  s.ld = ld;
-  s.n = n;
-  s.r = static_cast<int>(w0) + 2 * lane;
-  s.xr0 = x[s.r < n ? s.r : n - 1];  // rows >= n multiply zero padding
-  s.xr1 = x[s.r + 1 < n ? s.r + 1 : n - 1];
-  double* __restrict__ tout = tpart + static_cast<int64_t>(blockIdx.x) * ldp;
+  int64_t cbase;  // first column as sy_tile counts it
+  double* __restrict__ tout = tpart + static_cast<int64_t>(bi) * ldp;
+  if (PACKED) {  // the tile is its own 128 x 128 matrix: local row / column numbers, x and tout shifted to its columns
+    s.M = M + static_cast<int64_t>(lin) * (kSyTile * kSyTile);
+    s.x = x + c0;
+    s.ld = kSyTile;
+    s.n = n - c0;
+    s.r = 2 * lane;
+    cbase = 0;
+    tout += c0;
+  } else {
+    s.M = M;
+    s.x = x;
+    s.ld = ld;
+    s.n = n;
+    s.r = static_cast<int>(gr);
+    cbase = c0;
+  }
+  s.xr0 = x[gr < n ? gr : n - 1];  // rows >= n multiply zero padding
+  s.xr1 = x[gr + 1 < n ? gr + 1 : n - 1];
   double n0 = 0.0, n1 = 0.0;
-  if (blockIdx.x == blockIdx.y) sy_tile<true, NT>(s, c0, n0, n1, tout, lane);
-  else sy_tile<false, NT>(s, c0, n0, n1, tout, lane);
-  *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(blockIdx.y) * ldp + s.r) = double2_t{n0, n1};
+  if (lin < ncached) {
+    if (bi == bj) sy_tile<true, false>(s, cbase, n0, n1, tout, lane);
+    else sy_tile<false, false>(s, cbase, n0, n1, tout, lane);
+  } else {
+    if (bi == bj) sy_tile<true, true>(s, cbase, n0, n1, tout, lane);
+    else sy_tile<false, true>(s, cbase, n0, n1, tout, lane);
+  }
+  *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(bj) * ldp + gr) = double2_t{n0, n1};
+}
+
+// column-major padded storage -> tile-packed storage (one workgroup per lower-triangle tile)
+__global__ __launch_bounds__(kBlock) void symv_pack_kernel(const double* __restrict__ M, int64_t ld,
+                                                           double* __restrict__ P) {
+  unsigned bi, bj;
+  tri_decode(blockIdx.x, bi, bj);
+  const double* src = M + static_cast<int64_t>(bj) * kSyTile * ld + static_cast<int64_t>(bi) * kSyTile;
+  double* dst = P + static_cast<int64_t>(blockIdx.x) * (kSyTile * kSyTile);
+  for (int e = 2 * threadIdx.x; e < kSyTile * kSyTile; e += 2 * kBlock)
+    *reinterpret_cast<double2_t*>(dst + e) =
+        *reinterpret_cast<const double2_t*>(src + static_cast<int64_t>(e / kSyTile) * ld + (e % kSyTile));
 }
 
 // y[i] = sum_{g <= d} npart[g][i] + sum_{w >= d} tpart[w][i],  d = i / 128 (i's diagonal tile).
@@ -222,18 +279,37 @@ SymvPlan symv_plan(int64_t n) {
   p.npad = round_up(n, kSyTile);
   p.ldp = p.npad;
   p.ntile = static_cast<int32_t>(p.npad / kSyTile);
+  p.packed = false;
+  int64_t budget = kSymvCacheBytes;
+  if (const char* env = getenv("ADMM_HIP_SYMV_CACHE_MB")) budget = static_cast<int64_t>(atoll(env)) << 20;  // tuning knob
+  p.ncached = symv_cached_tiles(p, budget);
   return p;
+}
+
+int64_t symv_tiles(const SymvPlan& p) { return static_cast<int64_t>(p.ntile) * (p.ntile + 1) / 2; }
+size_t symv_packed_elems(const SymvPlan& p) { return static_cast<size_t>(symv_tiles(p)) * kSyTile * kSyTile; }
+
+int64_t symv_cached_tiles(const SymvPlan& p, int64_t budget_bytes) {
+  const int64_t tiles = symv_tiles(p), tile_bytes = int64_t{8} * kSyTile * kSyTile;
+  if (!stream_hint(tiles * tile_bytes)) return tiles;  // small enough to stay cache-resident as a whole
+  const int64_t fit = budget_bytes / tile_bytes;
+  return fit < tiles ? fit : tiles;
+}
+
+void launch_symv_pack(const SymvPlan& p, const double* M, int64_t ld, double* P, hipStream_t stream) {
+  hipLaunchKernelGGL(symv_pack_kernel, dim3(static_cast<unsigned>(symv_tiles(p))), dim3(kBlock), 0, stream, M, ld, P);
 }
 
 void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const double* x, double* npart, double* tpart,
                        double* y, const Ctrl* ctrl, hipStream_t stream, int part_rank, int part_count, bool reduce) {
-  dim3 grid(static_cast<unsigned>(p.ntile), static_cast<unsigned>(p.ntile));
-  if (stream_hint(4 * p.npad * p.npad))
-    hipLaunchKernelGGL(symv_lower_kernel<true>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
-                       part_rank, part_count, ctrl);
+  const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
+  if (p.packed)
+    hipLaunchKernelGGL(symv_lower_kernel<true>, dim3(static_cast<unsigned>(symv_tiles(p))), dim3(kWave), 0, stream, M,
+                       p.n, ld, x, npart, tpart, p.ldp, part_rank, part_count, ncached, ctrl);
   else
-    hipLaunchKernelGGL(symv_lower_kernel<false>, grid, dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp,
-                       part_rank, part_count, ctrl);
+    hipLaunchKernelGGL(symv_lower_kernel<false>, dim3(static_cast<unsigned>(p.ntile), static_cast<unsigned>(p.ntile)),
+                       dim3(kWave), 0, stream, M, p.n, ld, x, npart, tpart, p.ldp, part_rank, part_count, ncached,
+                       ctrl);
   if (!reduce) return;  // the consumer sums the partial rows itself (prox_fin_kernel)
   const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
