@@ -86,7 +86,7 @@ class EngineInfo(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("xsolve_requested", C.c_int32), ("xsolve_used", C.c_int32),
         ("pinv_used", C.c_int32), ("probed", C.c_int32), ("trsv_blocks", C.c_int32), ("jacobi_sweeps", C.c_int32),
-        ("reserved", C.c_int32), ("factor_n", C.c_int64), ("rank", C.c_int64),
+        ("unwrapped_fused", C.c_int32), ("factor_n", C.c_int64), ("rank", C.c_int64),
         ("cond_estimate", C.c_double), ("probe_err_inverse", C.c_double), ("probe_err_trsv", C.c_double),
         ("probe_diff", C.c_double),
     ]

@@ -320,6 +320,60 @@ static int decide_sy_split(admm_engine* e) {
   return ADMM_OK;
 }
 
+// pinv(D) as an explicit n x m matrix for the two-launch unwrapped iteration (unwrapped.hip): the caller's args.Dplus as
+// it is, or inv(D'D)*D' from the factor create() has just built -- its explicit inverse when that is the form in use
+// (or the pseudo-inverse of a rank-deficient D'D), a temporary one for the small factors that default to triangular
+// solves.  Not built when the accuracy probe rejected the explicit inverse, when the caller asked for another x-solve
+// form, on sharded engines, or for sizes the kernel does not cover: the generic A = D iteration runs then.
+static int build_unwrapped_pinv(admm_engine* e, const double* Dp_given) {
+  const int64_t m = e->m, n = e->n;
+  if (std::getenv("ADMM_HIP_NO_UNWRAPPED_FUSED")) return ADMM_OK;
+  if (!uw_supported(m, n) || (e->comm && comm_nranks(e->comm) > 1)) return ADMM_OK;
+  if (static_cast<double>(m) * static_cast<double>(n) * 8.0 > 1.5e9) return ADMM_OK;
+  const int64_t ldp = round_up(n, 2);
+  if (Dp_given) {
+    ADMM_TRY(e->mem.alloc(&e->Dp, static_cast<size_t>(ldp) * m));
+    ADMM_HIP_TRY(hipMemcpy2DAsync(e->Dp, ldp * sizeof(double), Dp_given, n * sizeof(double), n * sizeof(double), m,
+                                  hipMemcpyDeviceToDevice, e->stream));
+  } else {
+    SliceFactor& f = e->xfac;
+    if (e->xsolve_requested == ADMM_XSOLVE_TRSV || e->xsolve_requested == ADMM_XSOLVE_CG) return ADMM_OK;
+    SliceFactor tmp{};
+    const double* Minv = nullptr;
+    int64_t ldM = 0;
+    if (f.mode == ADMM_XSOLVE_INVERSE && f.Minv && !f.planSy.packed) {
+      Minv = f.Minv;
+      ldM = f.ldM;
+    } else if (f.mode == ADMM_XSOLVE_TRSV && !f.probed && f.F) {
+      tmp.F = f.F;
+      tmp.n = f.n;
+      tmp.ld = f.ld;
+      tmp.dinv = f.dinv;
+      ADMM_TRY(build_explicit_inverse(e, tmp, false));
+      Minv = tmp.Minv;
+      ldM = tmp.ldM;
+    } else {
+      return ADMM_OK;
+    }
+    ADMM_TRY(e->mem.alloc(&e->Dp, static_cast<size_t>(ldp) * m));
+    ADMM_HIP_TRY(hipMemsetAsync(e->Dp, 0, sizeof(double) * ldp * m, e->stream));
+    launch_gemm(0, 1, n, m, n, 1.0, Minv, ldM, e->D, e->ldD, 0.0, e->Dp, ldp, false, e->stream);
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (tmp.Minv) mem_free_one(e->mem, tmp.Minv);
+  }
+  e->ldDp = ldp;
+  e->uwR = uw_rows_per_block(m);
+  e->uwnblk = static_cast<int32_t>(ceil_div(m, static_cast<int64_t>(e->uwR)));
+  e->uwldg = round_up(n, 2);
+  ADMM_TRY(e->mem.alloc(&e->uwG, static_cast<size_t>(2) * e->uwnblk * e->uwldg));
+  ADMM_HIP_TRY(hipMemsetAsync(e->uwG, 0, sizeof(double) * 2 * e->uwnblk * e->uwldg, e->stream));
+  e->uwnchunk = uw_chunks(n);
+  e->uwldax = round_up(m, 2);
+  ADMM_TRY(e->mem.alloc(&e->uwAx, static_cast<size_t>(e->uwnchunk) * e->uwldax));
+  ADMM_TRY(e->mem.alloc(&e->uwX, static_cast<size_t>(2) * e->uwldg));
+  return ADMM_OK;
+}
+
 // ---- one-time reductions some solvers do before the loop, on the device ---------------------------------------------
 // W (n x n, ld, lower triangle valid, SPD) -> its explicit inverse, full symmetric storage (tile-padded, ld *ldM).
 // W is destroyed; the result is owned by e->mem (release with mem_free_one).
@@ -824,6 +878,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         E_HIP(hipMemcpy2DAsync(e->DplusT, e->ldD * sizeof(double), Dpt, m * sizeof(double), m * sizeof(double), n,
                                hipMemcpyDeviceToDevice, e->stream));
         E_HIP(hipStreamSynchronize(e->stream));
+        E_TRY(build_unwrapped_pinv(e, Dp));
+        E_HIP(hipStreamSynchronize(e->stream));
         mem_free_one(e->mem, Dp);
         mem_free_one(e->mem, Dpt);
         e->xsolve = ADMM_XSOLVE_PINV;
@@ -869,6 +925,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         if (need_pinv) E_TRY(factorize_pinv(e, Wkeep, n, ld));
         else mem_free_one(e->mem, Wkeep);
       }
+      E_TRY(build_unwrapped_pinv(e, nullptr));
       break;
     }
     case ADMM_PROB_QP_BOUNDED: {
@@ -1383,6 +1440,7 @@ int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
   info->rank = f->pinv ? f->rank : (has ? f->n : 0);
   info->trsv_blocks = (has && f->mode == ADMM_XSOLVE_TRSV) ? f->trsv.nblk : 0;
   info->jacobi_sweeps = f->jacobi_sweeps;
+  info->unwrapped_fused = e->Dp ? 1 : 0;
   info->cond_estimate = has ? f->cond_diag : NAN;
   info->probe_err_inverse = f->probed ? f->err_inv : NAN;
   info->probe_err_trsv = f->probed ? f->err_trsv : NAN;

@@ -155,6 +155,12 @@ struct admm_engine {
   double* s2 = nullptr;
   GemvNPlan planD2N{};
   double* partD2N = nullptr;
+  // two-launch unwrapped iteration (unwrapped.hip): pinv(D) as an n x m matrix and the double-buffered partial rows
+  double* Dp = nullptr;
+  int64_t ldDp = 0;
+  double *uwG = nullptr, *uwAx = nullptr, *uwX = nullptr;  // partial rows of x, partial D*x, x double-buffered
+  int32_t uwR = 0, uwnblk = 0, uwnchunk = 0;
+  int64_t uwldg = 0, uwldax = 0;
   admm_operator_callback acb = nullptr, atcb = nullptr;  // options.A / options.At as function handles (no D)
   void *auser = nullptr, *atuser = nullptr;
   double* axbuf = nullptr;  // A(x) when A is a callback

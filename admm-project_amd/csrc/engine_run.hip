@@ -576,7 +576,34 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       launch_sum_partials_t(e->planDT, e->partDT, nrhs, e->g, e->ldg, e->ctrl, e->stream);
     }
   };
-  if (!e->a_identity) {
+  // The unwrapped iteration with an explicit pseudo-inverse (linear SVM, unwrappedadmm.m:76-92) runs as TWO launches per
+  // iteration (unwrapped.hip) when nothing outside the fused element update is asked for: plain ADMM, no recorded dual
+  // residual (unwrappedadmm.m:92 sets nodualerror), library operators, library objective, one rank.
+  const bool uw_fused = e->Dp && e->problem == ADMM_PROB_LINEARSVM && alg == 0 && o.relax == 1.0 && o.nodualerror &&
+                        !sharded && !e->xcb && !e->zcb && !e->ocb && std::getenv("ADMM_HIP_NO_UNWRAPPED_FUSED") == nullptr;
+  UwArgs ua{};
+  if (uw_fused) {
+    ua.D = e->D;
+    ua.ldD = e->ldD;
+    ua.Dp = e->Dp;
+    ua.ldP = e->ldDp;
+    ua.m = e->m;
+    ua.n = e->n;
+    ua.R = e->uwR;
+    ua.nblk = e->uwnblk;
+    ua.G = e->uwG;
+    ua.ldg = e->uwldg;
+    ua.axpart = e->uwAx;
+    ua.ldax = e->uwldax;
+    ua.nchunk = e->uwnchunk;
+    ua.xbuf = e->uwX;
+    ua.ldx = e->uwldg;
+    ua.iter = 0;
+    ua.fin_pending = 0;
+    ua.init = 1;  // partial rows of Dplus*(z0 - u0): what the first iteration sums into its x
+    launch_uw_prox(ua, pa, e->ctrl, e->stream);
+    ua.init = 0;
+  } else if (!e->a_identity) {
     transposed_products(1);
     ADMM_TRY(op_rc);
     if (sharded) ADMM_TRY(comm_allreduce_device(e->comm, e->g, static_cast<size_t>(e->ldg), e->stream));
@@ -590,7 +617,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // the CG x-solve (which polls the device between inner iterations), or with event timing on
   // (hipEventElapsedTime rejects events recorded by graph nodes: "invalid resource handle").
   const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
-  const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 &&
+  const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 && !uw_fused &&
                          e->xsolve != ADMM_XSOLVE_CG && heavy <= (int64_t{32} << 20) && !e->xcb && !e->zcb && !e->ocb;
   // A = I iterations whose finalize depends on nothing but the prox kernel's partial sums end in ONE launch
   // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
@@ -600,6 +627,19 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && !sharded && !obj_kernels &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   auto enqueue_iteration = [&]() -> int {
+    if (uw_fused) {
+      TimerScope ts(e, ADMM_K_PROX);
+      pa.axsrc = nullptr;
+      pa.ax_t = nullptr;
+      pa.x_out = nullptr;
+      FinArgs fprev = fa;  // the previous iteration's finalize rides along with this iteration's first launch
+      fprev.x = e->uwX + ((ua.iter + 1) & 1) * e->uwldg;
+      launch_uw_ax(ua, fprev, e->ctrl, e->stream);
+      launch_uw_prox(ua, pa, e->ctrl, e->stream);
+      ua.iter += 1;
+      ua.fin_pending = 1;
+      return ADMM_OK;
+    }
     {
       const double* axsrc;
       const double* axt;
@@ -794,6 +834,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
     }
     enq += batch;
+    if (uw_fused && ua.fin_pending && loop_rc == ADMM_OK) {  // the last enqueued iteration's finalize, on its own
+      FinArgs flast = uw_fin_args(ua, fa);
+      flast.x = e->uwX + ((ua.iter + 1) & 1) * e->uwldg;
+      launch_finalize(flast, e->stream);
+      ua.fin_pending = 0;
+    }
     // the host polls after EVERY batch, domaxiters runs included: an unbounded run of launches without a host
     // sync (6000 for a 1000-iteration SVM run) overruns a buffer inside rocprofv3's counter-collection mode
     // (SIGSEGV in the launch path of the profiler, r2 record in DESIGN section 6); one 64-byte read-back per 64
@@ -813,6 +859,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(ADMM_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+  }
+  if (uw_fused && e->ctrl_host->steps > 0)  // the x of the last completed iteration (double-buffered on its parity)
+  {
+    ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->uwX + ((e->ctrl_host->steps - 1) & 1) * e->uwldg, sizeof(double) * e->n,
+                                hipMemcpyDeviceToDevice, e->stream));
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   }
   const double runtime = std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count();
   if (e->profiling) collect_timers(e);

@@ -179,6 +179,33 @@ void launch_residual_sq(const double* part, int32_t nchunk, int64_t ld, const do
 // objpart[block] = sum_i x_i*(0.5*(sum_c part[c][i]) + q_i)   (1/2 x'Px + q'x, quadraticprogram.m:242)
 void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const double* x, const double* q,
                          int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
+// Two-launch iteration of unwrapped ADMM with an explicit pseudo-inverse (unwrapped.hip)
+struct UwArgs {
+  const double* D;   // m x n, column-major
+  int64_t ldD;
+  const double* Dp;  // n x m, column-major: pinv(D) (linearsvm.m:185)
+  int64_t ldP;
+  int64_t m, n;
+  int32_t R;         // rows per workgroup of uw_prox_kernel (multiple of 64)
+  int32_t nblk;      // its workgroups = partial rows of x
+  double* G;         // [2][nblk][ldg] partial rows of Dp*(c + z - u), double-buffered on the iteration parity
+  int64_t ldg;
+  double* axpart;    // [nchunk][ldax] partial D*x per 64-column chunk
+  int64_t ldax;
+  int32_t nchunk;    // <= 16
+  double* xbuf;      // [2][ldx] the x of the iteration (stored by uw_ax_kernel), double-buffered on its parity
+  int64_t ldx;
+  int64_t iter;      // 0-based iteration this launch belongs to (the host's count)
+  int32_t fin_pending;  // uw_ax_kernel: run the finalize logic of iteration iter - 1 in its extra workgroup
+  int32_t init;      // uw_prox_kernel: 1 = only the partial rows of Dp*(c + z0 - u0), before the first iteration
+};
+int uw_rows_per_block(int64_t m);
+int uw_chunks(int64_t n);
+bool uw_supported(int64_t m, int64_t n);
+FinArgs uw_fin_args(const UwArgs& a, const FinArgs& f);
+void launch_uw_ax(const UwArgs& a, const FinArgs& f, Ctrl* ctrl, hipStream_t stream);
+void launch_uw_prox(const UwArgs& a, const ProxArgs& pa, const Ctrl* ctrl, hipStream_t stream);
+
 // State of the caller's z when options.B is general (the loop's z buffers hold w = -B*z): after zming returned znew,
 // zprev <- z, z <- znew, zvals(:, i) = znew and -- fast ADMM -- v = z + coef*(z - zprev) (admm.m:568, 579) or the
 // restart value zprev (admm.m:586).  phase 0: state + history (+ v for alg 1, coefficient from ctrl->acurr as the fused

@@ -334,7 +334,7 @@ __device__ __forceinline__ void tv_block_scan(double* __restrict__ lds, int coun
 // (r2: issuing every global load of a tile -- z, u, s pairs and the wave-boundary neighbours -- before the first scan
 // costs 40 more VGPRs: 3 workgroups per CU instead of 4 and 0.2390 against 0.2331 ms per iteration on the same box,
 // 2 workgroups 0.3165.  Residency, not the number of dependent load rounds inside a workgroup, carries this kernel.)
-template <int E, bool NTS>
+template <int E, int MODE>  // MODE 0: default stores; 1: streaming stores; 2: + s kept cacheable; 3: + y kept cacheable; 4: both
 __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   __shared__ int32_t tail_group, tail_all;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
       const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
       double y0 = 0.0, y1 = 0.0;
       if (live1) {
-        const admm_double2 yy = load2<true>(a.yin + i0);
+        const admm_double2 yy = load2<!(MODE == 3 || MODE == 4)>(a.yin + i0);
         y0 = yy.x;
         y1 = yy.y;
       } else if (live0) {
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
         if (i0 + 2 < w1) x2 = L1[qb(i0 + 2)];
         double zp0, zp1 = 0.0;
         if (live1) {
-          const admm_double2 zz = load2<true>(a.z + i0), uu = load2<true>(a.u + i0), ss = load2<true>(a.s + i0);
+          const admm_double2 zz = load2<true>(a.z + i0), uu = load2<true>(a.u + i0),
+                             ss = load2<!(MODE == 2 || MODE == 4)>(a.s + i0);
           zp0 = zz.x;
           zp1 = zz.y;
           uo0 = uu.x;
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
           }
         }
         if (own0 && own1) {
+          constexpr bool NTS = MODE != 0;
           if (!a.skip_x) store2<NTS>(a.x + i0, admm_double2{x0, x1});
           store2<NTS>(a.zo + i0, admm_double2{zn0, zn1});
           store2<NTS>(a.uo + i0, admm_double2{un0, un1});
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
       const int64_t i0 = f0 + 2 * static_cast<int64_t>(j);
       const bool own0 = 2 * j < fcount && i0 >= o0, own1 = 2 * j + 1 < fcount && i0 + 1 >= o0;
       if (own0 && own1) {
-        store2<NTS>(a.yout + i0, admm_double2{L2[qf(i0)], L2[qf(i0 + 1)]});
+        store2<(MODE == 1 || MODE == 2)>(a.yout + i0, admm_double2{L2[qf(i0)], L2[qf(i0 + 1)]});
       } else {
         if (own0) a.yout[i0] = L2[qf(i0)];
         if (own1) a.yout[i0 + 1] = L2[qf(i0 + 1)];
@@ -697,8 +699,17 @@ void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const
     f.nblk = a.ngroups;
     f.slots_reduced = nullptr;
   }
-  if (nts) hipLaunchKernelGGL((tv_fused_kernel<8, true>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, f, ctrl);
-  else hipLaunchKernelGGL((tv_fused_kernel<8, false>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), lds, stream, a, f, ctrl);
+  int mode = nts ? 1 : 0;
+  if (nts)
+    if (const char* env = getenv("ADMM_HIP_TV_CACHE")) mode = atoi(env);
+  const dim3 grid(static_cast<unsigned>(ntiles)), block(kBlock);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((tv_fused_kernel<8, 0>), grid, block, lds, stream, a, f, ctrl); break;
+    case 2: hipLaunchKernelGGL((tv_fused_kernel<8, 2>), grid, block, lds, stream, a, f, ctrl); break;
+    case 3: hipLaunchKernelGGL((tv_fused_kernel<8, 3>), grid, block, lds, stream, a, f, ctrl); break;
+    case 4: hipLaunchKernelGGL((tv_fused_kernel<8, 4>), grid, block, lds, stream, a, f, ctrl); break;
+    default: hipLaunchKernelGGL((tv_fused_kernel<8, 1>), grid, block, lds, stream, a, f, ctrl); break;
+  }
   if (a.gcount) return;
   hipLaunchKernelGGL(tv_pack_kernel, dim3(S_COUNT), dim3(kBlock), 0, stream, a.part, a.part_stride,
                      static_cast<int32_t>(ntiles), slots16, ctrl);

@@ -357,7 +357,7 @@ class Engine:
                  L.XSOLVE_CALLBACK: "callback", L.XSOLVE_PINV: "pinv"}
         return dict(xsolve_requested=names.get(i.xsolve_requested, i.xsolve_requested),
                     xsolve_used=names.get(i.xsolve_used, i.xsolve_used), pinv_used=bool(i.pinv_used),
-                    probed=bool(i.probed), trsv_blocks=i.trsv_blocks, jacobi_sweeps=i.jacobi_sweeps,
+                    probed=bool(i.probed), unwrapped_fused=bool(i.unwrapped_fused), trsv_blocks=i.trsv_blocks, jacobi_sweeps=i.jacobi_sweeps,
                     factor_n=i.factor_n, rank=i.rank, cond_estimate=i.cond_estimate,
                     probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_diff=i.probe_diff)
 

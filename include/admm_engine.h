@@ -278,7 +278,7 @@ typedef struct admm_engine_info_t {
   int32_t probed;            /* 1: both forms were built and compared */
   int32_t trsv_blocks;       /* coarse blocks K of the blocked substitution (0 if not in use) */
   int32_t jacobi_sweeps;     /* sweeps of the eigen-solver (pinv) */
-  int32_t reserved;
+  int32_t unwrapped_fused;   /* 1: the two-launch unwrapped iteration with an explicit pinv(D) is available (linear SVM) */
   int64_t factor_n;          /* order of the factor (n; m for fat lasso) */
   int64_t rank;              /* numerical rank (== factor_n unless pinv_used) */
   double cond_estimate;      /* (max L_ii / min L_ii)^2, a lower bound of cond(L L'); pinv: lambda_max / lambda_min kept */

@@ -621,3 +621,37 @@ def test_consensus_lasso_partial_row_gather_path(gpu):
     ref = S.lasso(p["D"], p["s"], p["lam"], dict(o, slices=0), workers=3)
     _compare(got, ref, keys=("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "Hnormsq"))
     assert got["engine_info"]["xsolve_used"] == "inverse"
+
+
+@pytest.mark.parametrize("m,n,kind", [(257, 3, "hinge"), (1000, 130, "hinge"), (1000, 130, "01"), (6000, 400, "hinge"),
+                                      (900, 513, "hinge"), (1500, 400, "deficient"), (640, 96, "dplus")])
+def test_unwrapped_two_launch_iteration_matches_the_generic_path(gpu, monkeypatch, m, n, kind):
+    """unwrapped.hip: the linear SVM iteration as two launches (explicit pinv(D), partial rows carried across the kernel
+    boundaries, the finalize logic riding along with the next launch) against the generic five-launch A = D iteration
+    of the same engine, and against the oracle: early stop, histories, objective, both losses, a rank-deficient D
+    (pseudo-inverse from the eigen-solver) and a caller-supplied Dplus."""
+    if kind == "deficient":
+        p = gpu.synth.rank_deficient_pixels(seed=3, m=m, n=n)
+    else:
+        p = gpu.synth.mnist_like_problem(seed=2, m=m, n=n, digit=1)
+    D, ell, Cv = p["D"], p["ell"], p["C"]
+    o = dict(objevals=1, maxiters=120, x0=p["x0"], z0=p["z0"], u0=p["u0"])
+    if kind == "01":
+        o["lossfunction"] = "01"
+        o["maxiters"] = 12  # the 0-1 prox is discontinuous (q24): the first iterations only
+    if kind == "dplus":
+        o["Dplus"] = np.linalg.pinv(D)
+    got = gpu.linearsvm(D, ell, Cv, dict(o))
+    assert got["engine_info"]["unwrapped_fused"]
+    monkeypatch.setenv("ADMM_HIP_NO_UNWRAPPED_FUSED", "1")
+    gen = gpu.linearsvm(D, ell, Cv, dict(o))
+    monkeypatch.delenv("ADMM_HIP_NO_UNWRAPPED_FUSED")
+    assert not gen["engine_info"]["unwrapped_fused"]
+    assert got["steps"] == gen["steps"]
+    tol = 1e-7 if kind == "deficient" else 1e-9
+    for k in ("xvals", "zvals", "uvals", "pnorm", "perr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, got[k], gen[k], tol)
+    assert np.isnan(got["dnorm"]).all()
+    if kind in ("hinge", "dplus"):
+        ref = S.linearsvm(D, ell, Cv, dict(o))
+        _compare(got, ref, tol=1e-7)
