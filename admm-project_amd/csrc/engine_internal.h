@@ -155,6 +155,9 @@ struct admm_engine {
   double* s2 = nullptr;
   GemvNPlan planD2N{};
   double* partD2N = nullptr;
+  // deferred finalize (engine_run.hip): the previous iteration's finalize arguments ride along with the packed x-solve
+  const FinArgs* dfin = nullptr;
+  bool dfin_pending = false;
   // two-launch unwrapped iteration (unwrapped.hip): pinv(D) as an n x m matrix and the double-buffered partial rows
   double* Dp = nullptr;
   int64_t ldDp = 0;

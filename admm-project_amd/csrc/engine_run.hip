@@ -169,7 +169,10 @@ static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpar
                            bool leave_partials) {
   if (leave_partials && xsolve_has_partials(e)) {  // x = sum of these rows, taken by prox_fin_kernel
     const SliceFactor& f = e->xfac;
-    launch_symv_lower(f.planSy, f.Minv, f.ldM, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream, 0, 1, false);
+    if (e->dfin && f.planSy.packed)
+      launch_symv_lower_fin(f.planSy, f.Minv, e->rhs, e->syN, e->syT, *e->dfin, e->dfin_pending, e->ctrl, e->stream);
+    else
+      launch_symv_lower(f.planSy, f.Minv, f.ldM, e->rhs, e->syN, e->syT, e->x, e->ctrl, e->stream, 0, 1, false);
     *axsrc = e->syN;
     *axt = e->syT;
     *naxpart = f.planSy.ntile;
@@ -626,6 +629,15 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // without it the finalize logic needs none of the D' products that follow the prox kernel
   const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && !sharded && !obj_kernels &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
+  // With the packed lower-triangle x-solve in front of it, the finalize logic of an A = I iteration is deferred: the
+  // element update stores its block partials and ends; the next iteration's x-solve carries the finalize in one extra
+  // workgroup (symv_lower_fin_kernel), where its ~6 us of serial work overlap with 60 us of streaming, and the element
+  // update after that starts with the decision in ctrl.  A batch's last iteration gets a stand-alone finalize.
+  const bool defer_fin = fuse_tail && e->a_identity && xsolve_has_partials(e) && e->xfac.planSy.packed && !use_graph &&
+                         std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  FinArgs dff{};
+  e->dfin = nullptr;
+  e->dfin_pending = false;
   auto enqueue_iteration = [&]() -> int {
     if (uw_fused) {
       TimerScope ts(e, ADMM_K_PROX);
@@ -704,6 +716,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         pa.naxpart = naxpart;
         pa.axld = axld;
         pa.x_out = e->a_identity ? e->x : nullptr;
+        if (defer_fin) {  // the element update alone; the finalize rides along with the next x-solve
+          launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream, true);
+          dff = prox_fin_args(pa, fa);
+          e->dfin = &dff;
+          e->dfin_pending = true;
+          return ADMM_OK;
+        }
         if (fuse_tail) {  // z/u update + finalize in one launch
           launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream);
           if (e->a_identity) return ADMM_OK;  // the iteration ends here
@@ -834,6 +853,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       for (int32_t b = 0; b < batch && loop_rc == ADMM_OK; ++b) loop_rc = enqueue_iteration();
     }
     enq += batch;
+    if (defer_fin && e->dfin_pending && loop_rc == ADMM_OK) {  // the batch's last iteration
+      launch_finalize(dff, e->stream);
+      e->dfin_pending = false;
+    }
     if (uw_fused && ua.fin_pending && loop_rc == ADMM_OK) {  // the last enqueued iteration's finalize, on its own
       FinArgs flast = uw_fin_args(ua, fa);
       flast.x = e->uwX + ((ua.iter + 1) & 1) * e->uwldg;
@@ -851,6 +874,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       else if (e->ctrl_host->stop) stopped = true;
     }
   }
+  e->dfin = nullptr;
+  e->dfin_pending = false;
   if (gexec) (void)hipGraphExecDestroy(gexec);
   if (graph) (void)hipGraphDestroy(graph);
   ADMM_TRY(loop_rc);

@@ -7,9 +7,12 @@
 
 namespace admm {
 
-// sum over the kBlock threads that run finalize_body (four waves, whatever the launch's block size); result in thread 0
+// sum over the NT threads that run finalize_body (four waves, or one: whatever the launch's block size); result in
+// thread 0
+template <int NT>
 __device__ __forceinline__ double fin_block_sum(double v, double* scratch) {
   v = wave_sum(v);
+  if (NT == 64) return v;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) scratch[wid] = v;
@@ -17,8 +20,9 @@ __device__ __forceinline__ double fin_block_sum(double v, double* scratch) {
   return threadIdx.x == 0 ? ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3] : 0.0;
 }
 
-// Exactly kBlock threads (the first four waves of the calling workgroup) take part.
-template <bool COHERENT>
+// Exactly NT threads take part: kBlock (the first four waves of the calling workgroup), or 64 -- the one-wave
+// workgroup that rides along with the lower-triangle x-solve (symv.hip).
+template <bool COHERENT, int NT = kBlock>
 __device__ __forceinline__ void finalize_body(const FinArgs& a) {
   Ctrl* ctrl = a.ctrl;
   __shared__ double scratch[4];
@@ -31,7 +35,8 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     // all slots at once: 16 lanes per slot stride over the block partials, then a 16-lane
     // shuffle tree (fixed order -> reproducible); one round of global loads instead of S_COUNT.
     static_assert(S_COUNT <= 16, "slot layout");
-    const int slot = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int sub = threadIdx.x & 15;
+    for (int slot = threadIdx.x >> 4; slot < 16; slot += NT / 16) {
     double v = 0.0;
     if (slot < S_COUNT) {
       const double* __restrict__ ps = a.part + slot * kMaxPartBlocks;
@@ -51,6 +56,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (sub == 0) S[slot] = v;
+    }
     __syncthreads();
   }
   double ng2 = 0.0, ng3 = 0.0, nx2 = 0.0, objp = 0.0;
@@ -59,29 +65,29 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     ng3 = S[S_G3];
   } else if (a.g && !a.nodualerror) {
     double s2 = 0.0, s3 = 0.0;
-    for (int64_t j = threadIdx.x; j < a.nA; j += kBlock) {
+    for (int64_t j = threadIdx.x; j < a.nA; j += NT) {
       const double g2 = a.g[a.ldg + j], g3 = a.g[2 * a.ldg + j];
       s2 += g2 * g2;
       s3 += g3 * g3;
     }
-    ng2 = fin_block_sum(s2, scratch);
-    ng3 = fin_block_sum(s3, scratch);
+    ng2 = fin_block_sum<NT>(s2, scratch);
+    ng3 = fin_block_sum<NT>(s3, scratch);
   }
   if (a.x) {
     double s = 0.0;
-    for (int64_t j = threadIdx.x; j < a.nA; j += kBlock) {
+    for (int64_t j = threadIdx.x; j < a.nA; j += NT) {
       const double xv = a.x[j];
       s += xv * xv;
       if (a.xhist) a.xhist[static_cast<int64_t>(it) * a.nA + j] = xv;
     }
-    nx2 = fin_block_sum(s, scratch);
+    nx2 = fin_block_sum<NT>(s, scratch);
   }
   if (a.objp_reduced) {
     objp = a.objp_reduced[0];
   } else if (a.objpart) {
     double s = 0.0;
-    for (int b = threadIdx.x; b < a.nobjpart; b += kBlock) s += a.objpart[b];
-    objp = fin_block_sum(s, scratch);
+    for (int b = threadIdx.x; b < a.nobjpart; b += NT) s += a.objpart[b];
+    objp = fin_block_sum<NT>(s, scratch);
   }
   if (threadIdx.x != 0) return;
   const double Mlen = static_cast<double>(a.len_global > 0 ? a.len_global : a.len);

@@ -162,7 +162,10 @@ void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 // A = I, alg 0 / 1: z/u update AND the finalize logic in one launch (the last workgroup to arrive finalizes);
 // a.len <= 128 * kMaxPartBlocks
-void launch_prox_fin(const ProxArgs& a, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+void launch_prox_fin(const ProxArgs& a, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream,
+                     bool defer = false);
+// the finalize arguments launch_prox_fin hands to the last workgroup (or, deferred, to the next launch)
+FinArgs prox_fin_args(const ProxArgs& a, const FinArgs& f);
 void launch_fast_decide(const FinArgs& a, hipStream_t stream);   // alg 2: d, restart decision, alpha
 void launch_extrapolate(const ExtrapArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_finalize(const FinArgs& a, hipStream_t stream);
@@ -179,6 +182,11 @@ void launch_residual_sq(const double* part, int32_t nchunk, int64_t ld, const do
 // objpart[block] = sum_i x_i*(0.5*(sum_c part[c][i]) + q_i)   (1/2 x'Px + q'x, quadraticprogram.m:242)
 void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const double* x, const double* q,
                          int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
+// The packed lower-triangle x-solve (symv.hip) carrying the finalize logic of the previous iteration in workgroup 0;
+// the partial rows stay unsummed (prox_fin_kernel takes them)
+void launch_symv_lower_fin(const struct SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
+                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
+
 // Two-launch iteration of unwrapped ADMM with an explicit pseudo-inverse (unwrapped.hip)
 struct UwArgs {
   const double* D;   // m x n, column-major

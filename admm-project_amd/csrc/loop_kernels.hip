@@ -277,7 +277,10 @@ __device__ __forceinline__ double tail_gather(const ProxArgs& a, int64_t i, int3
   return s;
 }
 
-__global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArgs f, Ctrl* __restrict__ ctrl) {
+// defer = 1: the finalize logic is NOT run here; the block partials are stored plainly and the next launch on the
+// stream (the x-solve of the next iteration, or a stand-alone finalize) takes them after the kernel boundary.
+__global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArgs f, Ctrl* __restrict__ ctrl,
+                                                              int32_t defer) {
   const int32_t stop = ctrl->stop;
   const int64_t it = ctrl->iter;
   const double aprev = ctrl->acurr;
@@ -320,6 +323,10 @@ __global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArg
     }
   }
   __syncthreads();
+  if (defer) {
+    if (threadIdx.x < S_COUNT) a.part[threadIdx.x * kMaxPartBlocks + blockIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x];
+    return;
+  }
   if (threadIdx.x < S_COUNT) {
     const int s = threadIdx.x;
     __hip_atomic_store(a.part + s * kMaxPartBlocks + blockIdx.x, sred[0][s] + sred[1][s], __ATOMIC_RELAXED,
@@ -338,7 +345,19 @@ __global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArg
   finalize_body<true>(f);
 }
 
-void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+FinArgs prox_fin_args(const ProxArgs& a, const FinArgs& f) {
+  FinArgs ff = f;
+  ff.nblk = static_cast<int32_t>(ceil_div(a.len, kTailTile));
+  ff.g = nullptr;  // nothing but the block partials (and, for A = D, the x of this iteration) feeds the finalize logic
+  ff.objpart = nullptr;
+  ff.nobjpart = 0;
+  ff.slots_reduced = nullptr;
+  ff.objp_reduced = nullptr;
+  return ff;
+}
+
+void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nblk_out, hipStream_t stream,
+                     bool defer) {
   ProxArgs a = args;
   const bool need_ell = a.prox == PROX_HINGE || a.prox == PROX_01 || a.objx == OBJX_HINGE ||
                         a.objx == OBJX_ZEROONE || a.objx == OBJX_DOT;
@@ -349,14 +368,9 @@ void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nb
   if (!need_add) a.rhs_add = nullptr;
   const int64_t blocks = ceil_div(a.len, kTailTile);
   *nblk_out = static_cast<int>(blocks);
-  FinArgs ff = f;
-  ff.nblk = static_cast<int32_t>(blocks);
-  ff.g = nullptr;  // nothing but the block partials (and, for A = D, the x of this iteration) feeds the finalize logic
-  ff.objpart = nullptr;
-  ff.nobjpart = 0;
-  ff.slots_reduced = nullptr;
-  ff.objp_reduced = nullptr;
-  hipLaunchKernelGGL(prox_fin_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTailBlock), 0, stream, a, ff, ctrl);
+  const FinArgs ff = prox_fin_args(a, f);
+  hipLaunchKernelGGL(prox_fin_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTailBlock), 0, stream, a, ff, ctrl,
+                     defer ? 1 : 0);
 }
 
 void launch_finalize(const FinArgs& a, hipStream_t stream) {

@@ -27,6 +27,7 @@
 // tri_step_kernel in trsv.hip, streams at 6.0 TB/s, so the T-part's cross-lane work is what holds this kernel at 5.4.)
 #include <cstdlib>
 
+#include "finalize_device.h"
 #include "kernels.h"
 
 namespace admm {
@@ -144,19 +145,17 @@ __device__ __forceinline__ void tri_decode(unsigned t, unsigned& bi, unsigned& b
 // (ntile, ntile).  PACKED = true: M holds the lower-triangle tiles back to back (symv_pack_kernel); grid = their count.
 // x: n elements.  Tiles with linear index < ncached use default loads, the others non-temporal ones.
 template <bool PACKED>
-__global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
-                                                           const double* __restrict__ x, double* __restrict__ npart,
-                                                           double* __restrict__ tpart, int64_t ldp,
-                                                           int32_t part_rank, int32_t part_count, uint32_t ncached,
-                                                           const Ctrl* __restrict__ ctrl) {
-  if (ctrl && ctrl->stop) return;
+__device__ __forceinline__ void symv_lower_body(unsigned block_x, unsigned block_y, const double* __restrict__ M,
+                                                int64_t n, int64_t ld, const double* __restrict__ x,
+                                                double* __restrict__ npart, double* __restrict__ tpart, int64_t ldp,
+                                                int32_t part_rank, int32_t part_count, uint32_t ncached) {
   unsigned bi, bj, lin;
   if (PACKED) {
-    lin = blockIdx.x;
+    lin = block_x;
     tri_decode(lin, bi, bj);
   } else {
-    bi = blockIdx.x;
-    bj = blockIdx.y;
+    bi = block_x;
+    bj = block_y;
     if (bi < bj) return;  // tile strictly above the diagonal
     lin = bi * (bi + 1u) / 2u + bj;
   }
@@ -197,6 +196,33 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
     else sy_tile<false, true>(s, cbase, n0, n1, tout, lane);
   }
   *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(bj) * ldp + gr) = double2_t{n0, n1};
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restrict__ M, int64_t n, int64_t ld,
+                                                           const double* __restrict__ x, double* __restrict__ npart,
+                                                           double* __restrict__ tpart, int64_t ldp,
+                                                           int32_t part_rank, int32_t part_count, uint32_t ncached,
+                                                           const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  symv_lower_body<PACKED>(blockIdx.x, blockIdx.y, M, n, ld, x, npart, tpart, ldp, part_rank, part_count, ncached);
+}
+
+// The packed x-solve with a passenger: workgroup 0 runs the finalize logic of the PREVIOUS iteration (norms, tolerances,
+// stop decision: ~6 us of one workgroup's serial work) while the other workgroups stream the matrix.  Nothing in this
+// launch depends on that decision, and the fused element update that follows starts after it and no-ops when it has
+// raised ctrl->stop: the tail of an iteration shrinks to the element update itself (engine_run.hip, defer_fin).
+__global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __restrict__ M, int64_t n,
+                                                               const double* __restrict__ x,
+                                                               double* __restrict__ npart, double* __restrict__ tpart,
+                                                               int64_t ldp, uint32_t ncached, FinArgs f,
+                                                               int32_t fin_pending, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  if (blockIdx.x == 0) {
+    if (fin_pending) finalize_body<false, kWave>(f);
+    return;
+  }
+  symv_lower_body<true>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, 0, 1, ncached);
 }
 
 // column-major padded storage -> tile-packed storage (one workgroup per lower-triangle tile)
@@ -314,6 +340,13 @@ void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const dou
   const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
                      p.ldp, p.n, p.ntile, y, ctrl);
+}
+
+void launch_symv_lower_fin(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
+                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+  const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
+  hipLaunchKernelGGL(symv_lower_fin_kernel, dim3(static_cast<unsigned>(symv_tiles(p)) + 1u), dim3(kWave), 0, stream, M,
+                     p.n, x, npart, tpart, p.ldp, ncached, f, fin_pending ? 1 : 0, ctrl);
 }
 
 }  // namespace admm
