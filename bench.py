@@ -409,7 +409,9 @@ def main():
     dt_plain, _ = timed_run(eng, dist, a.steps, rho=rho)
     if a.xsolve == "inverse":
         alg_bytes = 8.0 * n * (n + 1) / 2  # lower triangle of the symmetric inverse, read once
-        kname = "symv_lower_kernel: x = inv(D'D+rho I) * y from the lower triangle only (its partial rows are summed by the one-launch tail prox_fin_kernel)"
+        kname = ("symv_lower_fin_kernel: x = inv(D'D+rho I) * y from the tile-packed lower triangle only (its first "
+                 "168 MB stay in the Infinity Cache between iterations, the rest streams non-temporally; workgroup 0 "
+                 "carries the previous iteration's finalize logic; the partial rows are summed by prox_fin_kernel)")
     else:
         alg_bytes = 8.0 * n * (n + 1)  # two triangular solves
         kname = "tri_step_kernel x 2K + tri_fold (x = L'\\(L\\y), blocked substitution, K coarse blocks)"
@@ -434,8 +436,8 @@ def main():
         return tot
 
     if n == 10000 and m == 100000:
-        traffic = (pmc_bytes("void admm::symv_lower_kernel<true>") if a.xsolve == "inverse"
-                   else None)
+        traffic = (pmc_bytes("admm::symv_lower_fin_kernel") or pmc_bytes("void admm::symv_lower_kernel<true>")
+                   if a.xsolve == "inverse" else None)
     xs_avg_ms = xs_ms / max(1, xs_cnt)
     achieved = alg_bytes / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
     out = {
