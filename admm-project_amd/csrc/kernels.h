@@ -97,8 +97,9 @@ struct TrsvPlan {
   int64_t n, npad;
   int64_t ldm, ldp;
   int32_t ntile, nblk, bt;   // 128-row tiles, coarse blocks, tiles per block
-  double* Fm;                // forward panels  [inv(L_kk); -L_below,k inv(L_kk)]   (lower, npad x npad)
-  double* Um;                // backward panels [-L_k,above' inv(L_kk)'; inv(L_kk)'] (upper, npad x npad)
+  double* Fm;                // forward panels  [inv(L_kk); -L_below,k inv(L_kk)]   (lower triangle, tile-packed)
+  double* Um;                // backward panels [-L_k,above' inv(L_kk)'; inv(L_kk)'] (upper triangle, tile-packed)
+  int64_t ncached;           // tiles of each triangle read with default loads (the rest stream non-temporally)
   double* P[2];              // [bt][npad] column-tile partials: the step in flight and the previous one
   double *v, *w;             // running right-hand sides (npad)
   bool streaming;            // non-temporal matrix loads (matrix larger than the caches)

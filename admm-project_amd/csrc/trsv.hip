@@ -36,8 +36,10 @@ constexpr int kTsPanel = 8;    // columns per load group
 constexpr int kTsBlockTiles = 16;  // 2048-row blocks: K = 5 at n = 10^4 (per-launch fixed cost ~6 us: 10 -> 217 us, 16 -> 182 us, 27 -> 177 us per pair)
 
 struct TriStepArgs {
-  const double* M;         // Fm or Um (npad x npad, ld)
-  int64_t ld;
+  const double* M;         // Fm or Um, tile-packed: the 128 x 128 tiles of the lower (Fm) / upper (Um) triangle back to
+                           // back, tile (R, C) at index R(R+1)/2 + C resp. C(C+1)/2 + R, column-major inside (ld 128)
+  uint32_t ncached;        // tiles with index < ncached are read with default loads (they stay in the Infinity Cache from
+                           // one solve to the next), the others non-temporally (symv.hip has the measurements)
   int64_t n;               // valid length of the vectors (caller vectors are not padded)
   const double* base_in;   // running right-hand side: rows outside the diagonal block carry base + partial sums
   double* base_out;
@@ -122,6 +124,54 @@ __device__ __forceinline__ void ts_fma(double2_t xp, int co, const double2_t (&d
   }
 }
 
+// the tile itself: lc0 = this wave's first column inside the tile, cw0 = the same as a global column
+template <int WAVES, bool NT>
+__device__ __forceinline__ void tri_tile(const TriStepArgs& a, const double* __restrict__ Mr, int lc0, int64_t cw0,
+                                         int64_t r, int32_t R, int32_t c, bool diag, int lane, int wave,
+                                         double2_t (*red)[kWave]) {
+  constexpr int WC = kTsTile / WAVES;
+  double2_t bufA[kTsPanel], bufB[kTsPanel];
+  ts_load<NT>(Mr, kTsTile, lc0, bufA);  // the matrix does not depend on the vectors: in flight during the prologue
+  // input block of this wave's columns: (base +) the previous step's partial sums, pair (2l, 2l+1) in lane l
+  double2_t xp{0.0, 0.0};
+  {
+    int32_t q0, q1;
+    ts_prev_range(a, a.dt0 + c, q0, q1);
+    const int64_t e = cw0 + 2 * (lane < WC / 2 ? lane : 0);
+    xp = ts_sum_prev(a, q0, q1, e);
+    if (a.x_use_base) xp += ts_load_vec(a.base_in, e, a.n);
+  }
+  // rows outside the diagonal block carry on: base_out = base_in + previous partial sums (first column tile only)
+  if (!diag && c == 0 && wave == 0) {
+    int32_t q0, q1;
+    ts_prev_range(a, R, q0, q1);
+    if (q1 > q0 || a.base_out != a.base_in)
+      ts_store_vec(a.base_out, r, a.n, ts_load_vec(a.base_in, r, a.n) + ts_sum_prev(a, q0, q1, r));
+  }
+  double a0 = 0.0, a1 = 0.0;
+  if (WC > kTsPanel) {
+#pragma unroll 1
+    for (int co = 0; co < WC; co += 2 * kTsPanel) {
+      ts_load<NT>(Mr, kTsTile, lc0 + co + kTsPanel, bufB);
+      ts_fma(xp, co, bufA, a0, a1);
+      if (co + 2 * kTsPanel < WC) ts_load<NT>(Mr, kTsTile, lc0 + co + 2 * kTsPanel, bufA);
+      ts_fma(xp, co + kTsPanel, bufB, a0, a1);
+    }
+  } else {
+    ts_fma(xp, 0, bufA, a0, a1);
+  }
+  double2_t acc{a0, a1};
+  if (WAVES > 1) {
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) acc += red[w][lane];
+  }
+  *reinterpret_cast<double2_t*>(a.Pcur + static_cast<int64_t>(c) * a.ldp + r) = acc;
+}
+
 // One workgroup = one 128 x 128 tile, WAVES waves of 128 x (128 / WAVES) columns each.
 template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * kWave) void tri_step_kernel(TriStepArgs a) {
@@ -145,47 +195,11 @@ __global__ __launch_bounds__(WAVES * kWave) void tri_step_kernel(TriStepArgs a) 
   if (diag && (a.upper ? c < R - a.dt0 : c > R - a.dt0)) return;  // all-zero tile of the triangular block
   const int64_t r = static_cast<int64_t>(R) * kTsTile + 2 * lane;  // this lane's row pair
   const int64_t cw0 = static_cast<int64_t>(a.dt0 + c) * kTsTile + wave * WC;  // this wave's first column
-  const double* __restrict__ Mr = a.M + r;
-  double2_t bufA[kTsPanel], bufB[kTsPanel];
-  ts_load<NT>(Mr, a.ld, cw0, bufA);  // the matrix does not depend on the vectors: in flight during the prologue
-  // input block of this wave's columns: (base +) the previous step's partial sums, pair (2l, 2l+1) in lane l
-  double2_t xp{0.0, 0.0};
-  {
-    int32_t q0, q1;
-    ts_prev_range(a, a.dt0 + c, q0, q1);
-    const int64_t e = cw0 + 2 * (lane < WC / 2 ? lane : 0);
-    xp = ts_sum_prev(a, q0, q1, e);
-    if (a.x_use_base) xp += ts_load_vec(a.base_in, e, a.n);
-  }
-  // rows outside the diagonal block carry on: base_out = base_in + previous partial sums (first column tile only)
-  if (!diag && c == 0 && wave == 0) {
-    int32_t q0, q1;
-    ts_prev_range(a, R, q0, q1);
-    if (q1 > q0 || a.base_out != a.base_in)
-      ts_store_vec(a.base_out, r, a.n, ts_load_vec(a.base_in, r, a.n) + ts_sum_prev(a, q0, q1, r));
-  }
-  double a0 = 0.0, a1 = 0.0;
-  if (WC > kTsPanel) {
-#pragma unroll 1
-    for (int co = 0; co < WC; co += 2 * kTsPanel) {
-      ts_load<NT>(Mr, a.ld, cw0 + co + kTsPanel, bufB);
-      ts_fma(xp, co, bufA, a0, a1);
-      if (co + 2 * kTsPanel < WC) ts_load<NT>(Mr, a.ld, cw0 + co + 2 * kTsPanel, bufA);
-      ts_fma(xp, co + kTsPanel, bufB, a0, a1);
-    }
-  } else {
-    ts_fma(xp, 0, bufA, a0, a1);
-  }
-  double2_t acc{a0, a1};
-  if (WAVES > 1) {
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave != 0) return;
-    acc = red[0][lane];
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) acc += red[w][lane];
-  }
-  *reinterpret_cast<double2_t*>(a.Pcur + static_cast<int64_t>(c) * a.ldp + r) = acc;
+  const uint32_t Ct = static_cast<uint32_t>(a.dt0 + c), Rt = static_cast<uint32_t>(R);
+  const uint32_t lin = a.upper ? Ct * (Ct + 1u) / 2u + Rt : Rt * (Rt + 1u) / 2u + Ct;
+  const double* __restrict__ Mr = a.M + static_cast<int64_t>(lin) * (kTsTile * kTsTile) + 2 * lane;
+  if (NT && lin >= a.ncached) tri_tile<WAVES, true>(a, Mr, wave * WC, cw0, r, R, c, diag, lane, wave, red);
+  else tri_tile<WAVES, false>(a, Mr, wave * WC, cw0, r, R, c, diag, lane, wave, red);
 }
 
 // x block of the last backward step: sum of its partials
@@ -216,6 +230,23 @@ __global__ __launch_bounds__(kBlock) void ts_transpose_block_kernel(const double
   }
 }
 
+// padded column-major square -> tile-packed triangle; tile t = (bi, bj), bi >= bj, holds M(bi, bj) of the lower triangle
+// (upper = 0) or M(bj, bi) of the upper one (upper = 1)
+__global__ __launch_bounds__(kBlock) void ts_pack_kernel(const double* __restrict__ M, int64_t ld, double* __restrict__ P,
+                                                         int upper) {
+  const unsigned t = blockIdx.x;
+  unsigned bi = static_cast<unsigned>((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while (bi * (bi + 1u) / 2u > t) --bi;
+  while ((bi + 1u) * (bi + 2u) / 2u <= t) ++bi;
+  const unsigned bj = t - bi * (bi + 1u) / 2u;
+  const int64_t tr = upper ? bj : bi, tc = upper ? bi : bj;  // tile row / column in M
+  const double* src = M + tc * kTsTile * ld + tr * kTsTile;
+  double* dst = P + static_cast<int64_t>(t) * (kTsTile * kTsTile);
+  for (int e = 2 * threadIdx.x; e < kTsTile * kTsTile; e += 2 * kBlock)
+    *reinterpret_cast<double2_t*>(dst + e) =
+        *reinterpret_cast<const double2_t*>(src + static_cast<int64_t>(e / kTsTile) * ld + (e % kTsTile));
+}
+
 static int ts_block_tiles() {
   if (const char* f = std::getenv("ADMM_TRSV_BLOCK_TILES")) {
     const int v = std::atoi(f);
@@ -228,8 +259,8 @@ size_t trsv_plan_elems(int64_t n) {
   const int64_t npad = round_up(n, kTsTile);
   const int64_t ntile = npad / kTsTile;
   const int64_t bt = std::min<int64_t>(ts_block_tiles(), ntile);
-  // Fm + Um + two partial buffers + v + w
-  return static_cast<size_t>(2 * npad * npad + 2 * bt * npad + 2 * npad);
+  // Fm + Um (tile-packed triangles) + two partial buffers + v + w
+  return static_cast<size_t>(ntile * (ntile + 1) * kTsTile * kTsTile + 2 * bt * npad + 2 * npad);
 }
 
 // L: n x n lower factor (upper part ignored); dinv64: its inverted 64x64 diagonal blocks.
@@ -245,15 +276,23 @@ int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, do
   p.bt = static_cast<int32_t>(ceil_div(p.ntile, p.nblk));  // balanced blocks
   p.ldm = p.npad;
   p.ldp = p.npad;
-  const size_t msz = static_cast<size_t>(p.npad) * p.npad;
-  p.Fm = buf;
-  p.Um = p.Fm + msz;
-  p.P[0] = p.Um + msz;
+  const size_t msz = static_cast<size_t>(p.npad) * p.npad;                                // the dense squares they are built in
+  const size_t psz = static_cast<size_t>(p.ntile) * (p.ntile + 1) / 2 * kTsTile * kTsTile;  // a packed triangle
+  double* const packedF = buf;
+  double* const packedU = buf + psz;
+  p.P[0] = packedU + psz;
   p.P[1] = p.P[0] + static_cast<int64_t>(p.bt) * p.npad;
   p.v = p.P[1] + static_cast<int64_t>(p.bt) * p.npad;
   p.w = p.v + p.npad;
-  p.streaming = stream_hint(static_cast<int64_t>(msz) * 8);
+  p.streaming = stream_hint(static_cast<int64_t>(psz) * 2 * 8);
+  // the split cache policy of symv.hip: both triangles are read once per solve pair and share the budget
+  p.ncached = p.streaming ? static_cast<int64_t>(kSymvCacheBytes / 2 / (8 * kTsTile * kTsTile)) : INT64_MAX;
   ADMM_HIP_TRY(hipMemsetAsync(buf, 0, trsv_plan_elems(n) * sizeof(double), stream));
+  double* dense = nullptr;  // Fm | Um as padded column-major squares: GEMM outputs, packed below
+  ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dense), 2 * msz * sizeof(double)));
+  ADMM_HIP_TRY(hipMemsetAsync(dense, 0, 2 * msz * sizeof(double), stream));
+  p.Fm = dense;
+  p.Um = dense + msz;
   for (int32_t k = 0; k < p.nblk; ++k) {
     const int64_t k0 = static_cast<int64_t>(k) * p.bt * kTsTile;
     const int64_t nb = std::min<int64_t>(static_cast<int64_t>(p.bt) * kTsTile, n - k0);
@@ -271,6 +310,14 @@ int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, do
     if (k0 > 0)  // Um_above = -(L_k,above)' * X_k'
       launch_gemm(1, 1, k0, nb, nb, -1.0, L + k0, ldl, Xk, p.ldm, 0.0, p.Um + k0 * p.ldm, p.ldm, false, stream);
   }
+  const unsigned ntri = static_cast<unsigned>(p.ntile) * static_cast<unsigned>(p.ntile + 1) / 2u;
+  hipLaunchKernelGGL(ts_pack_kernel, dim3(ntri), dim3(kBlock), 0, stream, p.Fm, p.ldm, packedF, 0);
+  hipLaunchKernelGGL(ts_pack_kernel, dim3(ntri), dim3(kBlock), 0, stream, p.Um, p.ldm, packedU, 1);
+  const hipError_t se = hipStreamSynchronize(stream);
+  (void)hipFree(dense);
+  ADMM_HIP_TRY(se);
+  p.Fm = packedF;
+  p.Um = packedU;
   return ADMM_OK;
 }
 
@@ -298,7 +345,7 @@ static void ts_step(const TriStepArgs& a, bool nt, hipStream_t stream) {
 // y, x: n elements (not padded); x may alias y.
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream) {
   TriStepArgs a{};
-  a.ld = p.ldm;
+  a.ncached = static_cast<uint32_t>(p.ncached > 0xffffffffLL ? 0xffffffffLL : p.ncached);
   a.ldp = p.ldp;
   a.n = p.n;
   a.ctrl = ctrl;
