@@ -655,3 +655,31 @@ def test_unwrapped_two_launch_iteration_matches_the_generic_path(gpu, monkeypatc
     if kind in ("hinge", "dplus"):
         ref = S.linearsvm(D, ell, Cv, dict(o))
         _compare(got, ref, tol=1e-7)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(objevals=1, maxiters=40), dict(fast=1, fasttype="strong", maxiters=60),
+                                  dict(relax=1.6, stopcond="both", maxiters=50), dict(convtest=1, stopcond="hnorm"),
+                                  dict(maxiters=13, domaxiters=1), dict(record_history=0, maxiters=70)])
+def test_lasso_deferred_finalize_on_the_packed_inverse(gpu, monkeypatch, opts):
+    """n = 1600 (>= 1536: tile-packed inverse, lower-triangle kernel): the finalize logic of iteration i rides along
+    with the x-solve of iteration i + 1 (symv_lower_fin_kernel) and the stop decision still lands on the iteration the
+    reference stops at -- early stops in the middle of a host batch, relaxation, fast ADMM, the convergence test, a
+    fixed iteration count that is not a multiple of the batch, no histories.  Compared with the oracle and with the
+    one-launch tail (ADMM_HIP_NO_DEFERRED_FINALIZE)."""
+    p = gpu.synth.lasso_problem(7, 2000, 1600)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    got = gpu.lasso(D, s, lam, dict(opts, xsolve="inverse"))
+    assert got["engine_info"]["xsolve_used"] == "inverse"
+    monkeypatch.setenv("ADMM_HIP_NO_DEFERRED_FINALIZE", "1")
+    one = gpu.lasso(D, s, lam, dict(opts, xsolve="inverse"))
+    monkeypatch.delenv("ADMM_HIP_NO_DEFERRED_FINALIZE")
+    assert got["steps"] == one["steps"]
+    for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr"):
+        assert np.array_equal(got[k], one[k]), k  # the same kernels in the same order: bitwise
+    if opts.get("record_history", 1):
+        ref = S.lasso(D, s, lam, dict(opts))
+        _compare(got, ref, tol=1e-7)
+    else:
+        ref = S.lasso(D, s, lam, {k: v for k, v in opts.items() if k != "record_history"})
+        assert got["steps"] == ref["steps"] and "xvals" not in got
+        _close("xopt", got["xopt"], ref["xopt"], 1e-7)
