@@ -82,8 +82,10 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   ExtrapArgs& xa = rs.xa;
   (void)alg; (void)len; (void)pa; (void)xa;
 
-  if (alg != 0) return fail(ADMM_E_UNSUPPORTED, "fast/accelerated ADMM is not implemented for 2-D total variation");
-  if (o.relax != 1.0) return fail(ADMM_E_UNSUPPORTED, "relaxation is not implemented for 2-D total variation");
+  // the z-closure of totalvariation.m applies D to what it is handed (getProxOps.m:199); with D of size 2N x N the
+  // relaxed Axhat (2N elements, admm.m:517) does not fit: a dimension error, as for the linear SVM (getProxOps.m:1088)
+  if (o.relax != 1.0)
+    return fail(ADMM_E_INVALID, "relaxation with the 2-D total-variation prox is a dimension error (D is 2N x N)");
   const int64_t Npix = e->tv2_H * e->tv2_W;
   if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
@@ -114,7 +116,74 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   const auto t0 = std::chrono::steady_clock::now();
   int32_t done = 0;
   bool stop_seen = false;
-  while (done < N && !stop_seen) {
+  if (alg != 0) {
+    // Fast / accelerated ADMM (admm.m:267-298, 563-600), as for the 1-D solver: the x-update takes (v, uhat), the
+    // generic fused prox kernel does the z/u update, extrapolation, histories and partial sums on the vector D*x,
+    // the D' stencils of the dual residual come from dz = z - zprev and u.  z, u live in buffer A, updated in place.
+    if (!e->dz) ADMM_TRY(e->mem.alloc(&e->dz, round_up(len, 2)));
+    if (!e->tmpA) ADMM_TRY(e->mem.alloc(&e->tmpA, round_up(len, 2)));
+    pa.z = e->tv_zA;
+    pa.u = e->tv_uA;
+    xa.z = e->tv_zA;
+    xa.u = e->tv_uA;
+    xa.rhs = nullptr;
+    pa.dz = e->dz;
+    pa.prox = PROX_SOFT;
+    pa.t = e->lambda / o.rho;  // getProxOps.m:199
+    pa.objz = OBJZ_NONE;
+    pa.objx = OBJX_NONE;
+    pa.x_out = nullptr;
+    pa.xhist = nullptr;
+    pa.rhs = nullptr;
+    pa.rhs_kind = RHS_NONE;
+    pa.a_identity = 0;
+    pa.c = nullptr;
+    fa.obj_scale_x = 0.0;
+    fa.obj_scale_z = 0.0;
+    fa.obj_scale_part = o.objevals ? 1.0 : 0.0;
+    while (done < N && !stop_seen) {
+      ta.z = e->v;  // x = xminf(x, v, uhat, rho)   admm.m:506
+      ta.u = e->uhat;
+      {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
+      }
+      if (e->tv2_dct) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+      else ADMM_TRY(cg_solve(e, e->rhs));
+      int nob = 0, nblk = 1;
+      launch_tv2d_dx(ta.H, ta.W, e->lambda, o.objevals, e->x, e->s, e->tmpA, e->objpart, &nob, e->xhist, e->ctrl,
+                     e->stream);
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        pa.axsrc = e->tmpA;
+        pa.ax_t = nullptr;
+        pa.naxpart = 1;
+        pa.axld = 0;
+        launch_prox(pa, e->ctrl, &nblk, e->stream);
+      }
+      fa.nblk = nblk;
+      fa.slots_reduced = nullptr;
+      fa.objp_reduced = nullptr;
+      if (alg == 2) {
+        launch_fast_decide(fa, e->stream);
+        launch_extrapolate(xa, e->ctrl, e->stream);
+      }
+      launch_tv2d_dual_vec(ta.H, ta.W, e->dz, e->tv_uA, e->part, nblk, e->ctrl, e->stream);
+      fa.objpart = o.objevals ? e->objpart : nullptr;
+      fa.nobjpart = o.objevals ? nob : 0;
+      {
+        TimerScope ts(e, ADMM_K_FINALIZE);
+        launch_finalize(fa, e->stream);
+      }
+      done += 1;
+      if (!e->tv2_dct || done % check_tv2 == 0 || done == N) {
+        ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
+        ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->ctrl_host->stop) stop_seen = true;
+      }
+    }
+  }
+  while (alg == 0 && done < N && !stop_seen) {
     const bool a_cur = (done & 1) == 0;  // iteration k reads buffer A when k is even
     ta.z = a_cur ? e->tv_zA : e->tv_zB;
     ta.u = a_cur ? e->tv_uA : e->tv_uB;
@@ -153,8 +222,8 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (e->profiling) collect_timers(e);
   const int32_t steps = e->ctrl_host->steps;
-  e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
-  e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+  e->z = (alg == 0 && (steps & 1)) ? e->tv_zB : e->tv_zA;  // fast ADMM updates buffer A in place
+  e->u = (alg == 0 && (steps & 1)) ? e->tv_uB : e->tv_uA;
   ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
   e->cg_total_last = e->cg_st_host->total;
   e->last = admm_run_summary{};

@@ -44,4 +44,11 @@ void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStre
 // following launch_tv2d_rhs; launch_tv2d_rhs is still needed once, for the first iteration)
 void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 
+// Unfused building blocks for the fast / accelerated ADMM variants: ax = D*x (2N) with the objective in block partials
+// and the x history column; the D' stencils of the dual residual / tolerance from dz = z - zprev and u
+void launch_tv2d_dx(int64_t H, int64_t W, double lambda, int objevals, const double* x, const double* s, double* ax,
+                    double* objpart, int* nobj_out, double* xhist, const Ctrl* ctrl, hipStream_t stream);
+void launch_tv2d_dual_vec(int64_t H, int64_t W, const double* dz, const double* u, double* part, int nblk,
+                          const Ctrl* ctrl, hipStream_t stream);
+
 }  // namespace admm

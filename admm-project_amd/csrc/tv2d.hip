@@ -294,6 +294,68 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
   tv2_block_partials(acc, a.part, 0, S_COUNT - 1);
 }
 
+// ---- building blocks of the fast / accelerated ADMM variants (the generic prox kernel does z, u, v, uhat)
+// ax = D*x as a 2N-vector, the objective 1/2||x - s||^2 + lambda*||D x||_1 in block partials, the x history column
+__global__ __launch_bounds__(kBlock) void tv2d_dx_kernel(int64_t H, int64_t W, double lambda, int objevals,
+                                                         const double* __restrict__ x, const double* __restrict__ s,
+                                                         double* __restrict__ ax, double* __restrict__ objpart,
+                                                         double* __restrict__ xhist, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  const int64_t it = ctrl->iter;
+  const int64_t N = H * W;
+  double acc = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double xi = x[idx];
+    const double dv = (i < H - 1) ? xi - x[idx + 1] : 0.0, dh = (j < W - 1) ? xi - x[idx + H] : 0.0;
+    ax[idx] = dv;
+    ax[N + idx] = dh;
+    if (objevals) {
+      const double e = xi - s[idx];
+      acc += 0.5 * (e * e) + lambda * (fabs(dv) + fabs(dh));
+    }
+    if (xhist) xhist[it * N + idx] = xi;
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) objpart[blockIdx.x] = t;
+}
+
+void launch_tv2d_dx(int64_t H, int64_t W, double lambda, int objevals, const double* x, const double* s, double* ax,
+                    double* objpart, int* nobj_out, double* xhist, const Ctrl* ctrl, hipStream_t stream) {
+  const int nb = tv2_blocks(H * W);
+  *nobj_out = nb;
+  hipLaunchKernelGGL(tv2d_dx_kernel, dim3(nb), dim3(kBlock), 0, stream, H, W, lambda, objevals, x, s, ax, objpart, xhist,
+                     ctrl);
+}
+
+// ||D'dz||^2 (admm.m:624, 632) and ||D'u||^2 (admm.m:654) from the vectors dz = z - zprev and u, into the S_G2 / S_G3
+// rows of the prox kernel's partial array (nblk blocks, as that kernel used)
+__global__ __launch_bounds__(kBlock) void tv2d_dual_vec_kernel(int64_t H, int64_t W, const double* __restrict__ dz,
+                                                               const double* __restrict__ u, double* __restrict__ part,
+                                                               const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t N = H * W;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
+       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t j = idx / H, i = idx - j * H;
+    const double g2 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return dz[k]; }, [&](int64_t k) { return dz[N + k]; });
+    const double g3 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return u[k]; }, [&](int64_t k) { return u[N + k]; });
+    acc[S_G2] += g2 * g2;
+    acc[S_G3] += g3 * g3;
+  }
+  tv2_block_partials(acc, part, S_G2, S_G3);
+}
+
+void launch_tv2d_dual_vec(int64_t H, int64_t W, const double* dz, const double* u, double* part, int nblk,
+                          const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(tv2d_dual_vec_kernel, dim3(nblk), dim3(kBlock), 0, stream, H, W, dz, u, part, ctrl);
+}
+
 void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
   const int nb = tv2_blocks(a.H * a.W);
   *nblk_out = nb;

@@ -69,6 +69,31 @@ def test_tv2d_denoises(gpu):
     assert r["objopt"] == pytest.approx(obj(r["xopt"]), rel=1e-9)
 
 
+@pytest.mark.parametrize("H,W", [(24, 17), (32, 64)])  # CG x-update / spectral x-update
+@pytest.mark.parametrize("opts", [dict(fast=1, fasttype="strong", objevals=1, maxiters=60),
+                                  dict(fast=1, fasttype="weak", objevals=1, maxiters=25),
+                                  dict(fast=1, fasttype="strong", stopcond="both", rho=2.0, maxiters=40)])
+def test_tv2d_fast_admm(gpu, H, W, opts):
+    """fast / accelerated ADMM (admm.m:267-298, 563-600) on the image solver: the x-update takes (v, uhat), the generic
+    fused kernel does z, u, v, uhat, the D' stencils come from dz and u.  Accelerated ADMM is compared while its
+    restart value is far from rounding noise (its decisions are knife-edge below that)."""
+    img = _image(H * 100 + W + 1, H, W)
+    got = gpu.totalvariation2d(img, 0.5, dict(opts))
+    ref = S.totalvariation2d(img, 0.5, dict(opts))
+    assert got["steps"] == ref["steps"]
+    keys = ("xvals", "zvals", "uvals", "vvals", "uhatvals", "avals", "dvals", "restarted", "pnorm", "dnorm", "perr", "derr",
+            "objevals", "xopt", "zopt", "uopt")
+    for k in keys:
+        assert (k in got) == (k in ref), k
+        if k in ref:
+            _close(k, got[k], ref[k], 1e-6)
+
+
+def test_tv2d_relaxation_is_a_dimension_error(gpu):
+    with pytest.raises(Exception, match="dimension error"):
+        gpu.totalvariation2d(_image(3, 16, 16), 0.5, dict(relax=1.5))
+
+
 def test_tv2d_argument_errors(gpu):
     with pytest.raises(ValueError, match="not an image"):
         gpu.totalvariation2d(np.zeros(10), 1.0, {})
