@@ -1247,6 +1247,21 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       // the K slice inverses are each read once per iteration: they share the Infinity-Cache budget of the split policy
       for (ConsSlice& sl : e->cslices)
         if (sl.fac.Minv) sl.fac.planSy.ncached = symv_cached_tiles(sl.fac.planSy, kSymvCacheBytes / (K > 0 ? K : 1));
+      if (e->csyN) {  // all slices packed and of one size: their x-solves run as ONE launch
+        bool packed = true;
+        std::vector<const double*> hp;
+        for (const ConsSlice& sl : e->cslices) {
+          packed = packed && sl.fac.planSy.packed;
+          hp.push_back(sl.fac.Minv);
+        }
+        if (packed) {
+          double* raw = nullptr;
+          E_TRY(e->mem.alloc(&raw, hp.size()));  // K pointers in K doubles
+          E_HIP(hipMemcpyAsync(raw, hp.data(), sizeof(double*) * hp.size(), hipMemcpyHostToDevice, e->stream));
+          E_HIP(hipStreamSynchronize(e->stream));
+          e->cMptr = reinterpret_cast<const double**>(raw);
+        }
+      }
       E_TRY(e->mem.alloc(&e->cY, K * e->cldn));
       E_TRY(e->mem.alloc(&e->cDts, K * e->cldn));
       E_HIP(hipMemsetAsync(e->cDts, 0, sizeof(double) * K * e->cldn, e->stream));

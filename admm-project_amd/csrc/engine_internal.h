@@ -158,6 +158,7 @@ struct admm_engine {
   // deferred finalize (engine_run.hip): the previous iteration's finalize arguments ride along with the packed x-solve
   const FinArgs* dfin = nullptr;
   bool dfin_pending = false;
+  const double** cMptr = nullptr;  // consensus: device array of the K packed slice inverses (one batched x-solve launch)
   // two-launch unwrapped iteration (unwrapped.hip): pinv(D) as an n x m matrix and the double-buffered partial rows
   double* Dp = nullptr;
   int64_t ldDp = 0;

@@ -1,5 +1,7 @@
 // engine_run_consensus.hip -- the iteration sequence of consensus lasso (getProxOps.m:383-442, 1217-1343; one slice
 // per rank when row-sharded), split out of admm_engine_run.
+#include <cstdlib>
+
 #include "engine_internal.h"
 
 namespace admm {
@@ -68,6 +70,10 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
     for (int32_t b = 0; b < batch; ++b) {
       {
         TimerScope ts(e, ADMM_K_XSOLVE);
+        if (e->cMptr && std::getenv("ADMM_HIP_CONS_UNBATCHED") == nullptr)
+          launch_symv_lower_batch(e->cslices[0].fac.planSy, e->cMptr, K, e->cY, ldn, e->csyN, e->csyT, e->cpstride,
+                                  e->ctrl, e->stream);
+        else
         for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
           ConsSlice& sl = e->cslices[k];
           const double* yk = e->cY + k * ldn;  // rho*(z - u_k) + D_k's_k, left by the previous update kernel
