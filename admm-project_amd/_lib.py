@@ -78,7 +78,7 @@ class Options(C.Structure):
 class RunSummary(C.Structure):
     _fields_ = [
         ("steps", C.c_int32), ("stopped_early", C.c_int32), ("convtest_failed_at", C.c_int32),
-        ("reserved", C.c_int32), ("runtime_s", C.c_double), ("objopt", C.c_double),
+        ("obj_gram_used", C.c_int32), ("runtime_s", C.c_double), ("objopt", C.c_double),
     ]
 
 

@@ -130,7 +130,7 @@ def getproxops(problem, args):
             Lf = Lf.toarray()  # lasso.m:175 stores the factor sparse
         # args.objgram (engine-side extension): objective through the cached Gram matrix, see admm_engine.h obj_gram
         eng = Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=rho, Lfactor=Lf, xsolve=xs, device=dev, comm=comm,
-                     obj_gram=int(bool(args.get("objgram", 0))), **cg)
+                     obj_gram=int(args.get("objgram", 0)), **cg)
         prob = _Problem("lasso", eng, dict(A=1, c=0.0, nA=n, nB=n))
     elif kind in ("lad", "huberfit"):
         D, s = _get(args, "D"), _get(args, "s")

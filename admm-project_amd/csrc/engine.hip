@@ -771,7 +771,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
-          if (desc->obj_gram && e->s) {  // keep G = D'D (before the rho shift) in the symmetric kernel's tile-padded layout
+          const bool gram_auto = desc->obj_gram == 0 && n >= kSymvHalfMin && m * n >= (int64_t{1} << 26);
+          if ((desc->obj_gram > 0 || gram_auto) && e->s) {  // keep G = D'D (before the rho shift) for the objective
+            e->obj_auto = desc->obj_gram == 0;
+            E_TRY(e->mem.alloc(&e->gobjpart, kMaxPartBlocks + 2));
             e->planG = symv_plan(n);
             e->planG.ncached = symv_cached_tiles(e->planG, 0);  // the x-solve's inverse owns the Infinity-Cache share
             e->ldG = e->planG.npad;
@@ -802,6 +805,15 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
               E_HIP(hipStreamSynchronize(e->stream));
             }
             e->half_ssq = 0.5 * ssq;
+            if (n >= kSymvHalfMin) {  // tile-packed like the inverses: half the memory, the faster layout
+              double* P = nullptr;
+              E_TRY(e->mem.alloc(&P, symv_packed_elems(e->planG)));
+              launch_symv_pack(e->planG, e->Gpad, e->ldG, P, e->stream);
+              E_HIP(hipStreamSynchronize(e->stream));
+              mem_free_one(e->mem, e->Gpad);
+              e->Gpad = P;
+              e->planG.packed = true;
+            }
           }
           launch_add_diag(W, n, ld, desc->rho, e->stream);
         } else {  // lasso.m:172  chol(1/rho*(D*D') + I)

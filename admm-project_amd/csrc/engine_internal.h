@@ -120,6 +120,9 @@ struct admm_engine {
   int64_t ldG = 0;
   SymvPlan planG{};
   double half_ssq = 0.0;
+  // obj_gram = 0 (automatic): calibrate against the literal form during the first batch, then decide (engine_run.hip)
+  bool obj_auto = false, obj_gram_ok = false, obj_gram_bad = false;
+  double* gobjpart = nullptr;  // [kMaxPartBlocks + 1] Gram-form partials during calibration; last entry: max discrepancy
   bool tv2_dct = false;          // spectral (DCT) x-update instead of CG: both sides a power of two (dct.h)
   DctTables dctH{}, dctW{};
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)

@@ -399,11 +399,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           return fail(ADMM_E_INVALID, "objevals on a lasso engine created from args.Dts alone: the objective "
                                       "0.5*||D*x - s||^2 (lasso.m:227) needs s (or an objective callback)");
         obj_lasso_gemv = true;
-        fa.obj_scale_part = 0.5;
-        if (e->Gpad) {  // 1/2*x'Gx - x'D's + 1/2*s's  (desc.obj_gram)
-          fa.obj_scale_part = 1.0;
-          fa.obj_const = e->half_ssq;
-        }
+        fa.obj_scale_part = 0.5;  // (the Gram form sets its own scale and constant per iteration, below)
         pa.objz = OBJZ_ABS;
         fa.obj_scale_z = e->lambda;
         break;
@@ -624,6 +620,13 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
                          e->xsolve != ADMM_XSOLVE_CG && heavy <= (int64_t{32} << 20) && !e->xcb && !e->zcb && !e->ocb;
   // A = I iterations whose finalize depends on nothing but the prox kernel's partial sums end in ONE launch
   // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
+  // the lasso objective through the cached Gram matrix: always (obj_gram = 1), or once the calibration of the first
+  // batch has shown it agrees with the literal D*x form to 1e-11 (obj_gram = 0; admm_engine.h)
+  bool gram_now = obj_lasso_gemv && e->Gpad && (!e->obj_auto || e->obj_gram_ok);
+  bool gram_calibrating = obj_lasso_gemv && e->Gpad && e->obj_auto && !e->obj_gram_ok && !e->obj_gram_bad;
+  if (use_graph || sharded) gram_calibrating = false;  // (a captured batch cannot switch; shards would have to agree)
+  if (gram_calibrating)
+    ADMM_HIP_TRY(hipMemsetAsync(e->gobjpart + kMaxPartBlocks, 0, sizeof(double), e->stream));
   const bool obj_kernels = o.objevals && (obj_lasso_gemv || obj_qp_gemv || obj_model_gemv || e->ocb);
   // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
   // without it the finalize logic needs none of the D' products that follow the prox kernel
@@ -770,12 +773,18 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       }
       fa.objpart = nullptr;
       fa.nobjpart = 0;
-      if (obj_lasso_gemv && e->Gpad) {  // the same number from the cached Gram matrix: one pass over its lower triangle
-        TimerScope ts(e, ADMM_K_GEMV_N);
-        int nob = 0;
+      // 1/2*x'Gx - x'D's (+ 1/2*s's) from the cached Gram matrix: one pass over its lower triangle
+      auto gram_objective = [&](double* part, int* nob) {
         if (e->gN) launch_symv_lower(e->planG, e->Gpad, e->ldG, e->x, e->gN, e->gT, e->gx, e->ctrl, e->stream);
         else launch_symv_small(e->Gpad, e->n, e->ldG, e->x, e->gx, e->ctrl, e->stream);
-        launch_qp_objective(e->gx, 1, 0, e->x, e->negDts, e->n, e->objpart, &nob, e->ctrl, e->stream);
+        launch_qp_objective(e->gx, 1, 0, e->x, e->negDts, e->n, part, nob, e->ctrl, e->stream);
+      };
+      if (obj_lasso_gemv && gram_now) {
+        TimerScope ts(e, ADMM_K_GEMV_N);
+        int nob = 0;
+        gram_objective(e->objpart, &nob);
+        fa.obj_scale_part = 1.0;
+        fa.obj_const = e->half_ssq;
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
       } else if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
@@ -784,8 +793,16 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_gemv_n(e->planDN, e->D, e->x, e->partDN, e->ctrl, e->stream);
         launch_residual_sq(e->partDN, e->planDN.nchunk, e->planDN.ldy, e->s, e->m, e->objpart, &nob, e->ctrl,
                            e->stream);
+        fa.obj_scale_part = 0.5;
+        fa.obj_const = 0.0;
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
+        if (gram_calibrating) {  // the Gram form beside it: how far apart are they?
+          int nog = 0;
+          gram_objective(e->gobjpart, &nog);
+          launch_obj_compare(e->objpart, nob, 0.5, 0.0, e->gobjpart, nog, 1.0, e->half_ssq,
+                             e->gobjpart + kMaxPartBlocks, e->ctrl, e->stream);
+        }
         if (sharded) {  // sum over the row shards of ||D_g*x - s_g||^2
           launch_pack_sum(e->objpart, nob, e->red + 16, e->ctrl, e->stream);
           ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 1, e->stream));
@@ -873,6 +890,18 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         loop_rc = fail(ADMM_E_DEVICE, "polling the device control block failed");
       else if (e->ctrl_host->stop) stopped = true;
     }
+    if (gram_calibrating && loop_rc == ADMM_OK) {  // the batch evaluated both forms of the lasso objective
+      double disc = 1.0;
+      if (hipMemcpy(&disc, e->gobjpart + kMaxPartBlocks, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        loop_rc = fail(ADMM_E_DEVICE, "reading the objective calibration failed");
+      gram_calibrating = false;
+      if (disc <= 1e-11) {
+        e->obj_gram_ok = true;
+        gram_now = true;
+      } else {
+        e->obj_gram_bad = true;
+      }
+    }
   }
   e->dfin = nullptr;
   e->dfin_pending = false;
@@ -903,6 +932,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   }
   e->last.stopped_early = (e->ctrl_host->steps < N) ? 1 : 0;
   e->last.convtest_failed_at = e->ctrl_host->convfail;
+  e->last.obj_gram_used = (o.objevals && gram_now) ? 1 : 0;
   e->last.runtime_s = runtime;
   e->last.objopt = NAN;
   if (o.objevals && e->last.steps > 0) {  // admm.m:752-754: obj(x,z) at the final iterates == last objevals entry

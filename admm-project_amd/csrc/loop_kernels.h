@@ -226,6 +226,10 @@ struct ZStateArgs {
   int32_t alg, phase;
 };
 void launch_zstate(const ZStateArgs& a, const Ctrl* ctrl, hipStream_t stream);
+// disc[0] = max(disc[0], |a - b| / |a|) for a = sa*sum(pa[0..na)) + ca, b = sb*sum(pb[0..nb)) + cb (one workgroup, fixed
+// order): the calibration of the Gram-form lasso objective against the literal one
+void launch_obj_compare(const double* pa, int na, double sa, double ca, const double* pb, int nb, double sb, double cb,
+                        double* disc, const Ctrl* ctrl, hipStream_t stream);
 // x = alpha*(sum_c part[c][i]) + beta*y[i] + add[i]  (add/y nullable)
 void launch_combine(const double* part, int32_t nchunk, int64_t ld, double alpha, const double* y, double beta,
                     const double* add, double* x, int64_t len, const Ctrl* ctrl, hipStream_t stream);

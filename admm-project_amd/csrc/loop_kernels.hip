@@ -464,6 +464,29 @@ void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const d
                      ld, x, q, len, objpart, ctrl);
 }
 
+__global__ __launch_bounds__(kBlock) void obj_compare_kernel(const double* __restrict__ pa, int na, double sa, double ca,
+                                                             const double* __restrict__ pb, int nb, double sb, double cb,
+                                                             double* __restrict__ disc, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double scratch[4];
+  double va = 0.0, vb = 0.0;
+  for (int i = threadIdx.x; i < na; i += kBlock) va += pa[i];
+  for (int i = threadIdx.x; i < nb; i += kBlock) vb += pb[i];
+  const double ta = block_sum(va, scratch);
+  __syncthreads();
+  const double tb = block_sum(vb, scratch);
+  if (threadIdx.x == 0) {
+    const double a = sa * ta + ca, b = sb * tb + cb;
+    const double rel = fabs(a - b) / fmax(fabs(a), 1e-300);
+    if (!(rel <= disc[0])) disc[0] = rel;  // NaN-safe maximum
+  }
+}
+
+void launch_obj_compare(const double* pa, int na, double sa, double ca, const double* pb, int nb, double sb, double cb,
+                        double* disc, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(obj_compare_kernel, dim3(1), dim3(kBlock), 0, stream, pa, na, sa, ca, pb, nb, sb, cb, disc, ctrl);
+}
+
 __global__ __launch_bounds__(kBlock) void combine_kernel(const double* __restrict__ part, int32_t nchunk, int64_t ld,
                                                          double alpha, const double* __restrict__ y, double beta,
                                                          const double* __restrict__ add, double* __restrict__ x,

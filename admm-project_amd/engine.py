@@ -113,7 +113,7 @@ class Engine:
             d.cg_tol = float(cg_tol)
         if cg_maxit is not None:
             d.cg_maxit = int(cg_maxit)
-        d.obj_gram = int(bool(obj_gram))
+        d.obj_gram = int(obj_gram)  # 0 automatic, 1 Gram form, -1 literal form (admm_engine.h)
         if slices is not None:
             sl = np.ascontiguousarray(np.asarray(slices, dtype=np.int64))
             keep.append(sl)

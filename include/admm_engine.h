@@ -149,10 +149,14 @@ typedef struct admm_problem_desc {
   admm_comm* comm;     /* NULL = single device; else rows are sharded across the ranks */
   double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
   int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
-  int32_t obj_gram;    /* lasso, tall, factor built by the engine: 1 = evaluate the objective's 1/2*||D*x - s||^2 (lasso.m:227)
-                          as 1/2*x'Gx - x'D's + 1/2*s's with the cached Gram matrix G = D'D -- one pass over G's lower
-                          triangle (4n^2 B) instead of one over D (8mn B).  Absolute rounding error ~1e-16*||s||^2,
-                          i.e. relative error eps*||s||^2/objective: opt-in, 0 = the literal D*x form */
+  int32_t obj_gram;    /* lasso, tall, factor built by the engine: how the objective's 1/2*||D*x - s||^2 (lasso.m:227) is
+                          evaluated.  The Gram form 1/2*x'Gx - x'D's + 1/2*s's with the cached G = D'D is one pass over
+                          G's lower triangle (4n^2 B) instead of one over D (8mn B); its absolute rounding error is
+                          ~1e-16*||s||^2, i.e. relative error eps*||s||^2/objective.
+                          0 = automatic: where the literal pass is expensive (n >= 1536, m*n >= 2^26) the engine keeps
+                              G, evaluates BOTH forms during the first host batch of the first objevals run (the
+                              literal values are the ones recorded) and switches to the Gram form only if they agreed
+                              to 1e-11 relative; 1 = the Gram form always; -1 = the literal D*x form always */
   /* ADMM_PROB_MODEL (getProxOps.m:83-89): P = args.PtP, q = args.Ptr above; and */
   const double* Q;     /* n x n: args.QtQ */
   const double* qz;    /* length n: args.Qts */
@@ -210,7 +214,7 @@ typedef struct admm_run_summary {
   int32_t steps;               /* results.steps (admm.m:746) */
   int32_t stopped_early;       /* 1 if a stop condition fired before maxiters */
   int32_t convtest_failed_at;  /* >0: iteration where the H-norm monotonicity test aborted (admm.m:686-701) */
-  int32_t reserved;
+  int32_t obj_gram_used;   /* 1: the run ended with the lasso objective in its Gram form (admm_problem_desc.obj_gram) */
   double runtime_s;            /* loop only: tic admm.m:315 .. toc admm.m:756 */
   double objopt;               /* results.objopt (admm.m:752-754), NaN if not evaluated */
 } admm_run_summary;

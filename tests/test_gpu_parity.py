@@ -683,3 +683,29 @@ def test_lasso_deferred_finalize_on_the_packed_inverse(gpu, monkeypatch, opts):
         ref = S.lasso(D, s, lam, {k: v for k, v in opts.items() if k != "record_history"})
         assert got["steps"] == ref["steps"] and "xvals" not in got
         _close("xopt", got["xopt"], ref["xopt"], 1e-7)
+
+
+def test_lasso_objective_switches_to_the_gram_form_after_calibration(gpu):
+    """obj_gram = 0 (default) on a problem where the literal pass is expensive (n >= 1536, m*n >= 2^26): the first batch
+    of the first objevals run evaluates both forms of 1/2*||D*x - s||^2, the literal values are recorded, and the later
+    batches use the Gram form -- the recorded objective matches the literal engine (obj_gram = -1) to 1e-10 throughout,
+    and a second run starts in the Gram form."""
+    L = gpu._lib
+    p = gpu.synth.lasso_problem(11, 42000, 1600)
+    kw = dict(D=p["D"], s=p["s"], lam=p["lam"], rho=1.0, xsolve=L.XSOLVE_INVERSE)
+    auto, lit = gpu.Engine(L.PROB_LASSO, **kw), gpu.Engine(L.PROB_LASSO, obj_gram=-1, **kw)
+    small = gpu.Engine(L.PROB_LASSO, D=p["D"][:3000], s=p["s"][:3000], lam=p["lam"], rho=1.0)
+    try:
+        run = dict(maxiters=40, domaxiters=1, objevals=1, record_history=0, check_every=8)
+        sa, sl = auto.run(**run), lit.run(**run)
+        assert sa.obj_gram_used == 1 and sl.obj_gram_used == 0
+        oa, ol = auto.fetch(L.F_OBJEVALS, 40), lit.fetch(L.F_OBJEVALS, 40)
+        assert np.array_equal(oa[:8], ol[:8])  # the calibration batch records the literal values
+        assert np.max(np.abs(oa - ol) / np.abs(ol)) < 1e-10
+        assert not np.array_equal(oa[8:], ol[8:])  # ... and the later ones really come from the other formula
+        s2 = auto.run(**run)
+        assert s2.obj_gram_used == 1
+        assert np.max(np.abs(auto.fetch(L.F_OBJEVALS, 40) - ol) / np.abs(ol)) < 1e-10
+        assert small.run(**run).obj_gram_used == 0  # cheap literal pass: G is not even kept
+    finally:
+        auto.close(), lit.close(), small.close()
