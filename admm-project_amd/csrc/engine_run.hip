@@ -556,8 +556,16 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (args.Dplus, linearsvm.m:185-186) row 0 is Dplus*t1 = the x-update itself (getProxOps.m:1067) and only the two
   // dual-residual products still stream D.
   int op_rc = ADMM_OK;
+  const FinArgs* tp_fin = nullptr;  // set for ONE call: that call's partial-sum launch carries this finalize
   auto transposed_products = [&](int nrhs) {
     TimerScope ts(e, ADMM_K_GEMV_T);
+    const FinArgs* fin = tp_fin;
+    tp_fin = nullptr;
+    auto sum_t = [&](int nr, double* gout) {
+      if (fin) launch_sum_partials_t_fin(e->planDT, e->partDT, nr, gout, e->ldg, *fin, e->ctrl, e->stream);
+      else launch_sum_partials_t(e->planDT, e->partDT, nr, gout, e->ldg, e->ctrl, e->stream);
+      fin = nullptr;
+    };
     if (e->atcb && !e->D) {  // options.At as a function handle (admm.m:165-167): one call per right-hand side
       const double* vecs[3] = {e->rhs, e->dz, e->u};
       for (int r = 0; r < nrhs && op_rc == ADMM_OK; ++r)
@@ -565,14 +573,14 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           op_rc = fail(ADMM_E_INVALID, "the At operator callback reported a failure");
     } else if (e->DplusT) {
       launch_gemv_t(e->planDT, e->DplusT, e->rhs, nullptr, nullptr, 1, e->partDT, e->ctrl, e->stream);
-      launch_sum_partials_t(e->planDT, e->partDT, 1, e->g, e->ldg, e->ctrl, e->stream);
+      sum_t(1, e->g);
       if (nrhs > 1) {
         launch_gemv_t(e->planDT, e->D, e->dz, e->u, nullptr, 2, e->partDT, e->ctrl, e->stream);
-        launch_sum_partials_t(e->planDT, e->partDT, 2, e->g + e->ldg, e->ldg, e->ctrl, e->stream);
+        sum_t(2, e->g + e->ldg);
       }
     } else {
       launch_gemv_t(e->planDT, e->D, e->rhs, e->dz, e->u, nrhs, e->partDT, e->ctrl, e->stream);
-      launch_sum_partials_t(e->planDT, e->partDT, nrhs, e->g, e->ldg, e->ctrl, e->stream);
+      sum_t(nrhs, e->g);
     }
   };
   // The unwrapped iteration with an explicit pseudo-inverse (linear SVM, unwrappedadmm.m:76-92) runs as TWO launches per
@@ -638,6 +646,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // update after that starts with the decision in ctrl.  A batch's last iteration gets a stand-alone finalize.
   const bool defer_fin = fuse_tail && e->a_identity && xsolve_has_partials(e) && e->xfac.planSy.packed && !use_graph &&
                          std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  // A = D iterations without a dual residual (fuse_tail): the finalize logic leaves the element update's launch too and
+  // runs as one extra workgroup of the partial-sum launch of D'*(c + z - u) that follows it (gemv.hip)
+  const bool defer_fin_ad = fuse_tail && !e->a_identity && e->D && !(e->atcb && !e->D) && !use_graph &&
+                            std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   FinArgs dff{};
   e->dfin = nullptr;
   e->dfin_pending = false;
@@ -726,7 +738,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           e->dfin_pending = true;
           return ADMM_OK;
         }
-        if (fuse_tail) {  // z/u update + finalize in one launch
+        if (fuse_tail && defer_fin_ad) {  // A = D without a dual residual: the finalize rides along with the partial
+          launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream, true);  // sums of the next right-hand side, just below
+          dff = prox_fin_args(pa, fa);
+          tp_fin = &dff;
+        } else if (fuse_tail) {  // z/u update + finalize in one launch
           launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream);
           if (e->a_identity) return ADMM_OK;  // the iteration ends here
         } else {

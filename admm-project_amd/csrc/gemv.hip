@@ -9,6 +9,7 @@
 // small vectors are staged: x through the scalar cache (gemv_n), v through LDS (gemv_t).
 // Partial results are written per chunk and summed by the consumer in a fixed order, so
 // results are bitwise reproducible (no float atomics).
+#include "finalize_device.h"
 #include "kernels.h"
 
 namespace admm {
@@ -293,6 +294,44 @@ __global__ __launch_bounds__(kBlock) void sum_partials_t_kernel(const double* __
     for (int k = 1; k < 16; ++k) t += sacc[k][jj];
     g[r * ldg_out + j] = t;
   }
+}
+
+// the same with a passenger: the last workgroup runs the deferred finalize logic of the iteration whose element update
+// has just run (engine_run.hip: defer_fin_ad) next to the partial sums instead of serially inside that update's launch
+__global__ __launch_bounds__(kBlock) void sum_partials_t_fin_kernel(const double* __restrict__ gpart, int32_t nchunk,
+                                                                    int nrhs, int64_t ldg, int64_t n,
+                                                                    double* __restrict__ g, int64_t ldg_out, FinArgs f,
+                                                                    const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  if (blockIdx.x == gridDim.x - 1) {
+    finalize_body<false>(f);
+    return;
+  }
+  __shared__ double sacc[16][17];
+  const int jj = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int64_t tiles_per_rhs = (n + 15) / 16;
+  const int r = static_cast<int>(blockIdx.x / tiles_per_rhs);
+  const int64_t j = (blockIdx.x - static_cast<int64_t>(r) * tiles_per_rhs) * 16 + jj;
+  double s = 0.0;
+  if (j < n) {
+#pragma unroll 4
+    for (int32_t c = slot; c < nchunk; c += 16) s += gpart[(static_cast<int64_t>(c) * nrhs + r) * ldg + j];
+  }
+  sacc[slot][jj] = s;
+  __syncthreads();
+  if (slot == 0 && j < n) {
+    double t = sacc[0][jj];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sacc[k][jj];
+    g[r * ldg_out + j] = t;
+  }
+}
+
+void launch_sum_partials_t_fin(const GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,
+                               const FinArgs& f, const Ctrl* ctrl, hipStream_t stream) {
+  const int64_t blocks = ceil_div(p.n, 16) * nrhs + 1;
+  hipLaunchKernelGGL(sum_partials_t_fin_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, gpart,
+                     p.nchunk, nrhs, p.ldg, p.n, g, ldg_out, f, ctrl);
 }
 
 void launch_sum_partials_t(const GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,

@@ -187,6 +187,10 @@ void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const d
 void launch_symv_lower_fin(const struct SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
                            const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
 
+// g[r][j] = sum_c gpart[c][r][j] (gemv.hip) with the deferred finalize logic in one extra workgroup
+void launch_sum_partials_t_fin(const struct GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,
+                               const FinArgs& f, const Ctrl* ctrl, hipStream_t stream);
+
 // Two-launch iteration of unwrapped ADMM with an explicit pseudo-inverse (unwrapped.hip)
 struct UwArgs {
   const double* D;   // m x n, column-major
