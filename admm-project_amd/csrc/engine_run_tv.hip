@@ -1,5 +1,7 @@
 // engine_run_tv.hip -- the iteration sequences of total variation (totalvariation.m:122-164; fused kernel, the
 // unfused fast / relaxed form) and of its 2-D extension (spectral or CG x-update), split out of admm_engine_run.
+#include <cstdlib>
+
 #include "engine_internal.h"
 
 namespace admm {
@@ -301,10 +303,11 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
     // and the two arrival hops at the end of 8600 tiles cost what the two launches cost.  ADMM_HIP_TV_ONE_LAUNCH=1.
     tv_one_launch = ngroups <= kMaxPartBlocks && std::getenv("ADMM_HIP_TV_ONE_LAUNCH") != nullptr;
     const size_t extra = tv_one_launch ? static_cast<size_t>(S_COUNT) * kMaxPartBlocks + (ngroups + 2) / 2 + 1 : 0;
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * (S_COUNT * ta.part_stride + extra)));
+    // (two sets of tile partials: the deferred tail of iteration i reads its set while iteration i + 1 writes the other)
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * (2 * S_COUNT * ta.part_stride + extra)));
     ta.part = tv_part;
     if (tv_one_launch) {
-      ta.gpart = tv_part + S_COUNT * ta.part_stride;
+      ta.gpart = tv_part + 2 * S_COUNT * ta.part_stride;
       ta.gcount = reinterpret_cast<int32_t*>(ta.gpart + static_cast<size_t>(S_COUNT) * kMaxPartBlocks);
       ta.ngroups = static_cast<int32_t>(ngroups);
       ADMM_HIP_TRY(hipMemsetAsync(ta.gcount, 0, sizeof(int32_t) * (ngroups + 1), e->stream));
@@ -433,6 +436,20 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
     ta.y = e->tv_y;
     launch_tv_sweep(ta, false, e->ctrl, e->stream);
   }
+  // Deferred tail (default for the fused kernel): the tile-partial sums and the finalize logic of iteration i are done by
+  // one extra workgroup of iteration i + 1's launch, hidden behind its tiles; a batch's last iteration gets the two
+  // small launches.  A stop raised by that workgroup makes iteration i + 2 a no-op; iteration i + 1 has run
+  // speculatively into the OTHER ping-pong buffers, and the final z, u, x are picked by the device's step count.
+  const bool tv_deferred = tv_fused && !tv_one_launch && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  // ... and the forward-sweep vector iteration i read must survive iteration i + 1 (the final x is rebuilt from it when
+  // no history holds x): three y buffers in rotation instead of two
+  double* tv_y3 = nullptr;
+  if (tv_deferred) ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_y3), sizeof(double) * round_up(e->n, 2)));
+  DevFree tv_y3_guard{tv_y3};
+  double* const ybuf[3] = {e->tv_y, e->tv_y2, tv_y3};
+  const int64_t tv_ntiles = tv_fused ? ceil_div(e->n, ta.ftile) : 0;
+  const int64_t tv_pset = static_cast<int64_t>(S_COUNT) * ta.part_stride;
+  bool tv_pending = false;
   while (done < N && !stop_seen) {
     const int32_t batch = (N - done < check_tv) ? N - done : check_tv;
     for (int32_t b = 0; b < batch; ++b) {
@@ -447,6 +464,22 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
         ta.yin = a_cur ? e->tv_y : e->tv_y2;
         ta.yout = a_cur ? e->tv_y2 : e->tv_y;
         fa.nblk = nblk;
+        if (tv_deferred) {
+          const int64_t k = done + b;
+          ta.yin = ybuf[k % 3];
+          ta.yout = ybuf[(k + 1) % 3];
+          ta.deferred = 1;
+          ta.iter_host = k;
+          ta.part = tv_part + (k & 1) * tv_pset;
+          ta.prev_part = tv_part + ((k + 1) & 1) * tv_pset;
+          ta.prev_ntiles = static_cast<int32_t>(tv_ntiles);
+          ta.slots16 = e->red;
+          ta.fin_pending = tv_pending ? 1 : 0;
+          fa.slots_reduced = e->red;
+          launch_tv_fused(ta, fa, e->red, e->ctrl, e->stream);
+          tv_pending = true;
+          continue;
+        }
         launch_tv_fused(ta, fa, e->red, e->ctrl, e->stream);
         if (tv_one_launch) continue;  // the launch ended the iteration itself
         fa.slots_reduced = e->red;
@@ -466,6 +499,14 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
       }
     }
     done += batch;
+    if (tv_deferred && tv_pending) {  // the batch's last iteration: its tail as two small launches
+      launch_tv_pack(tv_part + ((done - 1) & 1) * tv_pset, ta.part_stride, static_cast<int32_t>(tv_ntiles), e->red, e->ctrl,
+                     e->stream);
+      fa.slots_reduced = e->red;
+      fa.nblk = 1;
+      launch_finalize(fa, e->stream);
+      tv_pending = false;
+    }
     {  // poll after every batch (see engine_run.hip)
       ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
@@ -480,11 +521,14 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   }
   if (e->profiling) collect_timers(e);
   const int32_t steps = e->ctrl_host->steps;
+  if (tv_deferred && !ta.skip_x && e->xhist && steps > 0)  // x was overwritten by the speculative iteration after a stop
+    ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->xhist + static_cast<int64_t>(steps - 1) * e->n, sizeof(double) * e->n,
+                                hipMemcpyDeviceToDevice, e->stream));
   // iterations executed on the device decide which ping-pong buffer holds the final z, u
   e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
   e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
   if (ta.skip_x && steps > 0) {
-    ta.y = ((steps - 1) & 1) ? e->tv_y2 : e->tv_y;
+    ta.y = tv_deferred ? ybuf[(steps - 1) % 3] : (((steps - 1) & 1) ? e->tv_y2 : e->tv_y);
     launch_tv_sweep(ta, true, e->ctrl_idle, e->stream);  // the loop's own flag says "stopped" by now
     ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   }

@@ -39,6 +39,15 @@ struct TvArgs {
   int32_t* gcount;         // [ngroups + 1] arrival counters (zero between launches); null = two extra launches instead
   double* gpart;
   int32_t ngroups;
+  // deferred tail (default): the tile partials of iteration i are summed and its finalize logic run by ONE extra
+  // workgroup of iteration i + 1's launch (~40 us of serial work hidden behind 220 us of tiles); the tile partials are
+  // double-buffered, the iteration index comes from the host (the passenger advances ctrl->iter during the launch)
+  int32_t deferred;        // 1: grid = tiles + 1, `it` = iter_host
+  int32_t fin_pending;     // the passenger has an iteration to finalize
+  int64_t iter_host;
+  const double* prev_part; // tile partials of the previous iteration, [S_COUNT][part_stride]
+  int32_t prev_ntiles;
+  double* slots16;         // where the passenger leaves the 16 sums for finalize_body (FinArgs::slots_reduced)
 };
 constexpr int kTvGroup = 64;
 
@@ -62,5 +71,8 @@ bool tv_fused_ok(const TvArgs& a);
 // slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced); with a.gcount set the
 // launch ends the iteration itself (fin = the finalize arguments) and slots16 is unused
 void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const Ctrl* ctrl, hipStream_t stream);
+// slots16[s] = sum over the tiles of part[s][.] (the stand-alone form of the deferred tail's first half)
+void launch_tv_pack(const double* part, int64_t stride, int32_t ntiles, double* slots16, const Ctrl* ctrl,
+                    hipStream_t stream);
 
 }  // namespace admm

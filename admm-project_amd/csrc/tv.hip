@@ -345,7 +345,36 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
   __shared__ double wA[4], wB[4];
   __shared__ double sred[4][S_COUNT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int64_t n = a.n, it = ctrl->iter;
+  if (a.deferred && blockIdx.x == 0) {  // the passenger (dispatched first): tail of the PREVIOUS iteration
+    if (!a.fin_pending) return;
+    {  // all slots at once: 16 lanes per slot stride over the tiles, 16 loads in flight per lane; fixed order
+      const int slot = tid >> 4, sub = tid & 15;
+      double v = 0.0;
+      if (slot < S_COUNT) {
+        const double* __restrict__ ps = a.prev_part + slot * a.part_stride;
+        for (int32_t b0 = 0; b0 < a.prev_ntiles; b0 += 256) {
+          double w[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int32_t b = b0 + sub + 16 * k;
+            w[k] = ps[b < a.prev_ntiles ? b : a.prev_ntiles - 1];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (b0 + sub + 16 * k < a.prev_ntiles) v += w[k];
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (slot < S_COUNT && sub == 0) a.slots16[slot] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    finalize_body<false>(fin);  // fin.slots_reduced = a.slots16
+    return;
+  }
+  const unsigned tile_id = a.deferred ? blockIdx.x - 1u : blockIdx.x;
+  const int64_t n = a.n, it = a.deferred ? a.iter_host : ctrl->iter;
   const double rho = a.rho;
   const double cstar = rho / a.bstar, ibstar = 1.0 / a.bstar;
   double acc[S_COUNT];
@@ -353,7 +382,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
 
   {
-    const int64_t o0 = static_cast<int64_t>(blockIdx.x) * a.ftile;
+    const int64_t o0 = static_cast<int64_t>(tile_id) * a.ftile;
     const int64_t o1 = (o0 + a.ftile < n) ? o0 + a.ftile : n;
     const int64_t w0 = (o0 - a.halo - 2 > 0) ? o0 - a.halo - 2 : 0;          // even
     const int64_t w1 = (o1 + a.halo + 2 < n) ? o1 + a.halo + 2 : n;
@@ -514,7 +543,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
       const int s = threadIdx.x;
       const double t = ((sred[0][s] + sred[1][s]) + sred[2][s]) + sred[3][s];
       if (a.gcount) __hip_atomic_store(a.part + s * a.part_stride + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else a.part[s * a.part_stride + blockIdx.x] = t;
+      else a.part[s * a.part_stride + tile_id] = t;
     }
     // ---- 3. forward scan of the next iteration's right-hand side, owned store
     tv_block_scan<E>(L2, fcount, [&](int q) { return tv_coef<false>(a, f0 + q, n, rho, cstar); }, wA, wB);
@@ -702,7 +731,7 @@ void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const
   int mode = nts ? 1 : 0;
   if (nts)
     if (const char* env = getenv("ADMM_HIP_TV_CACHE")) mode = atoi(env);
-  const dim3 grid(static_cast<unsigned>(ntiles)), block(kBlock);
+  const dim3 grid(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block(kBlock);
   switch (mode) {
     case 0: hipLaunchKernelGGL((tv_fused_kernel<8, 0>), grid, block, lds, stream, a, f, ctrl); break;
     case 2: hipLaunchKernelGGL((tv_fused_kernel<8, 2>), grid, block, lds, stream, a, f, ctrl); break;
@@ -710,9 +739,14 @@ void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const
     case 4: hipLaunchKernelGGL((tv_fused_kernel<8, 4>), grid, block, lds, stream, a, f, ctrl); break;
     default: hipLaunchKernelGGL((tv_fused_kernel<8, 1>), grid, block, lds, stream, a, f, ctrl); break;
   }
-  if (a.gcount) return;
+  if (a.gcount || a.deferred) return;
   hipLaunchKernelGGL(tv_pack_kernel, dim3(S_COUNT), dim3(kBlock), 0, stream, a.part, a.part_stride,
                      static_cast<int32_t>(ntiles), slots16, ctrl);
+}
+
+void launch_tv_pack(const double* part, int64_t stride, int32_t ntiles, double* slots16, const Ctrl* ctrl,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(tv_pack_kernel, dim3(S_COUNT), dim3(kBlock), 0, stream, part, stride, ntiles, slots16, ctrl);
 }
 
 // ---- host side -------------------------------------------------------------------------

@@ -709,3 +709,27 @@ def test_lasso_objective_switches_to_the_gram_form_after_calibration(gpu):
         assert small.run(**run).obj_gram_used == 0  # cheap literal pass: G is not even kept
     finally:
         auto.close(), lit.close(), small.close()
+
+
+@pytest.mark.parametrize("opts", [dict(objevals=1), dict(record_history=0), dict(record_history=0, maxiters=11, domaxiters=1),
+                                  dict(stopcond="both", convtest=1, maxiters=90), dict(rho=3.0, objevals=1, maxiters=37)])
+@pytest.mark.parametrize("n", [4099, 50000])
+def test_total_variation_deferred_tail_matches_the_two_small_launches(gpu, monkeypatch, n, opts):
+    """1-D TV, fused kernel: the tile-partial sums and the finalize logic of iteration i ride along with iteration i + 1's
+    launch (one extra workgroup); the iteration after a stop has then run speculatively into the other ping-pong buffers
+    (three y buffers in rotation), and z, u, x are still those of the stopping iteration -- bitwise the results of the
+    form with two small launches per iteration, and the oracle's."""
+    p = gpu.synth.tv_problem(3, n)
+    got = gpu.totalvariation(p["s"], p["lam"], dict(opts))
+    monkeypatch.setenv("ADMM_HIP_NO_DEFERRED_FINALIZE", "1")
+    two = gpu.totalvariation(p["s"], p["lam"], dict(opts))
+    monkeypatch.delenv("ADMM_HIP_NO_DEFERRED_FINALIZE")
+    assert got["steps"] == two["steps"]
+    for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr", "xvals", "zvals", "uvals", "objevals"):
+        assert (k in got) == (k in two), k
+        if k in got:
+            assert np.array_equal(got[k], two[k]), k
+    ref = S.totalvariation(p["s"], p["lam"], {k: v for k, v in opts.items() if k != "record_history"})
+    assert got["steps"] == ref["steps"]
+    _close("xopt", got["xopt"], ref["xopt"], 1e-7)
+    _close("zopt", got["zopt"], ref["zopt"], 1e-7)
