@@ -310,8 +310,10 @@ static int decide_sy_split(admm_engine* e) {
   ADMM_HIP_TRY(hipMemcpyAsync(&lat_us, probe, sizeof(double), hipMemcpyDeviceToHost, e->stream));
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   lat_us /= nr;
-  const double t_us = 4.0 * static_cast<double>(f.planSy.npad) * static_cast<double>(f.planSy.npad) / 5.5e6;
-  e->sy_split = t_us * (1.0 - 1.0 / nr) > 1.15 * lat_us;
+  // (6.4e6 bytes/us: the packed kernel with the split cache policy; the unsplit path also keeps the deferred finalize
+  // and needs no reduce launch for its partial rows: ~8 us the split has to win back on top of the collective)
+  const double t_us = 4.0 * static_cast<double>(f.planSy.npad) * static_cast<double>(f.planSy.npad) / 6.4e6;
+  e->sy_split = t_us * (1.0 - 1.0 / nr) > 1.15 * lat_us + 8.0;
   if (const char* fl = std::getenv("ADMM_HIP_XSPLIT")) e->sy_split = fl[0] == '1';  // tests force either form
   // the probe (and the latency measurement) left partial sums behind; with the tiles split over ranks the slots
   // of foreign tiles are never written again and must read as zero

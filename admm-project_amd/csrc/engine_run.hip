@@ -638,7 +638,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   const bool obj_kernels = o.objevals && (obj_lasso_gemv || obj_qp_gemv || obj_model_gemv || e->ocb);
   // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
   // without it the finalize logic needs none of the D' products that follow the prox kernel
-  const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && !sharded && !obj_kernels &&
+  // (row-sharded A = I engines keep x, z, u replicated and exchange nothing per iteration unless the x-solve's tiles
+  // are split over the ranks -- symv_apply's one all-reduce, before this tail: they run the same tail as one rank)
+  const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && (!sharded || e->a_identity) &&
+                         !obj_kernels &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   // With the packed lower-triangle x-solve in front of it, the finalize logic of an A = I iteration is deferred: the
   // element update stores its block partials and ends; the next iteration's x-solve carries the finalize in one extra
