@@ -289,8 +289,18 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   ta.zhist = e->zhist;
   ta.uhist = e->uhist;
   ta.part = e->part;
-  // one fused launch per iteration (8 vector passes) when the halo is small; the three-kernel form otherwise
+  // one fused launch per iteration when the halo is small; the three-kernel form otherwise.  Default fused form: the
+  // direct kernel (no y vector, 5 vector passes, tv.hip: tv_direct_kernel); ADMM_HIP_TV_SCAN=1 keeps the 7-pass form
+  // whose sweeps are split over two launches
   const bool tv_fused = tv_fused_ok(ta) && std::getenv("ADMM_HIP_TV_UNFUSED") == nullptr;
+  const bool tv_direct = tv_fused && tv_direct_ok(ta) && std::getenv("ADMM_HIP_TV_SCAN") == nullptr &&
+                         std::getenv("ADMM_HIP_TV_ONE_LAUNCH") == nullptr && alg == 0 && o.relax == 1.0;
+  if (tv_direct) {
+    ta.margin = tv_direct_margin(ta);
+    ta.ftile = 256 * elems - 2 * ta.margin;
+    const double rr = o.rho / bstar;
+    ta.green = 1.0 / (bstar * (1.0 - rr * rr));
+  }
   double* tv_part = nullptr;  // per-tile partials of the fused kernel (one column per tile)
   bool tv_one_launch = false;
   if (tv_fused) {
@@ -429,7 +439,8 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   // rebuilds the final x from the forward-sweep vector the last executed iteration read (still intact: every
   // launch after the stop flag is a no-op, and an iteration writes the OTHER y buffer)
   ta.skip_x = (tv_fused && !e->xhist) ? 1 : 0;
-  if (tv_fused) {  // the forward sweep of iteration 0; every later one is produced by the fused kernel
+  if (tv_direct) ta.skip_x = 0;  // (x leaves the direct kernel only as a history column)
+  if (tv_fused && !tv_direct) {  // the forward sweep of iteration 0; every later one is produced by the fused kernel
     TimerScope ts(e, ADMM_K_XSOLVE);
     ta.z = e->tv_zA;
     ta.u = e->tv_uA;
@@ -442,11 +453,19 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   // speculatively into the OTHER ping-pong buffers, and the final z, u, x are picked by the device's step count.
   const bool tv_deferred = tv_fused && !tv_one_launch && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   // ... and the forward-sweep vector iteration i read must survive iteration i + 1 (the final x is rebuilt from it when
-  // no history holds x): three y buffers in rotation instead of two
-  double* tv_y3 = nullptr;
-  if (tv_deferred) ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_y3), sizeof(double) * round_up(e->n, 2)));
-  DevFree tv_y3_guard{tv_y3};
+  // no history holds x): three y buffers in rotation instead of two.  The direct kernel has no y: there z and u rotate
+  // through three buffers, and the final x is recomputed from the z, u the last executed iteration read.
+  double *tv_y3 = nullptr, *tv_z3 = nullptr, *tv_u3 = nullptr;
+  if (tv_deferred && !tv_direct)
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_y3), sizeof(double) * round_up(e->n, 2)));
+  if (tv_direct) {
+    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_z3), sizeof(double) * 2 * round_up(e->n, 2)));
+    tv_u3 = tv_z3 + round_up(e->n, 2);
+  }
+  DevFree tv_y3_guard{tv_y3}, tv_z3_guard{tv_z3};
   double* const ybuf[3] = {e->tv_y, e->tv_y2, tv_y3};
+  double* const zbuf[3] = {e->tv_zA, e->tv_zB, tv_z3};
+  double* const ubuf[3] = {e->tv_uA, e->tv_uB, tv_u3};
   const int64_t tv_ntiles = tv_fused ? ceil_div(e->n, ta.ftile) : 0;
   const int64_t tv_pset = static_cast<int64_t>(S_COUNT) * ta.part_stride;
   bool tv_pending = false;
@@ -464,7 +483,27 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
         ta.yin = a_cur ? e->tv_y : e->tv_y2;
         ta.yout = a_cur ? e->tv_y2 : e->tv_y;
         fa.nblk = nblk;
-        if (tv_deferred) {
+        if (tv_direct) {
+          const int64_t k = done + b;
+          ta.z = zbuf[k % 3];
+          ta.u = ubuf[k % 3];
+          ta.zo = zbuf[(k + 1) % 3];
+          ta.uo = ubuf[(k + 1) % 3];
+          ta.deferred = tv_deferred ? 1 : 0;
+          ta.iter_host = k;
+          ta.part = tv_part + (k & 1) * tv_pset;
+          ta.prev_part = tv_part + ((k + 1) & 1) * tv_pset;
+          ta.prev_ntiles = static_cast<int32_t>(tv_ntiles);
+          ta.slots16 = e->red;
+          ta.fin_pending = tv_pending ? 1 : 0;
+          fa.slots_reduced = e->red;
+          launch_tv_direct(ta, fa, e->ctrl, e->stream);
+          if (tv_deferred) {
+            tv_pending = true;
+            continue;
+          }
+          launch_tv_pack(ta.part, ta.part_stride, static_cast<int32_t>(tv_ntiles), e->red, e->ctrl, e->stream);
+        } else if (tv_deferred) {
           const int64_t k = done + b;
           ta.yin = ybuf[k % 3];
           ta.yout = ybuf[(k + 1) % 3];
@@ -480,7 +519,7 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
           tv_pending = true;
           continue;
         }
-        launch_tv_fused(ta, fa, e->red, e->ctrl, e->stream);
+        if (!tv_direct) launch_tv_fused(ta, fa, e->red, e->ctrl, e->stream);
         if (tv_one_launch) continue;  // the launch ended the iteration itself
         fa.slots_reduced = e->red;
       } else {
@@ -521,12 +560,36 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   }
   if (e->profiling) collect_timers(e);
   const int32_t steps = e->ctrl_host->steps;
-  if (tv_deferred && !ta.skip_x && e->xhist && steps > 0)  // x was overwritten by the speculative iteration after a stop
+  if (tv_deferred && !tv_direct && !ta.skip_x && e->xhist && steps > 0)  // x was overwritten by the speculative iteration after a stop
     ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->xhist + static_cast<int64_t>(steps - 1) * e->n, sizeof(double) * e->n,
                                 hipMemcpyDeviceToDevice, e->stream));
   // iterations executed on the device decide which ping-pong buffer holds the final z, u
   e->z = (steps & 1) ? e->tv_zB : e->tv_zA;
   e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
+  if (tv_direct) {
+    if (!e->xhist && steps > 0) {  // x of the last executed iteration, from the z, u it read: two stand-alone sweeps
+      ta.z = zbuf[(steps - 1) % 3];
+      ta.u = ubuf[(steps - 1) % 3];
+      ta.y = e->tv_y;
+      ta.x = e->x;
+      ta.xhist = nullptr;
+      launch_tv_sweep(ta, false, e->ctrl_idle, e->stream);  // the loop's own flag says "stopped" by now
+      launch_tv_sweep(ta, true, e->ctrl_idle, e->stream);
+    } else if (e->xhist && steps > 0) {
+      ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->xhist + static_cast<int64_t>(steps - 1) * e->n, sizeof(double) * e->n,
+                                  hipMemcpyDeviceToDevice, e->stream));
+    }
+    double *zf = zbuf[steps % 3], *uf = ubuf[steps % 3];
+    if (zf == tv_z3) {  // the third buffer is this run's own: the results move into buffer A
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, zf, sizeof(double) * e->n, hipMemcpyDeviceToDevice, e->stream));
+      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, uf, sizeof(double) * e->n, hipMemcpyDeviceToDevice, e->stream));
+      zf = e->tv_zA;
+      uf = e->tv_uA;
+    }
+    e->z = zf;
+    e->u = uf;
+    ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   if (ta.skip_x && steps > 0) {
     ta.y = tv_deferred ? ybuf[(steps - 1) % 3] : (((steps - 1) & 1) ? e->tv_y2 : e->tv_y);
     launch_tv_sweep(ta, true, e->ctrl_idle, e->stream);  // the loop's own flag says "stopped" by now

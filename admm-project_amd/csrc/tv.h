@@ -48,6 +48,9 @@ struct TvArgs {
   const double* prev_part; // tile partials of the previous iteration, [S_COUNT][part_stride]
   int32_t prev_ntiles;
   double* slots16;         // where the passenger leaves the 16 sums for finalize_body (FinArgs::slots_reduced)
+  // direct form (tv_direct_kernel): window margin (multiple of 8, >= halo + 8) and the Green's-function scale
+  int32_t margin;
+  double green;            // A = 1/(b*(1 - r^2)), r = rho/b*
 };
 constexpr int kTvGroup = 64;
 
@@ -71,6 +74,10 @@ bool tv_fused_ok(const TvArgs& a);
 // slots16 receives the 16 reduction slots summed over all tiles (FinArgs::slots_reduced); with a.gcount set the
 // launch ends the iteration itself (fin = the finalize arguments) and slots16 is unused
 void launch_tv_fused(const TvArgs& a, const FinArgs& fin, double* slots16, const Ctrl* ctrl, hipStream_t stream);
+// One launch per iteration without the y vector: 5 vector passes (tv.hip: tv_direct_kernel).  a.ftile = 2048 - 2*margin.
+int tv_direct_margin(const TvArgs& a);
+bool tv_direct_ok(const TvArgs& a);
+void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hipStream_t stream);
 // slots16[s] = sum over the tiles of part[s][.] (the stand-alone form of the deferred tail's first half)
 void launch_tv_pack(const double* part, int64_t stride, int32_t ntiles, double* slots16, const Ctrl* ctrl,
                     hipStream_t stream);

@@ -617,6 +617,278 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
   finalize_body<true>(fin);  // fin.part = gpart, fin.nblk = ngroups
 }
 
+// ---------------------------------------------------------------- one launch per iteration WITHOUT the y vector
+// tv_fused_kernel splits the tridiagonal solve over two launches (this iteration's backward sweep, the next one's
+// forward sweep) and pays for it with the y vector's round trip (7 vector passes) and two block-wide scans per tile --
+// a chain of barriers and shuffle steps that keeps a tile resident for ~26 us while it issues loads in two of its eight
+// phases: 4.3 TB/s.  Here a tile solves (I + rho*D'D) x = s + rho*D'(z - u) directly from z, u, s (5 passes: reads
+// s, z, u; writes z, u):
+//   * away from the two ends the matrix is Toeplitz, tridiag(-rho, 1+2rho, -rho), and its inverse is the two-sided
+//     exponential kernel  x_i = A * sum_k r^|k| b_(i+k),  r = rho/b* (the stationary multiplier of the sweeps),
+//     A = 1/(b*(1 - r^2)); |k| <= K = the sweeps' halo leaves a truncation below 1e-18.  A thread owns 8 consecutive
+//     positions: one K-term Horner sum on each side, then the two first-order recurrences across its 8 positions --
+//     ~2K + 30 FMAs and as many LDS reads per thread, no barrier, no cross-lane traffic;
+//   * the first and the last tile (where the boundary rows reflect) run the exact recurrences as two block scans
+//     inside the tile, from the true boundary on one side and with the usual warm-up margin on the other.
+// The z/u update, the residual sums, the histories and the deferred tail are those of tv_fused_kernel.  The final x
+// (no y to rebuild it from) is recomputed after the loop from the z, u the last executed iteration read: z and u
+// rotate through THREE buffers so that the speculative iteration behind a stop does not overwrite them.
+template <bool NTS>
+__global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  constexpr int E = 8;
+  constexpr int kCap = E * kBlock;
+  constexpr int kArr = kCap + (kCap >> 3) + 1;  // pos8(q) = q + (q >> 3): conflict-free for 8-strided positions
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* __restrict__ Bq = lds;         // right-hand side b (forward positions)
+  double* __restrict__ Xq = lds + kArr;  // x (forward positions; scan tiles: backward positions)
+  __shared__ double wA[4], wB[4];
+  __shared__ double sred[4][S_COUNT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (a.deferred && blockIdx.x == 0) {  // the passenger (dispatched first): tail of the PREVIOUS iteration
+    if (!a.fin_pending) return;
+    {
+      const int slot = tid >> 4, sub = tid & 15;
+      double v = 0.0;
+      if (slot < S_COUNT) {
+        const double* __restrict__ ps = a.prev_part + slot * a.part_stride;
+        for (int32_t b0 = 0; b0 < a.prev_ntiles; b0 += 256) {
+          double w[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int32_t b = b0 + sub + 16 * k;
+            w[k] = ps[b < a.prev_ntiles ? b : a.prev_ntiles - 1];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (b0 + sub + 16 * k < a.prev_ntiles) v += w[k];
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (slot < S_COUNT && sub == 0) a.slots16[slot] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    finalize_body<false>(fin);  // fin.slots_reduced = a.slots16
+    return;
+  }
+  const unsigned tile_id = a.deferred ? blockIdx.x - 1u : blockIdx.x;
+  const int64_t n = a.n, it = a.deferred ? a.iter_host : ctrl->iter;
+  const double rho = a.rho;
+  const double r = rho / a.bstar, ibstar = 1.0 / a.bstar;
+  const int K = a.halo, M = a.margin;
+  const int64_t o0 = static_cast<int64_t>(tile_id) * a.ftile;
+  const int64_t o1 = (o0 + a.ftile < n) ? o0 + a.ftile : n;
+  const int64_t w0 = (o0 - M > 0) ? o0 - M : 0;  // even (ftile and M are multiples of 8)
+  const int64_t w1 = (o1 + M < n) ? o1 + M : n;
+  const int count = static_cast<int>(w1 - w0);
+  // the Toeplitz kernel is exact to 1e-18 where neither end of the matrix is within K of a needed x
+  const bool direct = (o0 - 1 >= K) && (o1 + 1 + K <= n) && (o0 - M >= 0) && (o1 + M <= n);
+  auto pos8 = [](int q) -> int { return q + (q >> 3); };
+  auto pos16 = [](int q) -> int { return q + (q >> 4); };
+
+  // ---- 1. z, u, s of the window (kept in registers for step 3); b = s + rho*D'(z - u) into LDS
+  admm_double2 zr[E / 2], ur[E / 2], sr[E / 2];
+#pragma unroll
+  for (int k = 0; k < E / 2; ++k) {
+    const int j = tid + k * kBlock;
+    const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+    const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+    admm_double2 zz{0.0, 0.0}, uu{0.0, 0.0}, ss{0.0, 0.0};
+    if (live1) {
+      zz = load2<true>(a.z + i0);
+      uu = load2<true>(a.u + i0);
+      ss = load2<true>(a.s + i0);
+    } else if (live0) {
+      zz.x = a.z[i0];
+      uu.x = a.u[i0];
+      ss.x = a.s[i0];
+    }
+    zr[k] = zz;
+    ur[k] = uu;
+    sr[k] = ss;
+    const double t0 = zz.x - uu.x, t1 = zz.y - uu.y;
+    double tm = __shfl_up(t1, 1, 64);  // element i0-1 is the previous lane's second element
+    if (lane == 0 && live0 && i0 > 0) tm = a.z[i0 - 1] - a.u[i0 - 1];
+    const double b0 = ss.x + rho * ((i0 > 0) ? t0 - tm : t0);  // getProxOps.m:1047
+    const double b1 = ss.y + rho * (t1 - t0);
+    if (live0) Bq[direct ? pos8(2 * j) : pos16(2 * j)] = b0;
+    if (live1) Bq[direct ? pos8(2 * j + 1) : pos16(2 * j + 1)] = b1;
+  }
+  __syncthreads();
+
+  if (direct) {
+    // ---- 2a. x = A * (causal + anticausal exponential sums) for this thread's 8 consecutive positions
+    const int p0 = tid * E;
+    if (p0 >= M - E && p0 + E <= count - M + E) {  // covers every x the update below needs: [M - 1, count - M + 1)
+      double c = Bq[pos8(p0 - K)];
+#pragma unroll 4
+      for (int k = K - 1; k >= 0; --k) c = __builtin_fma(r, c, Bq[pos8(p0 - k)]);
+      double ac = Bq[pos8(p0 + E - 1 + K)];
+#pragma unroll 4
+      for (int k = K - 1; k >= 1; --k) ac = __builtin_fma(r, ac, Bq[pos8(p0 + E - 1 + k)]);
+      ac *= r;
+      double bv[E], cv[E], av[E];
+#pragma unroll
+      for (int j = 0; j < E; ++j) bv[j] = Bq[pos8(p0 + j)];
+      cv[0] = c;
+#pragma unroll
+      for (int j = 1; j < E; ++j) cv[j] = __builtin_fma(r, cv[j - 1], bv[j]);
+      av[E - 1] = ac;
+#pragma unroll
+      for (int j = E - 1; j >= 1; --j) av[j - 1] = r * (av[j] + bv[j]);
+      const double A = a.green;
+#pragma unroll
+      for (int j = 0; j < E; ++j) Xq[pos8(p0 + j)] = A * (cv[j] + av[j]);
+    }
+    __syncthreads();
+  } else {
+    // ---- 2b. a tile at an end of the matrix: the exact recurrences as two block scans (forward in place, then
+    // y/b in backward order into Xq, backward in place)
+    const double cstar = r;
+    tv_block_scan<E>(Bq, count, [&](int q) { return tv_coef<false>(a, w0 + q, n, rho, cstar); }, wA, wB);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int q = tid + k * kBlock;  // forward position
+      if (q < count) {
+        const int64_t i = w0 + q;
+        const int qq = count - 1 - q;
+        Xq[pos16(qq)] = Bq[pos16(q)] * ((i < a.nprefix) ? 1.0 / a.bprefix[i] : ibstar);
+      }
+    }
+    __syncthreads();
+    tv_block_scan<E>(Xq, count, [&](int q) { return tv_coef<true>(a, w1 - 1 - q, n, rho, cstar); }, wA, wB);
+  }
+  auto xat = [&](int64_t i) -> double {
+    const int q = static_cast<int>(i - w0);
+    return direct ? Xq[pos8(q)] : Xq[pos16(count - 1 - q)];
+  };
+
+  // ---- 3. z/u update (pairs, ascending), owned outputs, residual sums
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+#pragma unroll
+  for (int k = 0; k < E / 2; ++k) {
+    const int j = tid + k * kBlock;
+    const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+    const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+    double zn0 = 0.0, zn1 = 0.0, un0 = 0.0, un1 = 0.0, dz0 = 0.0, dz1 = 0.0;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0, ax0 = 0.0, ax1 = 0.0;
+    const double zp0 = zr[k].x, zp1 = zr[k].y, uo0 = ur[k].x, uo1 = ur[k].y, s0 = sr[k].x, s1 = sr[k].y;
+    if (live0) {
+      x0 = xat(i0);
+      if (live1) x1 = xat(i0 + 1);
+      if (i0 + 2 < w1) x2 = xat(i0 + 2);
+      ax0 = (i0 + 1 < n) ? x0 - x1 : x0;   // D*x, last row is x_n (totalvariation.m:127)
+      zn0 = tv_soft(uo0 + ax0, a.thresh);  // getProxOps.m:199
+      un0 = uo0 + (ax0 + (-zn0));          // admm.m:548 (c = 0)
+      dz0 = zn0 - zp0;
+      if (live1) {
+        ax1 = (i0 + 2 < n) ? x1 - x2 : x1;
+        zn1 = tv_soft(uo1 + ax1, a.thresh);
+        un1 = uo1 + (ax1 + (-zn1));
+        dz1 = zn1 - zp1;
+      }
+    }
+    // the left neighbour (element i0-1) is the previous lane's second element
+    double unm = __shfl_up(un1, 1, 64), dzm = __shfl_up(dz1, 1, 64);
+    if (lane == 0 && live0 && i0 > w0) {  // wave boundary: recompute element i0-1
+      const double xm = xat(i0 - 1);
+      const double zpm = a.z[i0 - 1], uom = a.u[i0 - 1];
+      const double axm = xm - x0;
+      const double znm = tv_soft(uom + axm, a.thresh);
+      unm = uom + (axm + (-znm));
+      dzm = znm - zpm;
+    }
+    const bool left = i0 > 0;  // i0 == w0 > 0 is never an owned position (window margin)
+    if (live0) {
+      const bool own0 = i0 >= o0 && i0 < o1, own1 = live1 && i0 + 1 >= o0 && i0 + 1 < o1;
+      if (own0) {
+        const double rr = ax0 + (-zn0), du = un0 - uo0;
+        const double g2 = left ? dz0 - dzm : dz0, g3 = left ? un0 - unm : un0;
+        acc[S_R2] += rr * rr;
+        acc[S_AX2] += ax0 * ax0;
+        acc[S_Z2] += zn0 * zn0;
+        acc[S_DZ2] += dz0 * dz0;
+        acc[S_U2] += un0 * un0;
+        acc[S_DU2] += du * du;
+        acc[S_G2] += g2 * g2;
+        acc[S_G3] += g3 * g3;
+        if (a.objevals) {  // totalvariation.m:134-135
+          if (i0 + 1 < n) acc[S_OBJZ] += fabs(x1 - x0);
+          const double e = x0 - s0;
+          acc[S_OBJX] += e * e;
+        }
+      }
+      if (own1) {
+        const double rr = ax1 + (-zn1), du = un1 - uo1;
+        const double g2 = dz1 - dz0, g3 = un1 - un0;
+        acc[S_R2] += rr * rr;
+        acc[S_AX2] += ax1 * ax1;
+        acc[S_Z2] += zn1 * zn1;
+        acc[S_DZ2] += dz1 * dz1;
+        acc[S_U2] += un1 * un1;
+        acc[S_DU2] += du * du;
+        acc[S_G2] += g2 * g2;
+        acc[S_G3] += g3 * g3;
+        if (a.objevals) {
+          if (i0 + 2 < n) acc[S_OBJZ] += fabs(x2 - x1);
+          const double e = x1 - s1;
+          acc[S_OBJX] += e * e;
+        }
+      }
+      if (own0 && own1) {
+        store2<NTS>(a.zo + i0, admm_double2{zn0, zn1});
+        store2<NTS>(a.uo + i0, admm_double2{un0, un1});
+      } else {
+        if (own0) {
+          a.zo[i0] = zn0;
+          a.uo[i0] = un0;
+        }
+        if (own1) {
+          a.zo[i0 + 1] = zn1;
+          a.uo[i0 + 1] = un1;
+        }
+      }
+      if (a.xhist) {  // history columns start at it*n (odd-aligned for odd n): scalar stores
+        if (own0) {
+          a.xhist[it * n + i0] = x0;
+          a.zhist[it * n + i0] = zn0;
+          a.uhist[it * n + i0] = un0;
+        }
+        if (own1) {
+          a.xhist[it * n + i0 + 1] = x1;
+          a.zhist[it * n + i0 + 1] = zn1;
+          a.uhist[it * n + i0 + 1] = un1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (tid < S_COUNT)
+    a.part[tid * a.part_stride + tile_id] = ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
+}
+
+int tv_direct_margin(const TvArgs& a) { return static_cast<int>(round_up(static_cast<int64_t>(a.halo) + 8, 8)); }
+bool tv_direct_ok(const TvArgs& a) { return a.elems == 8 && a.halo >= 2 && tv_direct_margin(a) <= 256; }
+
+// a.ftile = 2048 - 2*a.margin, a.green = 1/(b*(1 - r^2)); grid = tiles (+ 1 passenger when a.deferred)
+void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hipStream_t stream) {
+  const int64_t ntiles = ceil_div(a.n, a.ftile);
+  constexpr int kCap = 8 * kBlock;
+  const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> 3) + 1) * sizeof(double);
+  const dim3 grid(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block(kBlock);
+  if (stream_hint(8 * 8 * a.n)) hipLaunchKernelGGL((tv_direct_kernel<true>), grid, block, lds, stream, a, fin, ctrl);
+  else hipLaunchKernelGGL((tv_direct_kernel<false>), grid, block, lds, stream, a, fin, ctrl);
+}
+
 // out16[s] = sum over the tiles of part[s][.], one workgroup per slot, fixed order
 __global__ __launch_bounds__(kBlock) void tv_pack_kernel(const double* __restrict__ part, int64_t stride, int32_t nblk,
                                                          double* __restrict__ out16, const Ctrl* __restrict__ ctrl) {
