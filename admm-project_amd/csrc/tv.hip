@@ -13,6 +13,15 @@
 // positions away by less than 1e-18 relative: each workgroup warms up on an H-element halo
 // instead of waiting for its predecessor -- no inter-workgroup communication, pure streaming.
 // The D / D' stencils and the rhs assembly are fused into the sweeps and the prox kernel.
+//
+// Three forms of an iteration, chosen by engine_run_tv.hip:
+//   tv_direct_kernel   (default, small halo)  one launch, 5 vector passes: away from the two ends of the matrix the
+//                      solve is the truncated two-sided exponential kernel of the Toeplitz operator, evaluated per
+//                      thread from LDS without scans; only the two end tiles run the recurrences (as block scans)
+//   tv_fused_kernel    one launch, 7 passes: this iteration's backward sweep + z/u update + the NEXT iteration's
+//                      forward sweep, the intermediate y travelling between launches (ADMM_HIP_TV_SCAN=1)
+//   tv_sweep x 2 + tv_prox   three launches (large halos: rho >~ 16), and the building blocks of the fast /
+//                      accelerated / relaxed variants (tv_dx, tv_dual, tv_relax_z around the generic prox kernel)
 #include <cstdlib>
 
 #include "kernels.h"
