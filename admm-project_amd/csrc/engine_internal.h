@@ -195,7 +195,7 @@ struct admm_engine {
 
   // histories of the last run
   int32_t hist_cap = 0;
-  bool hist_vectors = false, hist_fast = false;
+  bool hist_vectors = false, hist_fast = false, hist_bgen = false;
   double *xhist = nullptr, *zhist = nullptr, *uhist = nullptr, *vhist = nullptr, *uhathist = nullptr;
   double *pnorm = nullptr, *dnorm = nullptr, *perr = nullptr, *derr = nullptr, *objv = nullptr, *hnorm = nullptr,
          *avals = nullptr, *dvals = nullptr, *restarted = nullptr;

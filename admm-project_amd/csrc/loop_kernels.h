@@ -234,6 +234,16 @@ void launch_zstate(const ZStateArgs& a, const Ctrl* ctrl, hipStream_t stream);
 // order): the calibration of the Gram-form lasso objective against the literal one
 void launch_obj_compare(const double* pa, int na, double sa, double ca, const double* pb, int nb, double sb, double cb,
                         double* disc, const Ctrl* ctrl, hipStream_t stream);
+// Start of a run from zero iterates: x, z, u, v, uhat, the nine scalar histories and the control block in one launch
+struct RunInitArgs {
+  double *x, *z, *u, *v, *uhat;
+  int64_t nA, len;
+  double* scal[9];
+  int32_t N;
+  Ctrl* ctrl;
+  Ctrl c0;
+};
+void launch_run_init(const RunInitArgs& a, hipStream_t stream);
 // x = alpha*(sum_c part[c][i]) + beta*y[i] + add[i]  (add/y nullable)
 void launch_combine(const double* part, int32_t nchunk, int64_t ld, double alpha, const double* y, double beta,
                     const double* add, double* x, int64_t len, const Ctrl* ctrl, hipStream_t stream);

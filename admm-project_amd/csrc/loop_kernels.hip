@@ -464,6 +464,31 @@ void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const d
                      ld, x, q, len, objpart, ctrl);
 }
 
+__global__ __launch_bounds__(kBlock) void run_init_kernel(RunInitArgs a) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, T = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = t; i < a.nA; i += T) a.x[i] = 0.0;
+  for (int64_t i = t; i < a.len; i += T) {
+    a.z[i] = 0.0;
+    a.u[i] = 0.0;
+    a.v[i] = 0.0;
+    a.uhat[i] = 0.0;
+  }
+  for (int64_t i = t; i < a.N; i += T) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.scal[k][i] = 0.0;
+  }
+  if (t == 0) *a.ctrl = a.c0;
+}
+
+void launch_run_init(const RunInitArgs& a, hipStream_t stream) {
+  int64_t most = a.len > a.nA ? a.len : a.nA;
+  if (a.N > most) most = a.N;
+  int64_t blocks = ceil_div(most, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(run_init_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a);
+}
+
 __global__ __launch_bounds__(kBlock) void obj_compare_kernel(const double* __restrict__ pa, int na, double sa, double ca,
                                                              const double* __restrict__ pb, int nb, double sb, double cb,
                                                              double* __restrict__ disc, const Ctrl* __restrict__ ctrl) {
