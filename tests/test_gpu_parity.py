@@ -733,3 +733,14 @@ def test_total_variation_deferred_tail_matches_the_two_small_launches(gpu, monke
     assert got["steps"] == ref["steps"]
     _close("xopt", got["xopt"], ref["xopt"], 1e-7)
     _close("zopt", got["zopt"], ref["zopt"], 1e-7)
+
+
+@pytest.mark.parametrize("n,rho", [(1936, 1.0), (1937, 1.0), (1993, 1.0), (3872, 1.0), (3873, 1.0), (3929, 1.0), (5809, 1.0),
+                                   (20000, 10.0), (12001, 30.0), (7000, 0.05)])
+def test_total_variation_direct_kernel_tile_boundaries(gpu, n, rho):
+    """tv_direct_kernel: lengths around multiples of the owned tile (1936 positions at rho = 1: the last tile is then
+    empty-but-one, exactly full, or ends inside the margin of the tile before it -- every such tile must take the exact
+    scan path), and slowly decaying kernels (rho = 10, 30: 124 / 216 taps per side)."""
+    p = gpu.synth.tv_problem(n % 89, n)
+    o = dict(objevals=1, rho=rho, maxiters=25)
+    _compare(gpu.totalvariation(p["s"], 1.0, dict(o)), S.totalvariation(p["s"], 1.0, dict(o)), tol=1e-7)
