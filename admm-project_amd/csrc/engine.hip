@@ -3,6 +3,7 @@
 // quadraticprogram.m:210-232, basispursuit.m:116-127), result fetch, timers, destroy.  The loop itself
 // (admm.m:252-767) is engine_run.hip.
 #include "engine_internal.h"
+#include "loop_kernels.h"
 
 namespace admm {
 
@@ -571,7 +572,11 @@ int symv_apply(admm_engine* e, const double* y, double* out) {
   const SliceFactor& f = e->xfac;
   const int nr = e->comm ? comm_nranks(e->comm) : 1;
   if (nr > 1 && e->sy_split) {
-    launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
+    if (e->dfin && f.planSy.packed)  // the previous iteration's deferred finalize rides along (engine_run.hip)
+      launch_symv_lower_fin(f.planSy, f.Minv, y, e->syN, e->syT, *e->dfin, e->dfin_pending, e->ctrl, e->stream,
+                            comm_rank(e->comm), nr, out);
+    else
+      launch_symv_lower(f.planSy, f.Minv, f.ldM, y, e->syN, e->syT, out, e->ctrl, e->stream, comm_rank(e->comm), nr);
     return comm_allreduce_device(e->comm, out, static_cast<size_t>(f.n), e->stream);
   }
   apply_inverse(e, f, y, out, e->ctrl);

@@ -670,7 +670,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // element update stores its block partials and ends; the next iteration's x-solve carries the finalize in one extra
   // workgroup (symv_lower_fin_kernel), where its ~6 us of serial work overlap with 60 us of streaming, and the element
   // update after that starts with the decision in ctrl.  A batch's last iteration gets a stand-alone finalize.
-  const bool defer_fin = fuse_tail && e->a_identity && xsolve_has_partials(e) && e->xfac.planSy.packed && !use_graph &&
+  // (also with the x-solve's tiles split over the ranks: symv_apply hands the same passenger to its launch)
+  const bool split_symv = sharded && e->sy_split && e->xfac.mode == ADMM_XSOLVE_INVERSE && e->xfac.Minv && !e->xcb &&
+                          (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED) && !e->fat;
+  const bool defer_fin = fuse_tail && e->a_identity && (xsolve_has_partials(e) || split_symv) && e->xfac.planSy.packed && !use_graph &&
                          std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   // A = D iterations without a dual residual (fuse_tail): the finalize logic leaves the element update's launch too and
   // runs as one extra workgroup of the partial-sum launch of D'*(c + z - u) that follows it (gemv.hip)

@@ -184,8 +184,10 @@ void launch_qp_objective(const double* part, int32_t nchunk, int64_t ld, const d
                          int64_t len, double* objpart, int* nblk_out, const Ctrl* ctrl, hipStream_t stream);
 // The packed lower-triangle x-solve (symv.hip) carrying the finalize logic of the previous iteration in workgroup 0;
 // the partial rows stay unsummed (prox_fin_kernel takes them)
+// part_rank / part_count: the tile split over the ranks (launch_symv_lower); y != null: also sum the partial rows into y
 void launch_symv_lower_fin(const struct SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
-                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
+                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream, int part_rank = 0,
+                           int part_count = 1, double* y = nullptr);
 
 // g[r][j] = sum_c gpart[c][r][j] (gemv.hip) with the deferred finalize logic in one extra workgroup
 void launch_sum_partials_t_fin(const struct GemvTPlan& p, const double* gpart, int nrhs, double* g, int64_t ldg_out,

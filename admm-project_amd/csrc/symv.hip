@@ -215,14 +215,15 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
 __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __restrict__ M, int64_t n,
                                                                const double* __restrict__ x,
                                                                double* __restrict__ npart, double* __restrict__ tpart,
-                                                               int64_t ldp, uint32_t ncached, FinArgs f,
-                                                               int32_t fin_pending, const Ctrl* __restrict__ ctrl) {
+                                                               int64_t ldp, int32_t part_rank, int32_t part_count,
+                                                               uint32_t ncached, FinArgs f, int32_t fin_pending,
+                                                               const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   if (blockIdx.x == 0) {
     if (fin_pending) finalize_body<false, kWave>(f);
     return;
   }
-  symv_lower_body<true>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, 0, 1, ncached);
+  symv_lower_body<true>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, part_rank, part_count, ncached);
 }
 
 // K packed matrices of one size in ONE launch (consensus lasso: the K slice inverses of a rank; blockIdx.y = slice):
@@ -364,10 +365,15 @@ void launch_symv_lower_batch(const SymvPlan& p, const double* const* Ms_dev, int
 }
 
 void launch_symv_lower_fin(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
-                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+                           const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream, int part_rank,
+                           int part_count, double* y) {
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
   hipLaunchKernelGGL(symv_lower_fin_kernel, dim3(static_cast<unsigned>(symv_tiles(p)) + 1u), dim3(kWave), 0, stream, M,
-                     p.n, x, npart, tpart, p.ldp, ncached, f, fin_pending ? 1 : 0, ctrl);
+                     p.n, x, npart, tpart, p.ldp, part_rank, part_count, ncached, f, fin_pending ? 1 : 0, ctrl);
+  if (!y) return;  // the consumer sums the partial rows itself
+  const int64_t blocks = ceil_div(p.n, 16);
+  hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,
+                     p.ldp, p.n, p.ntile, y, ctrl);
 }
 
 }  // namespace admm
