@@ -745,7 +745,41 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->fat = m_global < n;
       if (sharded && e->fat)
         return bail(fail(ADMM_E_UNSUPPORTED, "row-sharded lasso needs a tall matrix (global m >= n)"));
-      E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+      // A big host matrix whose Gram matrix is needed anyway: upload it in row chunks and accumulate D_c'*D_c of the
+      // chunk that has arrived on a second stream while the next chunk crosses PCIe (the copy from pageable memory
+      // keeps the host busy, the GEMM does not): create() drops from upload + Gram to about the longer of the two
+      double* Wpre = nullptr;  // D'*D, accumulated during the upload (lasso.m:168 before the rho shift)
+      const int64_t ldW = round_up(e->fat ? m : n, 16);
+      if (mk == ADMM_MEM_HOST && !e->fat && !desc->L && e->xsolve != ADMM_XSOLVE_CG && m >= 32768 &&
+          static_cast<double>(m) * n >= 1e8 && std::getenv("ADMM_HIP_NO_UPLOAD_OVERLAP") == nullptr) {
+        const int64_t ldsrc = desc->ldD ? desc->ldD : m;
+        e->ldD = round_up(m, 512);
+        E_TRY(e->mem.alloc(&e->D, static_cast<size_t>(e->ldD) * n));
+        if (e->ldD != m) E_HIP(hipMemsetAsync(e->D, 0, sizeof(double) * e->ldD * n, e->stream));
+        E_TRY(e->mem.alloc(&Wpre, static_cast<size_t>(ldW) * n));
+        E_HIP(hipMemsetAsync(Wpre, 0, sizeof(double) * ldW * n, e->stream));
+        hipStream_t gs = nullptr;
+        hipEvent_t ev = nullptr;
+        E_HIP(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+        E_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        const int64_t chunk = round_up(ceil_div(m, int64_t{8}), 512);
+        hipError_t herr = hipSuccess;
+        for (int64_t r0 = 0; r0 < m && herr == hipSuccess; r0 += chunk) {
+          const int64_t rows = (m - r0 < chunk) ? m - r0 : chunk;
+          herr = hipMemcpy2DAsync(e->D + r0, e->ldD * sizeof(double), desc->D + r0, ldsrc * sizeof(double),
+                                  rows * sizeof(double), n, hipMemcpyHostToDevice, e->stream);
+          if (herr == hipSuccess) herr = hipEventRecord(ev, e->stream);
+          if (herr == hipSuccess) herr = hipStreamWaitEvent(gs, ev, 0);
+          if (herr == hipSuccess)
+            launch_gemm(1, 0, n, n, rows, 1.0, e->D + r0, e->ldD, e->D + r0, e->ldD, 1.0, Wpre, ldW, true, gs);
+        }
+        if (herr == hipSuccess) herr = hipStreamSynchronize(gs);
+        (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(gs);
+        E_HIP(herr);
+      } else {
+        E_TRY(upload_matrix(e->mem, &e->D, &e->ldD, desc->D, m, n, desc->ldD ? desc->ldD : m, mk, e->stream));
+      }
       if (desc->s) E_TRY(upload(e->mem, &e->s, desc->s, m, mk, e->stream));
       e->planDN = gemv_n_plan(m, n, e->ldD);
       e->planDT = gemv_t_plan(m, n, e->ldD);
@@ -770,12 +804,12 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       }
       const int64_t nF = e->fat ? m : n;
       const int64_t ld = round_up(nF, 16);
-      double* W = nullptr;
-      E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * nF));
+      double* W = Wpre;
+      if (!W) E_TRY(e->mem.alloc(&W, static_cast<size_t>(ld) * nF));
       if (!desc->L) {
-        E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
+        if (!Wpre) E_HIP(hipMemsetAsync(W, 0, sizeof(double) * ld * nF, e->stream));
         if (!e->fat) {  // lasso.m:168  chol(D'*D + rho*I)
-          launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
+          if (!Wpre) launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
           const bool gram_auto = desc->obj_gram == 0 && n >= kSymvHalfMin && m * n >= (int64_t{1} << 26);
