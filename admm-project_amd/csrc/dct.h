@@ -32,6 +32,12 @@ void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const Dc
 // transpose -> rows_solve -> transpose
 void launch_dct_rows_solve_strided(double* img, int64_t H, int64_t W, double rho, const DctTables& th,
                                    const DctTables& tw, const Ctrl* ctrl, hipStream_t stream);
+// The row stage without a transform: dst = inv((1 + rho*lamH[i]) I + rho*L_W) applied along every row i of src (H x W,
+// column-major, the column-transformed image), as the truncated Toeplitz kernel on the mirrored row (dct.hip);
+// src != dst.  tv2d_rows_green_taps(rho) = terms per side; usable while that is well below W.
+int tv2d_rows_green_taps(double rho);
+void launch_tv2d_rows_green(const double* src, double* dst, int64_t H, int64_t W, double rho, const DctTables& th,
+                            const Ctrl* ctrl, hipStream_t stream);
 // dst (cols x rows, column-major) = src (rows x cols, column-major) transposed
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
                       hipStream_t stream);

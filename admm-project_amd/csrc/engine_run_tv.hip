@@ -62,7 +62,15 @@ static int dct_solve_tv2d(admm_engine* e, double* y) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   const int64_t H = e->tv2_H, W = e->tv2_W;
   launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);                 // along i, in place
-  if (std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr) {  // default: row transform on the untransposed image
+  const int taps = tv2d_rows_green_taps(e->last_opts.rho);
+  if (taps <= 96 && W >= 4 * taps && std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
+      std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr) {
+    // default: no row transform at all -- the exact Toeplitz kernel of the row operator on the mirrored row (dct.hip)
+    launch_tv2d_rows_green(y, e->x, H, W, e->last_opts.rho, e->dctH, e->ctrl, e->stream);
+    launch_dct_cols_inverse(e->x, e->x, H, W, e->dctH, e->ctrl, e->stream);
+    return ADMM_OK;
+  }
+  if (std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr) {  // row transform on the untransposed image
     launch_dct_rows_solve_strided(y, H, W, e->last_opts.rho, e->dctH, e->dctW, e->ctrl, e->stream);
     launch_dct_cols_inverse(y, e->x, H, W, e->dctH, e->ctrl, e->stream);
     return ADMM_OK;
