@@ -891,7 +891,9 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (!desc->D || m <= 0 || n <= 0) return bail(fail(ADMM_E_INVALID, "problem needs D (m x n)"));
       if (!svm && !desc->s) return bail(fail(ADMM_E_INVALID, "LAD/Huber need the signal vector s"));
       if (svm && !desc->ell) return bail(fail(ADMM_E_INVALID, "linear SVM needs the label vector ell"));
-      if (m_global < n && xs != ADMM_XSOLVE_CALLBACK)
+      // (the linear SVM's x-update is pinv(D)*(z-u), linearsvm.m:185: it exists for a wide D too -- the rank-deficient
+      // D'D falls through to the pseudo-inverse below; lad.m:134 / huberfit.m:166 call chol, which errors)
+      if (m_global < n && xs != ADMM_XSOLVE_CALLBACK && !(svm && !sharded))
         return bail(fail(ADMM_E_INVALID, "D must have full column rank (m >= n) for chol(D'*D) (lad.m:134)"));
       e->a_identity = false;
       e->nA = n;

@@ -744,3 +744,20 @@ def test_total_variation_direct_kernel_tile_boundaries(gpu, n, rho):
     p = gpu.synth.tv_problem(n % 89, n)
     o = dict(objevals=1, rho=rho, maxiters=25)
     _compare(gpu.totalvariation(p["s"], 1.0, dict(o)), S.totalvariation(p["s"], 1.0, dict(o)), tol=1e-7)
+
+
+@pytest.mark.parametrize("m,n", [(161, 231), (40, 400), (3, 17)])
+def test_svm_wide_matrix_uses_the_pseudo_inverse(gpu, m, n):
+    """linearsvm.m:185 x = pinv(D)*(z - u) exists for m < n as well (D'D is then rank deficient by construction): the
+    engine's eigen-solver path against the oracle's np.linalg.pinv.  With full row rank D*pinv(D) = I, so D*x = z - u
+    exactly and u collapses to rounding noise: u is compared absolutely."""
+    q = gpu.synth.mnist_like_problem(seed=5, m=m, n=n, digit=3)
+    o = dict(objevals=1, x0=q["x0"], z0=q["z0"], u0=q["u0"])
+    got = gpu.linearsvm(q["D"], q["ell"], q["C"], dict(o))
+    ref = S.linearsvm(q["D"], q["ell"], q["C"], dict(o))
+    assert got["engine_info"]["pinv_used"] and got["engine_info"]["rank"] <= m
+    assert got["steps"] == ref["steps"]
+    for k in ("xvals", "zvals", "pnorm", "perr", "objevals", "xopt", "zopt"):
+        _close(k, got[k], ref[k], 1e-6)
+    np.testing.assert_allclose(got["uvals"], ref["uvals"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got["uopt"], ref["uopt"], rtol=1e-6, atol=1e-9)
