@@ -65,14 +65,20 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
   const auto t0 = std::chrono::steady_clock::now();
   int32_t done = 0;
   bool stop_seen = false;
+  // with the batched x-solve in front, the finalize logic of iteration i is deferred into iteration i + 1's batched
+  // launch (one passenger workgroup; engine_run.hip: defer_fin has the reasoning); a batch's last one runs stand-alone
+  const bool batched = e->cMptr && std::getenv("ADMM_HIP_CONS_UNBATCHED") == nullptr;
+  const bool defer_fin = batched && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  FinArgs fprev{};
+  bool fin_pending = false;
   while (done < N && !stop_seen) {
     const int32_t batch = (N - done < check_c) ? N - done : check_c;
     for (int32_t b = 0; b < batch; ++b) {
       {
         TimerScope ts(e, ADMM_K_XSOLVE);
-        if (e->cMptr && std::getenv("ADMM_HIP_CONS_UNBATCHED") == nullptr)
+        if (batched)
           launch_symv_lower_batch(e->cslices[0].fac.planSy, e->cMptr, K, e->cY, ldn, e->csyN, e->csyT, e->cpstride,
-                                  e->ctrl, e->stream);
+                                  e->ctrl, e->stream, fin_pending ? &fprev : nullptr);
         else
         for (int32_t k = 0; k < K; ++k) {  // getProxOps.m:1228-1253
           ConsSlice& sl = e->cslices[k];
@@ -138,12 +144,19 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
           fa.objp_reduced = e->red + 17;
         }
       }
-      {
+      if (defer_fin) {
+        fprev = fa;
+        fin_pending = true;
+      } else {
         TimerScope ts(e, ADMM_K_FINALIZE);
         launch_finalize(fa, e->stream);
       }
     }
     done += batch;
+    if (fin_pending) {
+      launch_finalize(fprev, e->stream);
+      fin_pending = false;
+    }
     {  // poll after every batch (see engine_run.hip)
       ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipStreamSynchronize(e->stream));

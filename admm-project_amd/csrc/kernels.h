@@ -57,8 +57,11 @@ int64_t symv_tiles(const SymvPlan& p);          // lower-triangle tiles
 size_t symv_packed_elems(const SymvPlan& p);    // doubles of the tile-packed storage
 int64_t symv_cached_tiles(const SymvPlan& p, int64_t budget_bytes);
 // K tile-packed matrices of one plan in one launch (partial rows left unsummed): Ms_dev = device array of K pointers
+// fin != null: workgroup (0, 0) runs the finalize logic of the previous iteration with these arguments
+struct FinArgs;
 void launch_symv_lower_batch(const SymvPlan& p, const double* const* Ms_dev, int32_t K, const double* x0, int64_t xstride,
-                             double* npart0, double* tpart0, int64_t pstride, const Ctrl* ctrl, hipStream_t stream);
+                             double* npart0, double* tpart0, int64_t pstride, const Ctrl* ctrl, hipStream_t stream,
+                             const FinArgs* fin = nullptr);
 // P (symv_packed_elems doubles) <- the lower-triangle tiles of the padded column-major M (npad x npad, ld)
 void launch_symv_pack(const SymvPlan& p, const double* M, int64_t ld, double* P, hipStream_t stream);
 // y = M*x for a small symmetric M (full storage, ld even, 16-byte aligned; x 16-byte aligned): one wave per column

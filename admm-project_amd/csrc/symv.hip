@@ -228,16 +228,21 @@ __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __r
 
 // K packed matrices of one size in ONE launch (consensus lasso: the K slice inverses of a rank; blockIdx.y = slice):
 // x, npart, tpart of slice k at x0 + k*xstride, npart0 + k*pstride, tpart0 + k*pstride
+// (workgroup (0, 0) is a passenger: the deferred finalize logic of the previous iteration, as in symv_lower_fin_kernel)
 __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* const* __restrict__ Ms, int64_t n,
                                                                  const double* __restrict__ x0, int64_t xstride,
                                                                  double* __restrict__ npart0,
                                                                  double* __restrict__ tpart0, int64_t pstride,
-                                                                 int64_t ldp, uint32_t ncached,
-                                                                 const Ctrl* __restrict__ ctrl) {
+                                                                 int64_t ldp, uint32_t ncached, FinArgs f,
+                                                                 int32_t fin_pending, const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stop) return;
+  if (blockIdx.x == 0) {
+    if (blockIdx.y == 0 && fin_pending) finalize_body<false, kWave>(f);
+    return;
+  }
   const int64_t k = blockIdx.y;
-  symv_lower_body<true>(blockIdx.x, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride, tpart0 + k * pstride, ldp,
-                        0, 1, ncached);
+  symv_lower_body<true>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride, tpart0 + k * pstride,
+                        ldp, 0, 1, ncached);
 }
 
 // column-major padded storage -> tile-packed storage (one workgroup per lower-triangle tile)
@@ -358,10 +363,13 @@ void launch_symv_lower(const SymvPlan& p, const double* M, int64_t ld, const dou
 }
 
 void launch_symv_lower_batch(const SymvPlan& p, const double* const* Ms_dev, int32_t K, const double* x0, int64_t xstride,
-                             double* npart0, double* tpart0, int64_t pstride, const Ctrl* ctrl, hipStream_t stream) {
+                             double* npart0, double* tpart0, int64_t pstride, const Ctrl* ctrl, hipStream_t stream,
+                             const FinArgs* fin) {
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
-  hipLaunchKernelGGL(symv_lower_batch_kernel, dim3(static_cast<unsigned>(symv_tiles(p)), static_cast<unsigned>(K)),
-                     dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0, pstride, p.ldp, ncached, ctrl);
+  const FinArgs f = fin ? *fin : FinArgs{};
+  hipLaunchKernelGGL(symv_lower_batch_kernel, dim3(static_cast<unsigned>(symv_tiles(p)) + 1u, static_cast<unsigned>(K)),
+                     dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0, pstride, p.ldp, ncached, f,
+                     fin ? 1 : 0, ctrl);
 }
 
 void launch_symv_lower_fin(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
