@@ -703,8 +703,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
     return bail(fail(ADMM_E_UNSUPPORTED, "prox callbacks are not supported on row-sharded engines"));
   // 2-D TV: AUTO = the direct spectral solve when both sides are powers of two, else (or on request) warm-started
   // CG; the CG vectors are allocated either way (one of them is the transposition scratch of the spectral solve)
+  // (the row stage needs no transform -- dct.hip: tv2d_rows_green_kernel -- so only the HEIGHT has to be a power of two
+  // as long as the row kernel's truncation fits the width; run() falls back to CG for a rho where it does not)
   const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
-                            dct_length_ok(desc->m) && dct_length_ok(desc->n);
+                            dct_length_ok(desc->m) && (dct_length_ok(desc->n) || (desc->n >= 64 && desc->n % 2 == 0));  // (the column DCT takes column pairs)
   if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
@@ -1170,7 +1172,8 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           return ADMM_OK;
         };
         E_TRY(tables(m, &e->dctH));
-        E_TRY(tables(n, &e->dctW));
+        e->tv2_rows_dct = dct_length_ok(n);
+        if (e->tv2_rows_dct) E_TRY(tables(n, &e->dctW));
         e->tv2_dct = true;
       }
       break;

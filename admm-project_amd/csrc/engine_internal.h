@@ -123,7 +123,8 @@ struct admm_engine {
   // obj_gram = 0 (automatic): calibrate against the literal form during the first batch, then decide (engine_run.hip)
   bool obj_auto = false, obj_gram_ok = false, obj_gram_bad = false;
   double* gobjpart = nullptr;  // [kMaxPartBlocks + 1] Gram-form partials during calibration; last entry: max discrepancy
-  bool tv2_dct = false;          // spectral (DCT) x-update instead of CG: both sides a power of two (dct.h)
+  bool tv2_dct = false;          // spectral x-update instead of CG: the height a power of two (dct.h)
+  bool tv2_rows_dct = false;     // ... and the width too: the row DCT exists as the fall-back of the Toeplitz row stage
   DctTables dctH{}, dctW{};
   double* tv_y2 = nullptr;  // ping-pong partner of tv_y (fused iteration kernel)
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;

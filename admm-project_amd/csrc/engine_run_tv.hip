@@ -58,13 +58,19 @@ int cg_solve_tv2d(admm_engine* e, const double* y) {
 // inverse row transform on row PAIRS read at stride H (dct_rows_solve_strided_kernel), inverse column DCT.  Round 1
 // transposed the image around the row pass (five passes, 10 N): 0.645 -> 0.590 ms per iteration at 4096^2 on the
 // same box (ADMM_HIP_TV2D_TRANSPOSED=1 brings that form back; e->cg_r is its scratch).
+// the Toeplitz row stage (dct.hip) covers this rho on this width
+static bool tv2d_rows_green_ok(const admm_engine* e, double rho) {
+  const int taps = tv2d_rows_green_taps(rho);
+  return taps <= 96 && e->tv2_W >= 4 * taps;
+}
+
 static int dct_solve_tv2d(admm_engine* e, double* y) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   const int64_t H = e->tv2_H, W = e->tv2_W;
   launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);                 // along i, in place
-  const int taps = tv2d_rows_green_taps(e->last_opts.rho);
-  if (taps <= 96 && W >= 4 * taps && std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
-      std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr) {
+  if (tv2d_rows_green_ok(e, e->last_opts.rho) &&
+      (!e->tv2_rows_dct || (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
+                            std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr))) {
     // default: no row transform at all -- the exact Toeplitz kernel of the row operator on the mirrored row (dct.hip)
     launch_tv2d_rows_green(y, e->x, H, W, e->last_opts.rho, e->dctH, e->ctrl, e->stream);
     launch_dct_cols_inverse(e->x, e->x, H, W, e->dctH, e->ctrl, e->stream);
@@ -97,6 +103,8 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   if (o.relax != 1.0)
     return fail(ADMM_E_INVALID, "relaxation with the 2-D total-variation prox is a dimension error (D is 2N x N)");
   const int64_t Npix = e->tv2_H * e->tv2_W;
+  // spectral x-update: needs the row DCT (width a power of two) or a rho the Toeplitz row stage covers; else CG
+  const bool spectral = e->tv2_dct && (e->tv2_rows_dct || tv2d_rows_green_ok(e, o.rho));
   if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
@@ -158,7 +166,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
         TimerScope ts(e, ADMM_K_XSOLVE);
         launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
       }
-      if (e->tv2_dct) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+      if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
       else ADMM_TRY(cg_solve(e, e->rhs));
       int nob = 0, nblk = 1;
       launch_tv2d_dx(ta.H, ta.W, e->lambda, o.objevals, e->x, e->s, e->tmpA, e->objpart, &nob, e->xhist, e->ctrl,
@@ -186,7 +194,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
         launch_finalize(fa, e->stream);
       }
       done += 1;
-      if (!e->tv2_dct || done % check_tv2 == 0 || done == N) {
+      if (!spectral || done % check_tv2 == 0 || done == N) {
         ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
         ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
         if (e->ctrl_host->stop) stop_seen = true;
@@ -204,7 +212,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
       launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
     }
     // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
-    if (e->tv2_dct) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+    if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
     else ADMM_TRY(cg_solve(e, e->rhs));
     int nblk = 1;
     {
@@ -219,7 +227,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
     done += 1;
     // the CG path synchronises inside every solve anyway; the spectral path runs check_tv2 iterations ahead
     // (everything enqueued after the stop flag is a no-op)
-    if (!e->tv2_dct || done % check_tv2 == 0 || done == N) {
+    if (!spectral || done % check_tv2 == 0 || done == N) {
       ADMM_HIP_TRY(hipMemcpyAsync(e->ctrl_host, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
       if (e->ctrl_host->stop) stop_seen = true;

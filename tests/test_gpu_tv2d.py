@@ -89,6 +89,22 @@ def test_tv2d_fast_admm(gpu, H, W, opts):
             _close(k, got[k], ref[k], 1e-6)
 
 
+@pytest.mark.parametrize("H,W,rho,spectral", [(32, 200, 1.0, True), (64, 334, 0.5, True), (16, 1000, 2.0, True),
+                                              (32, 100, 1.0, False), (32, 300, 10.0, False), (64, 333, 0.5, False)])
+def test_tv2d_any_width_when_the_height_is_a_power_of_two(gpu, H, W, rho, spectral):
+    """the row stage of the spectral solve is the Toeplitz kernel of the row operator (no row transform), so only the
+    height has to be a power of two -- while the kernel's truncation (42 terms per side at rho = 1) is well inside the
+    width and the width is even (the column DCT takes column pairs); otherwise the solve falls back to CG"""
+    img = _image(H + W, H, W)
+    o = dict(objevals=1, rho=rho, maxiters=30)
+    got = gpu.totalvariation2d(img, 0.5, dict(o))
+    ref = S.totalvariation2d(img, 0.5, dict(o))
+    assert got["steps"] == ref["steps"]
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, got[k], ref[k], 1e-7)
+    assert (got["cg_iters_total"] == 0) == spectral
+
+
 def test_tv2d_relaxation_is_a_dimension_error(gpu):
     with pytest.raises(Exception, match="dimension error"):
         gpu.totalvariation2d(_image(3, 16, 16), 0.5, dict(relax=1.5))
