@@ -313,7 +313,7 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
                          std::getenv("ADMM_HIP_TV_ONE_LAUNCH") == nullptr && alg == 0 && o.relax == 1.0;
   if (tv_direct) {
     ta.margin = tv_direct_margin(ta);
-    ta.ftile = 256 * elems - 2 * ta.margin;
+    ta.ftile = 256 * kTvDirectE - 2 * ta.margin;
     const double rr = o.rho / bstar;
     ta.green = 1.0 / (bstar * (1.0 - rr * rr));
   }

@@ -53,6 +53,7 @@ struct TvArgs {
   double green;            // A = 1/(b*(1 - r^2)), r = rho/b*
 };
 constexpr int kTvGroup = 64;
+constexpr int kTvDirectE = 8;  // positions per thread of tv_direct_kernel (tile = 256 * kTvDirectE window positions)
 
 // pivots of I + rho*D'D and the launch geometry for a given rho
 int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, int* halo, int* elems, int* tile);

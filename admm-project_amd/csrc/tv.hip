@@ -645,9 +645,10 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
 template <bool NTS>
 __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
-  constexpr int E = 8;
+  constexpr int E = kTvDirectE;
   constexpr int kCap = E * kBlock;
-  constexpr int kArr = kCap + (kCap >> 3) + 1;  // pos8(q) = q + (q >> 3): conflict-free for 8-strided positions
+  constexpr int kSh = (E == 8) ? 3 : 2;            // pad one slot per E positions: E-strided thread positions hit
+  constexpr int kArr = kCap + (kCap >> kSh) + 1;   // E + 1 apart, coprime with the 16 bank pairs
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* __restrict__ Bq = lds;         // right-hand side b (forward positions)
   double* __restrict__ Xq = lds + kArr;  // x (forward positions; scan tiles: backward positions)
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   const int count = static_cast<int>(w1 - w0);
   // the Toeplitz kernel is exact to 1e-18 where neither end of the matrix is within K of a needed x
   const bool direct = (o0 - 1 >= K) && (o1 + 1 + K <= n) && (o0 - M >= 0) && (o1 + M <= n);
-  auto pos8 = [](int q) -> int { return q + (q >> 3); };
+  auto pos8 = [](int q) -> int { return q + (q >> kSh); };
   auto pos16 = [](int q) -> int { return q + (q >> 4); };
 
   // ---- 1. z, u, s of the window (kept in registers for step 3); b = s + rho*D'(z - u) into LDS
@@ -891,8 +892,8 @@ bool tv_direct_ok(const TvArgs& a) { return a.elems == 8 && a.halo >= 2 && tv_di
 // a.ftile = 2048 - 2*a.margin, a.green = 1/(b*(1 - r^2)); grid = tiles (+ 1 passenger when a.deferred)
 void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hipStream_t stream) {
   const int64_t ntiles = ceil_div(a.n, a.ftile);
-  constexpr int kCap = 8 * kBlock;
-  const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> 3) + 1) * sizeof(double);
+  constexpr int kCap = kTvDirectE * kBlock;
+  const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> (kTvDirectE == 8 ? 3 : 2)) + 1) * sizeof(double);
   const dim3 grid(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block(kBlock);
   if (stream_hint(8 * 8 * a.n)) hipLaunchKernelGGL((tv_direct_kernel<true>), grid, block, lds, stream, a, fin, ctrl);
   else hipLaunchKernelGGL((tv_direct_kernel<false>), grid, block, lds, stream, a, fin, ctrl);

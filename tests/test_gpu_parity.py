@@ -727,8 +727,10 @@ def test_total_variation_deferred_tail_matches_the_two_small_launches(gpu, monke
     assert got["steps"] == two["steps"]
     for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr", "xvals", "zvals", "uvals", "objevals"):
         assert (k in got) == (k in two), k
-        if k in got:
-            assert np.array_equal(got[k], two[k]), k
+        if k in got and k in ("xopt", "zopt", "uopt", "xvals", "zvals", "uvals"):
+            assert np.array_equal(got[k], two[k]), k  # the iterates do not depend on how the tile partials are summed
+        elif k in got:
+            _close(k, got[k], two[k], 1e-12)  # (the passenger and tv_pack associate the tile sums differently)
     ref = S.totalvariation(p["s"], p["lam"], {k: v for k, v in opts.items() if k != "record_history"})
     assert got["steps"] == ref["steps"]
     _close("xopt", got["xopt"], ref["xopt"], 1e-7)
