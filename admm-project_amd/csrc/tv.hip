@@ -699,32 +699,53 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   auto pos16 = [](int q) -> int { return q + (q >> 4); };
 
   // ---- 1. z, u, s of the window (kept in registers for step 3); b = s + rho*D'(z - u) into LDS
-  admm_double2 zr[E / 2], ur[E / 2], sr[E / 2];
+  // Every load of the tile is issued before any is used: the window pairs AND, in lane 0 of each wave, the element just
+  // left of the wave's first pair -- loaded behind the shuffle it cost one more memory round trip per pair group, four
+  // per tile, on the tile's critical path.  s is not kept (the objective re-reads it: a cache hit).
+  admm_double2 zr[E / 2], ur[E / 2];
+  double zb[E / 2], ub[E / 2];  // z, u of element i0 - 1 (lane 0 only; steps 1 and 3)
+  {
+    admm_double2 sr[E / 2];
 #pragma unroll
-  for (int k = 0; k < E / 2; ++k) {
-    const int j = tid + k * kBlock;
-    const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
-    const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
-    admm_double2 zz{0.0, 0.0}, uu{0.0, 0.0}, ss{0.0, 0.0};
-    if (live1) {
-      zz = load2<true>(a.z + i0);
-      uu = load2<true>(a.u + i0);
-      ss = load2<true>(a.s + i0);
-    } else if (live0) {
-      zz.x = a.z[i0];
-      uu.x = a.u[i0];
-      ss.x = a.s[i0];
+    for (int k = 0; k < E / 2; ++k) {
+      const int j = tid + k * kBlock;
+      const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+      const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+      admm_double2 zz{0.0, 0.0}, uu{0.0, 0.0}, ss{0.0, 0.0};
+      if (live1) {
+        zz = load2<true>(a.z + i0);
+        uu = load2<true>(a.u + i0);
+        ss = load2<false>(a.s + i0);
+      } else if (live0) {
+        zz.x = a.z[i0];
+        uu.x = a.u[i0];
+        ss.x = a.s[i0];
+      }
+      zr[k] = zz;
+      ur[k] = uu;
+      sr[k] = ss;
+      zb[k] = 0.0;
+      ub[k] = 0.0;
+      if (lane == 0) {
+        const int64_t ib = (live0 && i0 > 0) ? i0 - 1 : 0;
+        zb[k] = a.z[ib];
+        ub[k] = a.u[ib];
+      }
     }
-    zr[k] = zz;
-    ur[k] = uu;
-    sr[k] = ss;
-    const double t0 = zz.x - uu.x, t1 = zz.y - uu.y;
-    double tm = __shfl_up(t1, 1, 64);  // element i0-1 is the previous lane's second element
-    if (lane == 0 && live0 && i0 > 0) tm = a.z[i0 - 1] - a.u[i0 - 1];
-    const double b0 = ss.x + rho * ((i0 > 0) ? t0 - tm : t0);  // getProxOps.m:1047
-    const double b1 = ss.y + rho * (t1 - t0);
-    if (live0) Bq[direct ? pos8(2 * j) : pos16(2 * j)] = b0;
-    if (live1) Bq[direct ? pos8(2 * j + 1) : pos16(2 * j + 1)] = b1;
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+      const int j = tid + k * kBlock;
+      const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
+      const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+      const admm_double2 zz = zr[k], uu = ur[k], ss = sr[k];
+      const double t0 = zz.x - uu.x, t1 = zz.y - uu.y;
+      double tm = __shfl_up(t1, 1, 64);  // element i0-1 is the previous lane's second element
+      if (lane == 0) tm = zb[k] - ub[k];
+      const double b0 = ss.x + rho * ((i0 > 0) ? t0 - tm : t0);  // getProxOps.m:1047
+      const double b1 = ss.y + rho * (t1 - t0);
+      if (live0) Bq[direct ? pos8(2 * j) : pos16(2 * j)] = b0;
+      if (live1) Bq[direct ? pos8(2 * j + 1) : pos16(2 * j + 1)] = b1;
+    }
   }
   __syncthreads();
 
@@ -786,7 +807,12 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
     double zn0 = 0.0, zn1 = 0.0, un0 = 0.0, un1 = 0.0, dz0 = 0.0, dz1 = 0.0;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, ax0 = 0.0, ax1 = 0.0;
-    const double zp0 = zr[k].x, zp1 = zr[k].y, uo0 = ur[k].x, uo1 = ur[k].y, s0 = sr[k].x, s1 = sr[k].y;
+    const double zp0 = zr[k].x, zp1 = zr[k].y, uo0 = ur[k].x, uo1 = ur[k].y;
+    double s0 = 0.0, s1 = 0.0;
+    if (a.objevals && live0) {  // totalvariation.m:134: 1/2*||x - s||^2
+      s0 = a.s[i0];
+      if (live1) s1 = a.s[i0 + 1];
+    }
     if (live0) {
       x0 = xat(i0);
       if (live1) x1 = xat(i0 + 1);
@@ -804,9 +830,9 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     }
     // the left neighbour (element i0-1) is the previous lane's second element
     double unm = __shfl_up(un1, 1, 64), dzm = __shfl_up(dz1, 1, 64);
-    if (lane == 0 && live0 && i0 > w0) {  // wave boundary: recompute element i0-1
+    if (lane == 0 && live0 && i0 > w0) {  // wave boundary: recompute element i0-1 (its old z, u: loaded in step 1)
       const double xm = xat(i0 - 1);
-      const double zpm = a.z[i0 - 1], uom = a.u[i0 - 1];
+      const double zpm = zb[k], uom = ub[k];
       const double axm = xm - x0;
       const double znm = tv_soft(uom + axm, a.thresh);
       unm = uom + (axm + (-znm));
