@@ -201,12 +201,14 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
       }
     }
   }
+  // alg == 0 carries the compact state v = z + u between iterations (tv2d.hip): iteration 0 reads z, u from buffer A
+  // and writes v into V0 = tv_zB, iteration k reads V((k-1)&1) and writes V(k&1), V1 = tv_uB; the last executed
+  // iteration's v is expanded into buffer A after the loop.
   while (alg == 0 && done < N && !stop_seen) {
-    const bool a_cur = (done & 1) == 0;  // iteration k reads buffer A when k is even
-    ta.z = a_cur ? e->tv_zA : e->tv_zB;
-    ta.u = a_cur ? e->tv_uA : e->tv_uB;
-    ta.zo = a_cur ? e->tv_zB : e->tv_zA;
-    ta.uo = a_cur ? e->tv_uB : e->tv_uA;
+    double* const vbuf[2] = {e->tv_zB, e->tv_uB};
+    ta.z = done == 0 ? e->tv_zA : vbuf[(done - 1) & 1];
+    ta.u = done == 0 ? e->tv_uA : nullptr;
+    ta.zo = vbuf[done & 1];
     if (done == 0) {  // later right-hand sides come out of the fused z/u pass of the previous iteration
       TimerScope ts(e, ADMM_K_XSOLVE);
       launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
@@ -217,7 +219,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
     int nblk = 1;
     {
       TimerScope ts(e, ADMM_K_PROX);
-      launch_tv2d_fused(ta, e->rhs, e->ctrl, &nblk, e->stream);
+      launch_tv2d_fused(ta, done > 0, e->rhs, e->ctrl, &nblk, e->stream);
     }
     fa.nblk = nblk;
     {
@@ -240,8 +242,11 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   const double rt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (e->profiling) collect_timers(e);
   const int32_t steps = e->ctrl_host->steps;
-  e->z = (alg == 0 && (steps & 1)) ? e->tv_zB : e->tv_zA;  // fast ADMM updates buffer A in place
-  e->u = (alg == 0 && (steps & 1)) ? e->tv_uB : e->tv_uA;
+  if (alg == 0 && steps > 0)  // z, u of the last executed iteration (fast ADMM updates buffer A in place)
+    launch_tv2d_expand((steps - 1) & 1 ? e->tv_uB : e->tv_zB, ta.thresh, len, e->tv_zA, e->tv_uA, e->stream);
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  e->z = e->tv_zA;
+  e->u = e->tv_uA;
   ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
   e->cg_total_last = e->cg_st_host->total;
   e->last = admm_run_summary{};

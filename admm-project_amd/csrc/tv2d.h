@@ -15,10 +15,9 @@ struct Tv2Args {
   double rho, thresh;      // thresh = lambda/rho
   const double* s;         // image (N)
   const double* x;         // current x (N)
-  const double* z;         // current z, u (2N, read)
+  const double* z;         // current z, u (2N, read); the fused kernel with state_in reads v = z + u through z
   const double* u;
-  double* zo;              // next z, u (2N, written by the prox kernel; ping-pong)
-  double* uo;
+  double* zo;              // next compact state v = z + u (2N, written by the fused kernel; ping-pong)
   int32_t objevals;
   double* xhist;
   double* zhist;
@@ -37,12 +36,13 @@ void launch_tv2d_cg_pq(int64_t H, int64_t W, double rho, const CgArgs& a, double
                        hipStream_t stream);
 // b = s + rho * D'(z - u)      right-hand side of the x-update
 void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t stream);
-// z/u update from x, residual sums, then the D' stencils of the dual residual / tolerance (second kernel)
-void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
-
-// prox + dual stencils + the NEXT x-update's right-hand side in one pass (replaces launch_tv2d_prox and the
-// following launch_tv2d_rhs; launch_tv2d_rhs is still needed once, for the first iteration)
-void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+// prox + dual stencils + the NEXT x-update's right-hand side in one pass (launch_tv2d_rhs is still needed once, for the
+// first iteration).  The loop state is v = z + u (z = soft(v), u = v - z): state_in = false reads a.z / a.u (a run's
+// first iteration), true reads v from a.z; a.zo receives the new v either way.
+void launch_tv2d_fused(const Tv2Args& a, bool state_in, double* bnext, const Ctrl* ctrl, int* nblk_out,
+                       hipStream_t stream);
+// z = soft(v, thresh), u = v - z   (len = 2N): the iterates behind a compact state
+void launch_tv2d_expand(const double* v, double thresh, int64_t len, double* z, double* u, hipStream_t stream);
 
 // Unfused building blocks for the fast / accelerated ADMM variants: ax = D*x (2N) with the objective in block partials
 // and the x history column; the D' stencils of the dual residual / tolerance from dz = z - zprev and u

@@ -127,83 +127,28 @@ __device__ __forceinline__ void tv2_block_partials(const double (&acc)[S_COUNT],
   }
 }
 
-__global__ __launch_bounds__(kBlock) void tv2d_prox_kernel(Tv2Args a, const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
-  const int64_t it = ctrl->iter;
-  const int64_t H = a.H, W = a.W, N = H * W;
-  double acc[S_COUNT];
-#pragma unroll
-  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
-       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int64_t j = idx / H, i = idx - j * H;
-    const double xi = a.x[idx];
-    const double d[2] = {(i < H - 1) ? xi - a.x[idx + 1] : 0.0, (j < W - 1) ? xi - a.x[idx + H] : 0.0};
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      const int64_t k = part * N + idx;
-      const double ax = d[part];
-      const double zp = a.z[k], uo = a.u[k];
-      const double zn = tv2_soft(uo + ax, a.thresh);
-      const double un = uo + (ax + (-zn));
-      const double r = ax + (-zn), dz = zn - zp, du = un - uo;
-      acc[S_R2] += r * r;
-      acc[S_AX2] += ax * ax;
-      acc[S_Z2] += zn * zn;
-      acc[S_DZ2] += dz * dz;
-      acc[S_U2] += un * un;
-      acc[S_DU2] += du * du;
-      if (a.objevals) acc[S_OBJZ] += fabs(ax);
-      a.zo[k] = zn;
-      a.uo[k] = un;
-      if (a.zhist) {
-        a.zhist[it * 2 * N + k] = zn;
-        a.uhist[it * 2 * N + k] = un;
-      }
-    }
-    if (a.objevals) {
-      const double e = xi - a.s[idx];
-      acc[S_OBJX] += e * e;
-    }
-    if (a.xhist) a.xhist[it * N + idx] = xi;
-  }
-  tv2_block_partials(acc, a.part, 0, S_OBJX);  // slots 0..7 (S_R2 .. S_OBJX)
-}
-
-// ||D'(z+ - z)||^2 (admm.m:624) and ||D'u+||^2 (admm.m:654): second pass, needs the neighbours' new values
-__global__ __launch_bounds__(kBlock) void tv2d_dual_kernel(Tv2Args a, const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
-  const int64_t H = a.H, W = a.W, N = H * W;
-  double acc[S_COUNT];
-#pragma unroll
-  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; idx < N;
-       idx += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int64_t j = idx / H, i = idx - j * H;
-    const double g2 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return a.zo[k] - a.z[k]; },
-                             [&](int64_t k) { return a.zo[N + k] - a.z[N + k]; });
-    const double g3 = tv2_dt(i, j, H, W, idx, [&](int64_t k) { return a.uo[k]; },
-                             [&](int64_t k) { return a.uo[N + k]; });
-    acc[S_G2] += g2 * g2;
-    acc[S_G3] += g3 * g3;
-  }
-  tv2_block_partials(acc, a.part, S_G2, S_G3);
-}
-
 // One pass per iteration instead of three: the z/u update, the D' stencils of the dual residual / tolerance AND the
 // next x-update's right-hand side b = s + rho*D'(z+ - u+).  The stencils need the NEW values of the rows i-1 (of Dv)
 // and j-1 (of Dh): each thread recomputes those two neighbour updates from the old iterates (same formula, same
 // inputs -> bit-identical to what the neighbour stores); the extra reads are cache hits (row i-1 sits in the same
-// line, column j-1 was streamed 16 workgroups earlier on the same XCD).  HBM traffic: 6N read + 5N written
-// instead of 9N + 6N + 6N for prox, dual and rhs kernels.
+// line, column j-1 was streamed 16 workgroups earlier on the same XCD).
+//
+// Compact dual state: the loop carries v = z + u (2N) instead of z and u (4N).  With z+ = soft(v+) and
+// u+ = v+ - z+ (admm.m:548 up to the rounding of one subtraction), where v+ = u + D x, both old iterates are
+// functions of the stored v: z = soft(v), u = v - z, evaluated with the threshold they were made with, so bitwise the
+// values the previous pass used.  HBM traffic: x, v (2N), s read, v+ (2N) and b written = 7N per iteration, against
+// 11N with z and u stored apart (and 9N + 6N + 6N for separate prox, dual and rhs kernels).  VIN = false is a run's
+// first iteration: z, u come from the engine's iterates as given (warm starts need not satisfy z = soft(z + u)).
+// launch_tv2d_expand writes z, u back out of the last v when the run ends.
+template <bool VIN>
 __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* __restrict__ bnext,
                                                             const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   const int64_t it = ctrl->iter;
   const int64_t H = a.H, W = a.W, N = H * W;
   const double* __restrict__ x = a.x;
-  const double* __restrict__ z = a.z;
-  const double* __restrict__ u = a.u;
+  const double* __restrict__ z = a.z;  // VIN: v
+  const double* __restrict__ u = a.u;  // VIN: unused
   const double t = a.thresh;
   double acc[S_COUNT];
 #pragma unroll
@@ -218,8 +163,24 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
     const double xi = x[idx];
     const double x_dn = x[hasv ? idx + 1 : idx], x_rt = x[hash ? idx + H : idx];
     const double x_up = x[iu], x_lf = x[il];
-    const double u_own[2] = {u[idx], u[N + idx]}, z_own[2] = {z[idx], z[N + idx]};
-    const double u_up = u[iu], z_up = z[iu], u_lf = u[N + il], z_lf = z[N + il];
+    double z_own[2] = {z[idx], z[N + idx]}, z_up = z[iu], z_lf = z[N + il];
+    double u_own[2], u_up, u_lf;
+    if (VIN) {  // the loaded values are v = z + u
+      const double v0 = z_own[0], v1 = z_own[1], vu = z_up, vl = z_lf;
+      z_own[0] = tv2_soft(v0, t);
+      z_own[1] = tv2_soft(v1, t);
+      z_up = tv2_soft(vu, t);
+      z_lf = tv2_soft(vl, t);
+      u_own[0] = v0 - z_own[0];
+      u_own[1] = v1 - z_own[1];
+      u_up = vu - z_up;
+      u_lf = vl - z_lf;
+    } else {
+      u_own[0] = u[idx];
+      u_own[1] = u[N + idx];
+      u_up = u[iu];
+      u_lf = u[N + il];
+    }
     const double si = a.s[idx];
     const double d[2] = {hasv ? xi - x_dn : 0.0, hash ? xi - x_rt : 0.0};
     double zn[2], un[2], zp[2];
@@ -228,9 +189,10 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
       const int64_t k = part * N + idx;
       const double ax = d[part];
       const double uo = u_own[part];
+      const double vn = uo + ax;
       zp[part] = z_own[part];
-      zn[part] = tv2_soft(uo + ax, t);
-      un[part] = uo + (ax + (-zn[part]));
+      zn[part] = tv2_soft(vn, t);
+      un[part] = vn - zn[part];
       const double r = ax + (-zn[part]), dz = zn[part] - zp[part], du = un[part] - uo;
       acc[S_R2] += r * r;
       acc[S_AX2] += ax * ax;
@@ -239,8 +201,7 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
       acc[S_U2] += un[part] * un[part];
       acc[S_DU2] += du * du;
       if (a.objevals) acc[S_OBJZ] += fabs(ax);
-      a.zo[k] = zn[part];
-      a.uo[k] = un[part];
+      a.zo[k] = vn;
       if (a.zhist) {
         a.zhist[it * 2 * N + k] = zn[part];
         a.uhist[it * 2 * N + k] = un[part];
@@ -254,16 +215,16 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
     // the rows above / to the left: new z, u of (i-1, j) in the vertical part and of (i, j-1) in the horizontal one
     double znu = 0.0, unu = 0.0, zpu = 0.0, znl = 0.0, unl = 0.0, zpl = 0.0;
     if (up) {
-      const double ax = x_up - xi, uo = u_up;
+      const double vn = u_up + (x_up - xi);
       zpu = z_up;
-      znu = tv2_soft(uo + ax, t);
-      unu = uo + (ax + (-znu));
+      znu = tv2_soft(vn, t);
+      unu = vn - znu;
     }
     if (left) {
-      const double ax = x_lf - xi, uo = u_lf;
+      const double vn = u_lf + (x_lf - xi);
       zpl = z_lf;
-      znl = tv2_soft(uo + ax, t);
-      unl = uo + (ax + (-znl));
+      znl = tv2_soft(vn, t);
+      unl = vn - znl;
     }
     // D'w at (i, j), in tv2_dt's order of operations
     double g2 = 0.0, g3 = 0.0, gb = 0.0;
@@ -292,6 +253,25 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_kernel(Tv2Args a, double* _
     bnext[idx] = si + a.rho * gb;
   }
   tv2_block_partials(acc, a.part, 0, S_COUNT - 1);
+}
+
+// z = soft(v), u = v - z over the 2N elements of the compact state (the iterates a run hands back)
+__global__ __launch_bounds__(kBlock) void tv2d_expand_kernel(const double* __restrict__ v, double t, int64_t len,
+                                                             double* __restrict__ z, double* __restrict__ u) {
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; k < len;
+       k += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double vk = v[k], zk = tv2_soft(vk, t);
+    z[k] = zk;
+    u[k] = vk - zk;
+  }
+}
+
+void launch_tv2d_expand(const double* v, double thresh, int64_t len, double* z, double* u, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(tv2d_expand_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, v, thresh, len,
+                     z, u);
 }
 
 // ---- building blocks of the fast / accelerated ADMM variants (the generic prox kernel does z, u, v, uhat)
@@ -356,10 +336,12 @@ void launch_tv2d_dual_vec(int64_t H, int64_t W, const double* dz, const double* 
   hipLaunchKernelGGL(tv2d_dual_vec_kernel, dim3(nblk), dim3(kBlock), 0, stream, H, W, dz, u, part, ctrl);
 }
 
-void launch_tv2d_fused(const Tv2Args& a, double* bnext, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+void launch_tv2d_fused(const Tv2Args& a, bool state_in, double* bnext, const Ctrl* ctrl, int* nblk_out,
+                       hipStream_t stream) {
   const int nb = tv2_blocks(a.H * a.W);
   *nblk_out = nb;
-  hipLaunchKernelGGL(tv2d_fused_kernel, dim3(nb), dim3(kBlock), 0, stream, a, bnext, ctrl);
+  if (state_in) hipLaunchKernelGGL(tv2d_fused_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, a, bnext, ctrl);
+  else hipLaunchKernelGGL(tv2d_fused_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, a, bnext, ctrl);
 }
 
 void launch_tv2d_laplace(int64_t H, int64_t W, double rho, const double* p, double* w, const Ctrl* ctrl,
@@ -380,13 +362,6 @@ void launch_tv2d_rhs(const Tv2Args& a, double* b, const Ctrl* ctrl, hipStream_t 
   int64_t blocks = ceil_div(a.H * a.W, kBlock);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(tv2d_rhs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, b, ctrl);
-}
-
-void launch_tv2d_prox(const Tv2Args& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
-  const int nb = tv2_blocks(a.H * a.W);
-  *nblk_out = nb;
-  hipLaunchKernelGGL(tv2d_prox_kernel, dim3(nb), dim3(kBlock), 0, stream, a, ctrl);
-  hipLaunchKernelGGL(tv2d_dual_kernel, dim3(nb), dim3(kBlock), 0, stream, a, ctrl);
 }
 
 }  // namespace admm

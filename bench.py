@@ -192,14 +192,15 @@ def other_configs(ap, L, device, steps):
         dt2 = time.perf_counter() - t0
         inner = float(tv2.fetch(L.F_CG_ITERS, 1)[0]) / s2.steps
         if xs == L.XSOLVE_CG:
-            # doubles per ADMM iteration: CG start 12N + fused z/u/dual/rhs pass 11N + 10N per inner iteration
+            # doubles per ADMM iteration: CG start 12N + fused z/u/dual/rhs pass 7N + 10N per inner iteration
             # (fused direction + stencil: reads r, p, writes p, q; update: reads x, p, r, q, writes x, r)
-            gb = (23.0 + 10.0 * inner) * 8.0 * npix / 1e9
+            gb = (19.0 + 10.0 * inner) * 8.0 * npix / 1e9
             extra = {"x_update": "cg", "cg_inner_iters_per_step": inner, "cg_tol": 1e-11}
         else:
-            # fused z/u/dual/rhs pass 6N read + 5N written; spectral solve: three in-place passes (column DCT, row
-            # DCT + scale + inverse on row pairs at stride H, column inverse) = 6N   (round 1: five passes, 10N)
-            gb = 17.0 * 8.0 * npix / 1e9
+            # fused z/u/dual/rhs pass on the compact state v = z + u: 4N read (x, v, s) + 3N written (v, next rhs);
+            # spectral solve: three passes (column DCT, row stage, column inverse) = 6N.  (Up to r2i the pass
+            # carried z and u apart: 11N + 6N = 17N; round 1: 21N.)
+            gb = 13.0 * 8.0 * npix / 1e9
             extra = {"x_update": "dct"}
         res["totalvariation2d_4096x4096" + tag] = dict(
             {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3, "algorithmic_GB_per_iter": gb,
