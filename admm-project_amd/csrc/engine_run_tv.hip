@@ -474,19 +474,17 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   // speculatively into the OTHER ping-pong buffers, and the final z, u, x are picked by the device's step count.
   const bool tv_deferred = tv_fused && !tv_one_launch && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   // ... and the forward-sweep vector iteration i read must survive iteration i + 1 (the final x is rebuilt from it when
-  // no history holds x): three y buffers in rotation instead of two.  The direct kernel has no y: there z and u rotate
-  // through three buffers, and the final x is recomputed from the z, u the last executed iteration read.
-  double *tv_y3 = nullptr, *tv_z3 = nullptr, *tv_u3 = nullptr;
+  // no history holds x): three y buffers in rotation instead of two.  The direct kernel has no y and carries the
+  // compact state v = z + u (tv.hip): iteration 0 reads z, u from buffer A, iteration k reads v from vbuf[(k-1) % 3]
+  // and writes vbuf[k % 3] -- three buffers, so that the speculative iteration behind a stop overwrites neither the
+  // last executed iteration's output nor its input (the final x is recomputed from the z, u it read).
+  double *tv_y3 = nullptr, *tv_v3 = nullptr;
   if (tv_deferred && !tv_direct)
     ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_y3), sizeof(double) * round_up(e->n, 2)));
-  if (tv_direct) {
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_z3), sizeof(double) * 2 * round_up(e->n, 2)));
-    tv_u3 = tv_z3 + round_up(e->n, 2);
-  }
-  DevFree tv_y3_guard{tv_y3}, tv_z3_guard{tv_z3};
+  if (tv_direct) ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_v3), sizeof(double) * round_up(e->n, 2)));
+  DevFree tv_y3_guard{tv_y3}, tv_v3_guard{tv_v3};
   double* const ybuf[3] = {e->tv_y, e->tv_y2, tv_y3};
-  double* const zbuf[3] = {e->tv_zA, e->tv_zB, tv_z3};
-  double* const ubuf[3] = {e->tv_uA, e->tv_uB, tv_u3};
+  double* const vbuf[3] = {e->tv_zB, e->tv_uB, tv_v3};
   const int64_t tv_ntiles = tv_fused ? ceil_div(e->n, ta.ftile) : 0;
   const int64_t tv_pset = static_cast<int64_t>(S_COUNT) * ta.part_stride;
   bool tv_pending = false;
@@ -506,10 +504,11 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
         fa.nblk = nblk;
         if (tv_direct) {
           const int64_t k = done + b;
-          ta.z = zbuf[k % 3];
-          ta.u = ubuf[k % 3];
-          ta.zo = zbuf[(k + 1) % 3];
-          ta.uo = ubuf[(k + 1) % 3];
+          ta.state_in = k > 0 ? 1 : 0;
+          ta.z = k > 0 ? vbuf[(k - 1) % 3] : e->tv_zA;
+          ta.u = k > 0 ? nullptr : e->tv_uA;
+          ta.zo = vbuf[k % 3];
+          ta.uo = nullptr;
           ta.deferred = tv_deferred ? 1 : 0;
           ta.iter_host = k;
           ta.part = tv_part + (k & 1) * tv_pset;
@@ -589,8 +588,9 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   e->u = (steps & 1) ? e->tv_uB : e->tv_uA;
   if (tv_direct) {
     if (!e->xhist && steps > 0) {  // x of the last executed iteration, from the z, u it read: two stand-alone sweeps
-      ta.z = zbuf[(steps - 1) % 3];
-      ta.u = ubuf[(steps - 1) % 3];
+      if (steps > 1) launch_tv2d_expand(vbuf[(steps - 2) % 3], ta.thresh, e->n, e->tv_zA, e->tv_uA, e->stream);
+      ta.z = e->tv_zA;
+      ta.u = e->tv_uA;
       ta.y = e->tv_y;
       ta.x = e->x;
       ta.xhist = nullptr;
@@ -600,15 +600,10 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
       ADMM_HIP_TRY(hipMemcpyAsync(e->x, e->xhist + static_cast<int64_t>(steps - 1) * e->n, sizeof(double) * e->n,
                                   hipMemcpyDeviceToDevice, e->stream));
     }
-    double *zf = zbuf[steps % 3], *uf = ubuf[steps % 3];
-    if (zf == tv_z3) {  // the third buffer is this run's own: the results move into buffer A
-      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, zf, sizeof(double) * e->n, hipMemcpyDeviceToDevice, e->stream));
-      ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, uf, sizeof(double) * e->n, hipMemcpyDeviceToDevice, e->stream));
-      zf = e->tv_zA;
-      uf = e->tv_uA;
-    }
-    e->z = zf;
-    e->u = uf;
+    // z, u of the last executed iteration out of its compact state, into buffer A
+    if (steps > 0) launch_tv2d_expand(vbuf[(steps - 1) % 3], ta.thresh, e->n, e->tv_zA, e->tv_uA, e->stream);
+    e->z = e->tv_zA;
+    e->u = e->tv_uA;
     ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   }
   if (ta.skip_x && steps > 0) {

@@ -51,6 +51,9 @@ struct TvArgs {
   // direct form (tv_direct_kernel): window margin (multiple of 8, >= halo + 8) and the Green's-function scale
   int32_t margin;
   double green;            // A = 1/(b*(1 - r^2)), r = rho/b*
+  // direct form, compact dual state: z (read) and zo (written) hold v = z + u; state_in = 0 on a run's first iteration,
+  // which reads z and u as given.  uo is not used.
+  int32_t state_in;
 };
 constexpr int kTvGroup = 64;
 constexpr int kTvDirectE = 8;  // positions per thread of tv_direct_kernel (tile = 256 * kTvDirectE window positions)

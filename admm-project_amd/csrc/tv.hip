@@ -642,7 +642,15 @@ __global__ __launch_bounds__(kBlock, 4) void tv_fused_kernel(TvArgs a, FinArgs f
 // The z/u update, the residual sums, the histories and the deferred tail are those of tv_fused_kernel.  The final x
 // (no y to rebuild it from) is recomputed after the loop from the z, u the last executed iteration read: z and u
 // rotate through THREE buffers so that the speculative iteration behind a stop does not overwrite them.
-template <bool NTS>
+//
+// Compact dual state (VIN): the loop carries v = z + u, ONE vector, instead of z and u.  With u+ = clamp(v+, -t, t) and
+// z+ = v+ - u+ (the soft threshold and admm.m:548 up to the rounding of one subtraction), v+ = u + D x, both old
+// iterates are functions of the stored v, recomputed bitwise as the previous pass had them: 3 vector passes (reads v, s;
+// writes v) instead of 5.  VIN = false is a run's first iteration (z, u as given: a warm start need not satisfy
+// z = soft(z + u)); launch_tv2d_expand turns the last v back into z, u when the run ends.
+__device__ __forceinline__ double tv_clamp(double v, double t) { return __builtin_fmin(__builtin_fmax(v, -t), t); }
+
+template <bool NTS, bool VIN>
 __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   constexpr int E = kTvDirectE;
@@ -702,8 +710,9 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   // Every load of the tile is issued before any is used: the window pairs AND, in lane 0 of each wave, the element just
   // left of the wave's first pair -- loaded behind the shuffle it cost one more memory round trip per pair group, four
   // per tile, on the tile's critical path.  s is not kept (the objective re-reads it: a cache hit).
-  admm_double2 zr[E / 2], ur[E / 2];
-  double zb[E / 2], ub[E / 2];  // z, u of element i0 - 1 (lane 0 only; steps 1 and 3)
+  admm_double2 zr[E / 2], ur[E / 2];  // VIN: zr holds v, ur is unused
+  double zb[E / 2], ub[E / 2];        // z, u of element i0 - 1 (lane 0 only; steps 1 and 3); VIN: zb holds v
+  const double th = a.thresh;
   {
     admm_double2 sr[E / 2];
 #pragma unroll
@@ -714,11 +723,11 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
       admm_double2 zz{0.0, 0.0}, uu{0.0, 0.0}, ss{0.0, 0.0};
       if (live1) {
         zz = load2<true>(a.z + i0);
-        uu = load2<true>(a.u + i0);
+        if (!VIN) uu = load2<true>(a.u + i0);
         ss = load2<false>(a.s + i0);
       } else if (live0) {
         zz.x = a.z[i0];
-        uu.x = a.u[i0];
+        if (!VIN) uu.x = a.u[i0];
         ss.x = a.s[i0];
       }
       zr[k] = zz;
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
       if (lane == 0) {
         const int64_t ib = (live0 && i0 > 0) ? i0 - 1 : 0;
         zb[k] = a.z[ib];
-        ub[k] = a.u[ib];
+        if (!VIN) ub[k] = a.u[ib];
       }
     }
 #pragma unroll
@@ -738,9 +747,11 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
       const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
       const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
       const admm_double2 zz = zr[k], uu = ur[k], ss = sr[k];
-      const double t0 = zz.x - uu.x, t1 = zz.y - uu.y;
+      // z - u;  VIN: (v - c) - c with c = clamp(v), the two roundings of z = v - c and z - u
+      const double t0 = VIN ? (zz.x - tv_clamp(zz.x, th)) - tv_clamp(zz.x, th) : zz.x - uu.x;
+      const double t1 = VIN ? (zz.y - tv_clamp(zz.y, th)) - tv_clamp(zz.y, th) : zz.y - uu.y;
       double tm = __shfl_up(t1, 1, 64);  // element i0-1 is the previous lane's second element
-      if (lane == 0) tm = zb[k] - ub[k];
+      if (lane == 0) tm = VIN ? (zb[k] - tv_clamp(zb[k], th)) - tv_clamp(zb[k], th) : zb[k] - ub[k];
       const double b0 = ss.x + rho * ((i0 > 0) ? t0 - tm : t0);  // getProxOps.m:1047
       const double b1 = ss.y + rho * (t1 - t0);
       if (live0) Bq[direct ? pos8(2 * j) : pos16(2 * j)] = b0;
@@ -753,17 +764,34 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     // ---- 2a. x = A * (causal + anticausal exponential sums) for this thread's 8 consecutive positions
     const int p0 = tid * E;
     if (p0 >= M - E && p0 + E <= count - M + E) {  // covers every x the update below needs: [M - 1, count - M + 1)
-      double c = Bq[pos8(p0 - K)];
-#pragma unroll 4
-      for (int k = K - 1; k >= 0; --k) c = __builtin_fma(r, c, Bq[pos8(p0 - k)]);
-      double ac = Bq[pos8(p0 + E - 1 + K)];
-#pragma unroll 4
-      for (int k = K - 1; k >= 1; --k) ac = __builtin_fma(r, ac, Bq[pos8(p0 + E - 1 + k)]);
+      // Taps in whole groups of 8 (G*8 >= K of them; the margin M = 8*G + 8 holds them): the padded position of
+      // element p0 + 8*g + j is 9*(tid + g) + j, so a group is eight reads at constant offsets from one address.
+      static_assert(E == 8, "the grouped tap loops assume one pad slot per 8 positions");
+      const int G = (K + 7) >> 3;
+      const double* __restrict__ own = Bq + 9 * tid;
+      double c = 0.0;  // sum_{k=1..8G} r^(k-1) b(p0 - k)
+      {
+        const double* __restrict__ g = own - 9 * G;
+#pragma unroll 2
+        for (int q = 0; q < G; ++q, g += 9) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) c = __builtin_fma(r, c, g[j]);
+        }
+      }
+      double ac = 0.0;  // sum_{k=1..8G} r^k b(p0 + 7 + k)
+      {
+        const double* __restrict__ g = own + 9 * G;
+#pragma unroll 2
+        for (int q = 0; q < G; ++q, g -= 9) {
+#pragma unroll
+          for (int j = 7; j >= 0; --j) ac = __builtin_fma(r, ac, g[j]);
+        }
+      }
       ac *= r;
       double bv[E], cv[E], av[E];
 #pragma unroll
-      for (int j = 0; j < E; ++j) bv[j] = Bq[pos8(p0 + j)];
-      cv[0] = c;
+      for (int j = 0; j < E; ++j) bv[j] = own[j];
+      cv[0] = __builtin_fma(r, c, bv[0]);
 #pragma unroll
       for (int j = 1; j < E; ++j) cv[j] = __builtin_fma(r, cv[j - 1], bv[j]);
       av[E - 1] = ac;
@@ -771,7 +799,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
       for (int j = E - 1; j >= 1; --j) av[j - 1] = r * (av[j] + bv[j]);
       const double A = a.green;
 #pragma unroll
-      for (int j = 0; j < E; ++j) Xq[pos8(p0 + j)] = A * (cv[j] + av[j]);
+      for (int j = 0; j < E; ++j) Xq[9 * tid + j] = A * (cv[j] + av[j]);
     }
     __syncthreads();
   } else {
@@ -807,7 +835,16 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
     double zn0 = 0.0, zn1 = 0.0, un0 = 0.0, un1 = 0.0, dz0 = 0.0, dz1 = 0.0;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0, ax0 = 0.0, ax1 = 0.0;
-    const double zp0 = zr[k].x, zp1 = zr[k].y, uo0 = ur[k].x, uo1 = ur[k].y;
+    double zp0 = zr[k].x, zp1 = zr[k].y, uo0 = ur[k].x, uo1 = ur[k].y;
+    if (VIN) {  // z, u again from v -- behind a barrier for the optimiser: carried over from step 1 they would cost
+                // 16 registers across the solve (and spill); three instructions per element here
+      asm volatile("" : "+v"(zp0), "+v"(zp1));
+      uo0 = tv_clamp(zp0, th);
+      uo1 = tv_clamp(zp1, th);
+      zp0 -= uo0;
+      zp1 -= uo1;
+    }
+    double vn0 = 0.0, vn1 = 0.0;
     double s0 = 0.0, s1 = 0.0;
     if (a.objevals && live0) {  // totalvariation.m:134: 1/2*||x - s||^2
       s0 = a.s[i0];
@@ -818,13 +855,15 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
       if (live1) x1 = xat(i0 + 1);
       if (i0 + 2 < w1) x2 = xat(i0 + 2);
       ax0 = (i0 + 1 < n) ? x0 - x1 : x0;   // D*x, last row is x_n (totalvariation.m:127)
-      zn0 = tv_soft(uo0 + ax0, a.thresh);  // getProxOps.m:199
-      un0 = uo0 + (ax0 + (-zn0));          // admm.m:548 (c = 0)
+      vn0 = uo0 + ax0;
+      un0 = tv_clamp(vn0, th);  // admm.m:548 (c = 0): u + (D x - z) = v+ - z
+      zn0 = vn0 - un0;          // getProxOps.m:199: soft(u + D x, lambda/rho)
       dz0 = zn0 - zp0;
       if (live1) {
         ax1 = (i0 + 2 < n) ? x1 - x2 : x1;
-        zn1 = tv_soft(uo1 + ax1, a.thresh);
-        un1 = uo1 + (ax1 + (-zn1));
+        vn1 = uo1 + ax1;
+        un1 = tv_clamp(vn1, th);
+        zn1 = vn1 - un1;
         dz1 = zn1 - zp1;
       }
     }
@@ -832,11 +871,15 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     double unm = __shfl_up(un1, 1, 64), dzm = __shfl_up(dz1, 1, 64);
     if (lane == 0 && live0 && i0 > w0) {  // wave boundary: recompute element i0-1 (its old z, u: loaded in step 1)
       const double xm = xat(i0 - 1);
-      const double zpm = zb[k], uom = ub[k];
-      const double axm = xm - x0;
-      const double znm = tv_soft(uom + axm, a.thresh);
-      unm = uom + (axm + (-znm));
-      dzm = znm - zpm;
+      double zpm = zb[k], uom = ub[k];
+      if (VIN) {
+        asm volatile("" : "+v"(zpm));
+        uom = tv_clamp(zpm, th);
+        zpm -= uom;
+      }
+      const double vnm = uom + (xm - x0);
+      unm = tv_clamp(vnm, th);
+      dzm = (vnm - unm) - zpm;
     }
     const bool left = i0 > 0;  // i0 == w0 > 0 is never an owned position (window margin)
     if (live0) {
@@ -876,17 +919,10 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
         }
       }
       if (own0 && own1) {
-        store2<NTS>(a.zo + i0, admm_double2{zn0, zn1});
-        store2<NTS>(a.uo + i0, admm_double2{un0, un1});
+        store2<NTS>(a.zo + i0, admm_double2{vn0, vn1});  // the compact state v+ = z+ + u+
       } else {
-        if (own0) {
-          a.zo[i0] = zn0;
-          a.uo[i0] = un0;
-        }
-        if (own1) {
-          a.zo[i0 + 1] = zn1;
-          a.uo[i0 + 1] = un1;
-        }
+        if (own0) a.zo[i0] = vn0;
+        if (own1) a.zo[i0 + 1] = vn1;
       }
       if (a.xhist) {  // history columns start at it*n (odd-aligned for odd n): scalar stores
         if (own0) {
@@ -921,8 +957,14 @@ void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hip
   constexpr int kCap = kTvDirectE * kBlock;
   const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> (kTvDirectE == 8 ? 3 : 2)) + 1) * sizeof(double);
   const dim3 grid(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block(kBlock);
-  if (stream_hint(8 * 8 * a.n)) hipLaunchKernelGGL((tv_direct_kernel<true>), grid, block, lds, stream, a, fin, ctrl);
-  else hipLaunchKernelGGL((tv_direct_kernel<false>), grid, block, lds, stream, a, fin, ctrl);
+  const bool nts = stream_hint(8 * 8 * a.n);
+  if (a.state_in) {
+    if (nts) hipLaunchKernelGGL((tv_direct_kernel<true, true>), grid, block, lds, stream, a, fin, ctrl);
+    else hipLaunchKernelGGL((tv_direct_kernel<false, true>), grid, block, lds, stream, a, fin, ctrl);
+  } else {
+    if (nts) hipLaunchKernelGGL((tv_direct_kernel<true, false>), grid, block, lds, stream, a, fin, ctrl);
+    else hipLaunchKernelGGL((tv_direct_kernel<false, false>), grid, block, lds, stream, a, fin, ctrl);
+  }
 }
 
 // out16[s] = sum over the tiles of part[s][.], one workgroup per slot, fixed order

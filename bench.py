@@ -167,7 +167,7 @@ def other_configs(ap, L, device, steps):
     t0 = time.perf_counter()
     s = tv.run(maxiters=k, domaxiters=1, record_history=0)
     dt = time.perf_counter() - t0
-    passes = 5  # direct iteration kernel: reads s, z, u; writes z, u (x only as a history column)  
+    passes = 3  # direct iteration kernel on the compact state v = z + u: reads s, v; writes v (5 up to r2i: z and u apart)
     res["totalvariation_16777216"] = {"iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3,
                                       "algorithmic_GB_per_iter": passes * 8.0 * n / 1e9,
                                       "achieved_GBs": passes * 8.0 * n * s.steps / dt / 1e9,
