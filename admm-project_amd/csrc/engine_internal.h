@@ -130,6 +130,9 @@ struct admm_engine {
   double *tv_y = nullptr, *tv_zA = nullptr, *tv_uA = nullptr, *tv_zB = nullptr, *tv_uB = nullptr;
   double* tv_bprefix = nullptr;
   size_t tv_bprefix_cap = 0;
+  double* tv_part = nullptr;    // tile partials of the fused 1-D kernels, kept across runs (grown when rho asks for more)
+  size_t tv_part_cap = 0;
+  double *tv_y3 = nullptr, *tv_v3 = nullptr;  // third rotation buffers of the deferred tail, allocated on first use
   // matrix-free x-update (xsolve = cg)
   double cg_tol = 1e-12;
   int32_t cg_maxit = 200;

@@ -335,7 +335,12 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
     tv_one_launch = ngroups <= kMaxPartBlocks && std::getenv("ADMM_HIP_TV_ONE_LAUNCH") != nullptr;
     const size_t extra = tv_one_launch ? static_cast<size_t>(S_COUNT) * kMaxPartBlocks + (ngroups + 2) / 2 + 1 : 0;
     // (two sets of tile partials: the deferred tail of iteration i reads its set while iteration i + 1 writes the other)
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_part), sizeof(double) * (2 * S_COUNT * ta.part_stride + extra)));
+    const size_t want = 2 * static_cast<size_t>(S_COUNT) * ta.part_stride + extra;
+    if (want > e->tv_part_cap) {  // (a per-run hipMalloc / hipFree pair costs more than 100 iterations at n = 2^24)
+      ADMM_TRY(e->mem.alloc(&e->tv_part, want));
+      e->tv_part_cap = want;
+    }
+    tv_part = e->tv_part;
     ta.part = tv_part;
     if (tv_one_launch) {
       ta.gpart = tv_part + 2 * S_COUNT * ta.part_stride;
@@ -344,12 +349,6 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
       ADMM_HIP_TRY(hipMemsetAsync(ta.gcount, 0, sizeof(int32_t) * (ngroups + 1), e->stream));
     }
   }
-  struct DevFree {
-    void* p;
-    ~DevFree() {
-      if (p) (void)hipFree(p);
-    }
-  } tv_part_guard{tv_part};
   fa.g = nullptr;
   fa.x = nullptr;
   fa.xhist = nullptr;
@@ -478,11 +477,10 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
   // compact state v = z + u (tv.hip): iteration 0 reads z, u from buffer A, iteration k reads v from vbuf[(k-1) % 3]
   // and writes vbuf[k % 3] -- three buffers, so that the speculative iteration behind a stop overwrites neither the
   // last executed iteration's output nor its input (the final x is recomputed from the z, u it read).
-  double *tv_y3 = nullptr, *tv_v3 = nullptr;
-  if (tv_deferred && !tv_direct)
-    ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_y3), sizeof(double) * round_up(e->n, 2)));
-  if (tv_direct) ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tv_v3), sizeof(double) * round_up(e->n, 2)));
-  DevFree tv_y3_guard{tv_y3}, tv_v3_guard{tv_v3};
+  if (tv_deferred && !tv_direct && !e->tv_y3) ADMM_TRY(e->mem.alloc(&e->tv_y3, round_up(e->n, 2)));
+  if (tv_direct && !e->tv_v3) ADMM_TRY(e->mem.alloc(&e->tv_v3, round_up(e->n, 2)));
+  double* const tv_y3 = e->tv_y3;
+  double* const tv_v3 = e->tv_v3;
   double* const ybuf[3] = {e->tv_y, e->tv_y2, tv_y3};
   double* const vbuf[3] = {e->tv_zB, e->tv_uB, tv_v3};
   const int64_t tv_ntiles = tv_fused ? ceil_div(e->n, ta.ftile) : 0;
