@@ -101,6 +101,23 @@ def test_total_variation_without_history(gpu, n, opts):
     np.testing.assert_allclose(got["xopt"], again["xopt"], rtol=0, atol=1e-13 * np.max(np.abs(again["xopt"])))
 
 
+@pytest.mark.parametrize("n,iters", [(5000, 1), (5000, 2), (5000, 3), (5000, 10), (70001, 13)])
+def test_total_variation_compact_state_with_arbitrary_start(gpu, n, iters):
+    """The direct 1-D kernel carries v = z + u between iterations and rebuilds z = soft(v), u = v - z from it.  A start
+    (z0, u0) that does NOT satisfy z0 = soft(z0 + u0) must still be read as given by the first iteration; 1-3 forced
+    iterations exercise every branch of the final x / z / u reconstruction (initial buffers, first and later states)."""
+    p = gpu.synth.tv_problem(seed=n + iters, n=n)
+    rng = np.random.default_rng(iters)
+    o = dict(objevals=1, maxiters=iters, domaxiters=1, x0=rng.standard_normal(n), z0=rng.standard_normal(n),
+             u0=0.3 * rng.standard_normal(n))
+    ref = S.totalvariation(p["s"], p["lam"], dict(o))
+    _compare(gpu.totalvariation(p["s"], p["lam"], dict(o)), ref)
+    got = gpu.totalvariation(p["s"], p["lam"], dict(o, record_history=0))
+    assert got["steps"] == iters
+    for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr"):
+        _close(k, got[k], ref[k], TOL, None)
+
+
 @pytest.mark.parametrize("rows,cols,opts", [(256, 64, dict()), (2500, 1600, dict(maxiters=12, domaxiters=1)),
                                             (700, 130, dict(rho=2.5, relax=1.4)), (400, 90, dict(fast=1, fasttype="strong", maxiters=40))])
 def test_lasso_objective_through_the_gram_matrix(gpu, rows, cols, opts):

@@ -105,6 +105,23 @@ def test_tv2d_any_width_when_the_height_is_a_power_of_two(gpu, H, W, rho, spectr
     assert (got["cg_iters_total"] == 0) == spectral
 
 
+@pytest.mark.parametrize("H,W,iters", [(64, 64, 1), (64, 64, 2), (64, 64, 7), (40, 33, 2), (128, 96, 12)])
+def test_tv2d_compact_state_with_arbitrary_start(gpu, H, W, iters):
+    """The fused pass carries v = z + u; z0, u0 that do not satisfy z0 = soft(z0 + u0) are read as given by the first
+    iteration, and the iterates handed back are expanded from the last state (spectral and CG x-updates)."""
+    img = _image(H + 7 * W + iters, H, W)
+    rng = np.random.default_rng(iters)
+    o = dict(objevals=1, maxiters=iters, domaxiters=1, x0=rng.standard_normal(H * W), z0=rng.standard_normal(2 * H * W),
+             u0=0.3 * rng.standard_normal(2 * H * W))
+    ref = S.totalvariation2d(img, 0.5, dict(o))
+    for extra in (dict(), dict(record_history=0)):
+        got = gpu.totalvariation2d(img, 0.5, dict(o, **extra))
+        assert got["steps"] == ref["steps"] == iters
+        keys = ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr") + (() if extra else ("xvals", "zvals", "uvals"))
+        for k in keys:
+            _close(k, got[k], ref[k], 1e-7)
+
+
 def test_tv2d_relaxation_is_a_dimension_error(gpu):
     with pytest.raises(Exception, match="dimension error"):
         gpu.totalvariation2d(_image(3, 16, 16), 0.5, dict(relax=1.5))
