@@ -413,6 +413,15 @@ __global__ __launch_bounds__(kBlock, 2) void tv2d_rows_green_kernel(const double
   const double d = 1.0 + rho * (lamH[ic] + 2.0);
   const double disc = sqrt(d * d - 4.0 * rho * rho);
   const double r = 2.0 * rho / (d + disc), A = 1.0 / disc;
+  // the wave's own truncation, from the largest ratio among its 64 rows: K (the host's bound, from r_0) is needed by
+  // the lowest vertical frequencies only -- at lambda = 4, rho = 1, 22 terms do what 44 do at lambda = 0
+  {
+    double rmax = r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, off, 64));
+    const int kw = static_cast<int>(-41.4465316738928 / log(rmax)) + 2;  // ln(1e-18)
+    K = __builtin_amdgcn_readfirstlane(kw < K ? kw : K);
+  }
   const double* __restrict__ row = src + ic;
   auto at = [&](int64_t j) -> double {  // mirrored column index (K < W)
     const int64_t jm = j < 0 ? -1 - j : (j >= W ? 2 * W - 1 - j : j);
