@@ -815,48 +815,26 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
           const bool gram_auto = desc->obj_gram == 0 && n >= kSymvHalfMin && m * n >= (int64_t{1} << 26);
-          if ((desc->obj_gram > 0 || gram_auto) && e->s) {  // keep G = D'D (before the rho shift) for the objective
+          if ((desc->obj_gram > 0 || gram_auto) && e->s) {
+            // The objective's data term without a pass over D: x solves (G + rho*I) x = y, so G x = y - rho*x and
+            // 1/2*||D x - s||^2 = 1/2*x'(y - rho*x) - x'D's + 1/2*s's comes out of the element update's own operands
+            // (OBJX_SOLVE, prox_device.h).  Needs 1/2*s's, over all shards, once.  (Up to r2i this kept a packed
+            // copy of G and spent one more symmetric-half pass per iteration on x'Gx.)
+            e->obj_alt = true;
             e->obj_auto = desc->obj_gram == 0;
             E_TRY(e->mem.alloc(&e->gobjpart, kMaxPartBlocks + 2));
-            e->planG = symv_plan(n);
-            e->planG.ncached = symv_cached_tiles(e->planG, 0);  // the x-solve's inverse owns the Infinity-Cache share
-            e->ldG = e->planG.npad;
-            E_TRY(e->mem.alloc(&e->Gpad, static_cast<size_t>(e->ldG) * e->ldG));
-            E_HIP(hipMemsetAsync(e->Gpad, 0, sizeof(double) * e->ldG * e->ldG, e->stream));
-            E_HIP(hipMemcpy2DAsync(e->Gpad, e->ldG * sizeof(double), W, ld * sizeof(double), n * sizeof(double), n,
-                                   hipMemcpyDeviceToDevice, e->stream));
-            launch_symmetrize_lower(e->Gpad, n, e->ldG, e->stream);
-            E_TRY(e->mem.alloc(&e->gx, round_up(n, 2)));
-            E_TRY(e->mem.alloc(&e->negDts, round_up(n, 2)));
-            launch_combine(e->rhs_add, 1, 0, -1.0, nullptr, 0.0, nullptr, e->negDts, n, nullptr, e->stream);
-            if (n >= 1536) {
-              E_TRY(e->mem.alloc(&e->gN, e->planG.npart_elems()));
-              E_TRY(e->mem.alloc(&e->gT, e->planG.tpart_elems()));
-              E_HIP(hipMemsetAsync(e->gN, 0, sizeof(double) * e->planG.npart_elems(), e->stream));
-              E_HIP(hipMemsetAsync(e->gT, 0, sizeof(double) * e->planG.tpart_elems(), e->stream));
-            }
-            // 1/2*s's over all shards
             std::vector<double> hs(static_cast<size_t>(m));
             E_HIP(hipMemcpyAsync(hs.data(), e->s, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
             E_HIP(hipStreamSynchronize(e->stream));
             double ssq = 0.0;
             for (double v : hs) ssq += v * v;
             if (sharded) {
-              E_HIP(hipMemcpyAsync(e->gx, &ssq, sizeof(double), hipMemcpyHostToDevice, e->stream));
-              E_TRY(comm_allreduce_device(e->comm, e->gx, 1, e->stream));
-              E_HIP(hipMemcpyAsync(&ssq, e->gx, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+              E_HIP(hipMemcpyAsync(e->gobjpart, &ssq, sizeof(double), hipMemcpyHostToDevice, e->stream));
+              E_TRY(comm_allreduce_device(e->comm, e->gobjpart, 1, e->stream));
+              E_HIP(hipMemcpyAsync(&ssq, e->gobjpart, sizeof(double), hipMemcpyDeviceToHost, e->stream));
               E_HIP(hipStreamSynchronize(e->stream));
             }
             e->half_ssq = 0.5 * ssq;
-            if (n >= kSymvHalfMin) {  // tile-packed like the inverses: half the memory, the faster layout
-              double* P = nullptr;
-              E_TRY(e->mem.alloc(&P, symv_packed_elems(e->planG)));
-              launch_symv_pack(e->planG, e->Gpad, e->ldG, P, e->stream);
-              E_HIP(hipStreamSynchronize(e->stream));
-              mem_free_one(e->mem, e->Gpad);
-              e->Gpad = P;
-              e->planG.packed = true;
-            }
           }
           launch_add_diag(W, n, ld, desc->rho, e->stream);
         } else {  // lasso.m:172  chol(1/rho*(D*D') + I)

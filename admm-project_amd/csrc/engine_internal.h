@@ -116,11 +116,9 @@ struct admm_engine {
   int64_t tv2_H = 0, tv2_W = 0;  // 2-D TV image shape
   Ctrl* ctrl_idle = nullptr;     // an all-zero control block for clean-up launches after the loop has stopped
   // lasso objective through the Gram matrix (desc.obj_gram): tile-padded copy of D'D, -D's, G*x scratch, 1/2*s's
-  double *Gpad = nullptr, *negDts = nullptr, *gx = nullptr, *gN = nullptr, *gT = nullptr;
-  int64_t ldG = 0;
-  SymvPlan planG{};
   double half_ssq = 0.0;
   // obj_gram = 0 (automatic): calibrate against the literal form during the first batch, then decide (engine_run.hip)
+  bool obj_alt = false;  // the solve-identity form of the lasso objective is available (1/2*s's is known)
   bool obj_auto = false, obj_gram_ok = false, obj_gram_bad = false;
   double* gobjpart = nullptr;  // [kMaxPartBlocks + 1] Gram-form partials during calibration; last entry: max discrepancy
   bool tv2_dct = false;          // spectral x-update instead of CG: the height a power of two (dct.h)

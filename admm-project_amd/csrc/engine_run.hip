@@ -653,12 +653,22 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
   // the lasso objective through the cached Gram matrix: always (obj_gram = 1), or once the calibration of the first
   // batch has shown it agrees with the literal D*x form to 1e-11 (obj_gram = 0; admm_engine.h)
-  bool gram_now = obj_lasso_gemv && e->Gpad && (!e->obj_auto || e->obj_gram_ok);
-  bool gram_calibrating = obj_lasso_gemv && e->Gpad && e->obj_auto && !e->obj_gram_ok && !e->obj_gram_bad;
+  // (the form: 1/2*x'(y - rho*x) - x'D's + 1/2*s's with y the right-hand side x was solved from -- OBJX_SOLVE, summed by
+  // the element update itself: no objective kernel at all, and the one-launch tail stays available with objevals = 1)
+  const bool alt_ok = obj_lasso_gemv && e->obj_alt && e->a_identity && !e->xcb && e->xsolve != ADMM_XSOLVE_CG &&
+                      e->rhs_kind == RHS_RHO_DTS;
+  bool gram_now = alt_ok && (!e->obj_auto || e->obj_gram_ok);
+  bool gram_calibrating = alt_ok && e->obj_auto && !e->obj_gram_ok && !e->obj_gram_bad;
   if (use_graph || sharded) gram_calibrating = false;  // (a captured batch cannot switch; shards would have to agree)
   if (gram_calibrating)
     ADMM_HIP_TRY(hipMemsetAsync(e->gobjpart + kMaxPartBlocks, 0, sizeof(double), e->stream));
-  const bool obj_kernels = o.objevals && (obj_lasso_gemv || obj_qp_gemv || obj_model_gemv || e->ocb);
+  if (gram_now || gram_calibrating) pa.objx = OBJX_SOLVE;
+  if (gram_now) {
+    fa.obj_scale_part = 0.0;
+    fa.obj_scale_x = 1.0;
+    fa.obj_const = e->half_ssq;
+  }
+  const bool obj_kernels = o.objevals && ((obj_lasso_gemv && !gram_now) || obj_qp_gemv || obj_model_gemv || e->ocb);
   // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
   // without it the finalize logic needs none of the D' products that follow the prox kernel
   // (row-sharded A = I engines keep x, z, u replicated and exchange nothing per iteration unless the x-solve's tiles
@@ -818,20 +828,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       }
       fa.objpart = nullptr;
       fa.nobjpart = 0;
-      // 1/2*x'Gx - x'D's (+ 1/2*s's) from the cached Gram matrix: one pass over its lower triangle
-      auto gram_objective = [&](double* part, int* nob) {
-        if (e->gN) launch_symv_lower(e->planG, e->Gpad, e->ldG, e->x, e->gN, e->gT, e->gx, e->ctrl, e->stream);
-        else launch_symv_small(e->Gpad, e->n, e->ldG, e->x, e->gx, e->ctrl, e->stream);
-        launch_qp_objective(e->gx, 1, 0, e->x, e->negDts, e->n, part, nob, e->ctrl, e->stream);
-      };
-      if (obj_lasso_gemv && gram_now) {
-        TimerScope ts(e, ADMM_K_GEMV_N);
-        int nob = 0;
-        gram_objective(e->objpart, &nob);
-        fa.obj_scale_part = 1.0;
+      if (obj_lasso_gemv && gram_now) {  // the element update's S_OBJX slot holds 1/2*x'Gx - x'D's already
+        fa.obj_scale_part = 0.0;
+        fa.obj_scale_x = 1.0;
         fa.obj_const = e->half_ssq;
-        fa.objpart = e->objpart;
-        fa.nobjpart = nob;
       } else if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
         TimerScope ts(e, ADMM_K_GEMV_N);
         int nob = 0;
@@ -842,12 +842,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         fa.obj_const = 0.0;
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
-        if (gram_calibrating) {  // the Gram form beside it: how far apart are they?
-          int nog = 0;
-          gram_objective(e->gobjpart, &nog);
-          launch_obj_compare(e->objpart, nob, 0.5, 0.0, e->gobjpart, nog, 1.0, e->half_ssq,
-                             e->gobjpart + kMaxPartBlocks, e->ctrl, e->stream);
-        }
+        if (gram_calibrating)  // the solve-identity form beside it (slot partials of the element update): how far apart?
+          launch_obj_compare(e->objpart, nob, 0.5, 0.0, e->part + static_cast<size_t>(S_OBJX) * kMaxPartBlocks, nblk, 1.0,
+                             e->half_ssq, e->gobjpart + kMaxPartBlocks, e->ctrl, e->stream);
         if (sharded) {  // sum over the row shards of ||D_g*x - s_g||^2
           launch_pack_sum(e->objpart, nob, e->red + 16, e->ctrl, e->stream);
           ADMM_TRY(comm_allreduce_device(e->comm, e->red + 16, 1, e->stream));

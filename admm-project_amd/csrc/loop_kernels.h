@@ -29,7 +29,11 @@ enum RhsKind : int32_t {
 enum ObjZKind : int32_t { OBJZ_NONE = 0, OBJZ_ABS = 1, OBJZ_HUBER = 2 };
 // Ax-side / x-side terms
 enum ObjXKind : int32_t { OBJX_NONE = 0, OBJX_HINGE = 1, OBJX_ZEROONE = 2, OBJX_ABS = 3,
-                          OBJX_DOT = 4 /* sum ell_i * x_i: b'*x, linearprogram.m:178 */ };
+                          OBJX_DOT = 4 /* sum ell_i * x_i: b'*x, linearprogram.m:178 */,
+                          // lasso, A = I: x solves (G + rho*I) x = y with y = rho*(zx-ux) + D's still in a.rhs, so
+                          // G x = y - rho*x and 1/2*x'Gx - x'D's = sum x_i*(1/2*(y_i - rho*x_i) - (D's)_i): the data
+                          // term of lasso.m:227 (plus 1/2*s's) without touching D or G
+                          OBJX_SOLVE = 5 };
 
 // reduction slots (per-block partials, summed in block order by the finalize kernel)
 enum Slot : int32_t {

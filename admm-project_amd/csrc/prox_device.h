@@ -18,7 +18,7 @@ __device__ __forceinline__ double huber_cvx(double x) {
 }
 
 struct ProxIn {  // every input of one element (see prox_load)
-  double zp, u_old, uhat_i, c_i, ell_i, zg_i, lb_i, ub_i, v_i, add_i;
+  double zp, u_old, uhat_i, c_i, ell_i, zg_i, lb_i, ub_i, v_i, add_i, rhs_i;
 };
 
 __device__ __forceinline__ ProxIn prox_load(const ProxArgs& a, int64_t i) {
@@ -36,6 +36,7 @@ __device__ __forceinline__ ProxIn prox_load(const ProxArgs& a, int64_t i) {
   const double* pub = a.ub ? a.ub : a.z;
   const double* pv = (a.alg == 2) ? a.v : a.z;
   const double* padd = a.rhs_add ? a.rhs_add : a.z;
+  const double* prhs = (a.objx == OBJX_SOLVE) ? a.rhs : a.z;  // the right-hand side the x-update just solved with
   ProxIn in;
   in.zp = a.z[i];
   in.u_old = a.u[i];
@@ -47,6 +48,7 @@ __device__ __forceinline__ ProxIn prox_load(const ProxArgs& a, int64_t i) {
   in.ub_i = pub[i];
   in.v_i = pv[i];
   in.add_i = padd[i];
+  in.rhs_i = prhs[i];
   return in;
 }
 
@@ -117,6 +119,7 @@ __device__ __forceinline__ void prox_apply(const ProxArgs& a, int64_t i, double 
     acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
   } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
   else if (a.objx == OBJX_DOT) acc[S_OBJX] += ell_i * ax;
+  else if (a.objx == OBJX_SOLVE) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho * ax) - add_i);
 
   a.z[i] = zn;
   a.u[i] = un;

@@ -482,11 +482,12 @@ def main():
         timed_run(eng, dist, 5, rho=rho, objevals=1)  # first objevals batch: both objective forms, then the decision
         dt1, s1 = timed_run(eng, dist, k1, rho=rho, objevals=1)
         out["objevals1"] = {"iters_per_s": k1 / dt1, "ms_per_step": dt1 / k1 * 1e3,
-                            "objective_form": "gram" if int(getattr(s1, "obj_gram_used", 0)) else "literal",
-                            "note": "lassotest.m:131 sets objevals=1.  Default (obj_gram = 0): the engine keeps G = D'D, "
-                                    "evaluates 1/2*||D*x - s||^2 both literally (one D*x pass, 8mn B) and as "
-                                    "1/2*x'Gx - x'D's + 1/2*s's (one pass over G's lower triangle, 4n^2 B) during the "
-                                    "first batch and keeps the second form only if they agreed to 1e-11 relative"}
+                            "objective_form": "solve_identity" if int(getattr(s1, "obj_gram_used", 0)) else "literal",
+                            "note": "lassotest.m:131 sets objevals=1.  Default (obj_gram = 0): the engine evaluates "
+                                    "1/2*||D*x - s||^2 both literally (one D*x pass, 8mn B) and as 1/2*x'(y - rho*x) - x'D's "
+                                    "+ 1/2*s's (y = the right-hand side x was solved from: G x = y - rho*x; summed by the "
+                                    "element update, no extra pass) during the first batch and keeps the second form only "
+                                    "if they agreed to 1e-11 relative"}
 
     factor = None
     if not a.no_cpu_baseline and world == 1:

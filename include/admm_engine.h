@@ -150,11 +150,12 @@ typedef struct admm_problem_desc {
   double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
   int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
   int32_t obj_gram;    /* lasso, tall, factor built by the engine: how the objective's 1/2*||D*x - s||^2 (lasso.m:227) is
-                          evaluated.  The Gram form 1/2*x'Gx - x'D's + 1/2*s's with the cached G = D'D is one pass over
-                          G's lower triangle (4n^2 B) instead of one over D (8mn B); its absolute rounding error is
-                          ~1e-16*||s||^2, i.e. relative error eps*||s||^2/objective.
-                          0 = automatic: where the literal pass is expensive (n >= 1536, m*n >= 2^26) the engine keeps
-                              G, evaluates BOTH forms during the first host batch of the first objevals run (the
+                          evaluated.  The Gram form is 1/2*x'Gx - x'D's + 1/2*s's with G = D'D; since x solves
+                          (G + rho*I) x = y (y = rho*(z - u) + D's, getProxOps.m:1195), G x = y - rho*x and the form
+                          is a sum over the element update's own operands -- no pass over D (8mn B) or G at all.  Its
+                          absolute error is ~1e-16*||s||^2 plus x'(residual of the x-solve).
+                          0 = automatic: where the literal pass is expensive (n >= 1536, m*n >= 2^26) the engine
+                              evaluates BOTH forms during the first host batch of the first objevals run (the
                               literal values are the ones recorded) and switches to the Gram form only if they agreed
                               to 1e-11 relative; 1 = the Gram form always; -1 = the literal D*x form always */
   /* ADMM_PROB_MODEL (getProxOps.m:83-89): P = args.PtP, q = args.Ptr above; and */

@@ -118,14 +118,17 @@ def test_total_variation_compact_state_with_arbitrary_start(gpu, n, iters):
         _close(k, got[k], ref[k], TOL, None)
 
 
+@pytest.mark.parametrize("xsolve", ["inverse", "trsv"])
 @pytest.mark.parametrize("rows,cols,opts", [(256, 64, dict()), (2500, 1600, dict(maxiters=12, domaxiters=1)),
-                                            (700, 130, dict(rho=2.5, relax=1.4)), (400, 90, dict(fast=1, fasttype="strong", maxiters=40))])
-def test_lasso_objective_through_the_gram_matrix(gpu, rows, cols, opts):
-    """objgram=1 (engine-side option): 1/2*||D*x - s||^2 evaluated as 1/2*x'Gx - x'D's + 1/2*s's from the cached Gram
-    matrix -- same iterates, objective equal to the literal form up to eps*||s||^2."""
+                                            (700, 130, dict(rho=2.5, relax=1.4)), (400, 90, dict(fast=1, fasttype="strong", maxiters=40)),
+                                            (400, 90, dict(fast=1, fasttype="weak", maxiters=30))])
+def test_lasso_objective_through_the_gram_matrix(gpu, rows, cols, opts, xsolve):
+    """objgram=1 (engine-side option): 1/2*||D*x - s||^2 evaluated as 1/2*x'Gx - x'D's + 1/2*s's with G x = y - rho*x
+    from the right-hand side y the x-update solved with (no pass over D or G; plain, relaxed and accelerated ADMM, both
+    x-solve forms) -- same iterates, objective equal to the literal form up to eps*||s||^2."""
     p = gpu.synth.lasso_problem(5, rows, cols)
     o = dict(objevals=1, **opts)
-    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, objgram=1, xsolve="inverse"))
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, objgram=1, xsolve=xsolve))
     ref = S.lasso(p["D"], p["s"], p["lam"], dict(o))
     _compare(got, ref, keys=tuple(k for k in HIST if k != "objevals"))
     bound = 1e-13 * float(p["s"] @ p["s"])
