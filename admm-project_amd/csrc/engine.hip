@@ -814,7 +814,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           if (!Wpre) launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
-          const bool gram_auto = desc->obj_gram == 0 && n >= kSymvHalfMin && m * n >= (int64_t{1} << 26);
+          const bool gram_auto = desc->obj_gram == 0;  // (any size: the form costs nothing, and is calibrated first)
           if ((desc->obj_gram > 0 || gram_auto) && e->s) {
             // The objective's data term without a pass over D: x solves (G + rho*I) x = y, so G x = y - rho*x and
             // 1/2*||D x - s||^2 = 1/2*x'(y - rho*x) - x'D's + 1/2*s's comes out of the element update's own operands

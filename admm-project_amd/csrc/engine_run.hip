@@ -487,6 +487,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   pa.uhathist = e->uhathist;
   pa.part = e->part;
   pa.rho = o.rho;
+  pa.rho_solve = e->rho_factor;
   pa.relax = o.relax;
   const bool split_z = e->zcb != nullptr || e->problem == ADMM_PROB_MODEL;  // z is computed between two kernels
   pa.prox = split_z ? PROX_GIVEN : e->prox;

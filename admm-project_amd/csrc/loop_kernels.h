@@ -81,6 +81,8 @@ struct ProxArgs {
   double* uhathist;        // fast only
   double* part;            // [S_COUNT][kMaxPartBlocks]
   double rho, relax, t;    // t: soft threshold | C/rho (hinge) | rho/C (01)
+  double rho_solve;        // OBJX_SOLVE: the shift of the factor the x-update solved with (a stale factor under adaptive
+                           // rho keeps its own: getProxOps.m:1190-1200 caches L, U once)
   int32_t prox;
   int32_t rhs_kind;
   int32_t alg;             // 0 plain, 1 fast (strong), 2 accelerated (weak)

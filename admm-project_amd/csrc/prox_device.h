@@ -119,7 +119,7 @@ __device__ __forceinline__ void prox_apply(const ProxArgs& a, int64_t i, double 
     acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
   } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
   else if (a.objx == OBJX_DOT) acc[S_OBJX] += ell_i * ax;
-  else if (a.objx == OBJX_SOLVE) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho * ax) - add_i);
+  else if (a.objx == OBJX_SOLVE) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho_solve * ax) - add_i);
 
   a.z[i] = zn;
   a.u[i] = un;

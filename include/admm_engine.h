@@ -154,7 +154,7 @@ typedef struct admm_problem_desc {
                           (G + rho*I) x = y (y = rho*(z - u) + D's, getProxOps.m:1195), G x = y - rho*x and the form
                           is a sum over the element update's own operands -- no pass over D (8mn B) or G at all.  Its
                           absolute error is ~1e-16*||s||^2 plus x'(residual of the x-solve).
-                          0 = automatic: where the literal pass is expensive (n >= 1536, m*n >= 2^26) the engine
+                          0 = automatic: the engine
                               evaluates BOTH forms during the first host batch of the first objevals run (the
                               literal values are the ones recorded) and switches to the Gram form only if they agreed
                               to 1e-11 relative; 1 = the Gram form always; -1 = the literal D*x form always */

@@ -706,10 +706,10 @@ def test_lasso_deferred_finalize_on_the_packed_inverse(gpu, monkeypatch, opts):
 
 
 def test_lasso_objective_switches_to_the_gram_form_after_calibration(gpu):
-    """obj_gram = 0 (default) on a problem where the literal pass is expensive (n >= 1536, m*n >= 2^26): the first batch
-    of the first objevals run evaluates both forms of 1/2*||D*x - s||^2, the literal values are recorded, and the later
-    batches use the Gram form -- the recorded objective matches the literal engine (obj_gram = -1) to 1e-10 throughout,
-    and a second run starts in the Gram form."""
+    """obj_gram = 0 (default): the first batch of the first objevals run evaluates both forms of 1/2*||D*x - s||^2, the
+    literal values are recorded, and the later batches use the form built on the x-update's right-hand side -- the
+    recorded objective matches the literal engine (obj_gram = -1) to 1e-10 throughout, and a second run starts in that
+    form (at any size: it costs nothing)."""
     L = gpu._lib
     p = gpu.synth.lasso_problem(11, 42000, 1600)
     kw = dict(D=p["D"], s=p["s"], lam=p["lam"], rho=1.0, xsolve=L.XSOLVE_INVERSE)
@@ -726,7 +726,7 @@ def test_lasso_objective_switches_to_the_gram_form_after_calibration(gpu):
         s2 = auto.run(**run)
         assert s2.obj_gram_used == 1
         assert np.max(np.abs(auto.fetch(L.F_OBJEVALS, 40) - ol) / np.abs(ol)) < 1e-10
-        assert small.run(**run).obj_gram_used == 0  # cheap literal pass: G is not even kept
+        assert small.run(**run).obj_gram_used == 1
     finally:
         auto.close(), lit.close(), small.close()
 
