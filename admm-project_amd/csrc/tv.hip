@@ -652,6 +652,12 @@ __device__ __forceinline__ double tv_clamp(double v, double t) { return __builti
 
 template <bool NTS, bool VIN>
 __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs fin, const Ctrl* __restrict__ ctrl) {
+  // every kernel argument the tile path reads, requested together with the control block's address: the compiler
+  // otherwise fetches them in three dependent groups behind the stop test (four scalar round trips before the first
+  // vector load of a 14 us tile)
+  asm volatile("" ::"s"(a.n), "s"(a.z), "s"(a.u), "s"(a.s), "s"(a.zo), "s"(a.part), "s"(a.ftile), "s"(a.margin),
+               "s"(a.halo), "s"(a.deferred), "s"(a.part_stride), "s"(a.thresh), "s"(a.rho), "s"(a.bstar), "s"(a.green),
+               "s"(a.objevals), "s"(a.xhist), "s"(ctrl));
   if (ctrl->stop) return;
   constexpr int E = kTvDirectE;
   constexpr int kCap = E * kBlock;

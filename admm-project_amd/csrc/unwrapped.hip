@@ -37,6 +37,10 @@ constexpr int kUwHalf = 512;
 constexpr int kUwMaxCols = 2;      // entries of x per thread of uw_prox_kernel: n <= 1024
 
 __global__ __launch_bounds__(kBlock) void uw_ax_kernel(UwArgs a, FinArgs f, Ctrl* __restrict__ ctrl) {
+  // all kernel arguments of the tile path requested at once (hipcc otherwise fetches them in dependent groups behind
+  // the stop test: four scalar round trips in a 7 us kernel)
+  asm volatile("" ::"s"(a.D), "s"(a.ldD), "s"(a.m), "s"(a.n), "s"(a.nblk), "s"(a.G), "s"(a.ldg), "s"(a.axpart),
+               "s"(a.ldax), "s"(a.xbuf), "s"(a.ldx), "s"(a.iter), "s"(a.fin_pending), "s"(ctrl));
   if (ctrl->stop) return;
   if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup(s): finalize of the previous iteration
     if (blockIdx.y == 0 && a.fin_pending) finalize_body<false>(f);
@@ -101,6 +105,9 @@ __global__ __launch_bounds__(kBlock) void uw_ax_kernel(UwArgs a, FinArgs f, Ctrl
 }
 
 __global__ __launch_bounds__(kUwProxThreads) void uw_prox_kernel(UwArgs a, ProxArgs pa, const Ctrl* __restrict__ ctrl) {
+  asm volatile("" ::"s"(a.Dp), "s"(a.ldP), "s"(a.m), "s"(a.n), "s"(a.R), "s"(a.nblk), "s"(a.G), "s"(a.ldg), "s"(a.axpart),
+               "s"(a.ldax), "s"(a.nchunk), "s"(a.iter), "s"(a.init), "s"(pa.z), "s"(pa.u), "s"(pa.c), "s"(pa.ell),
+               "s"(pa.len), "s"(pa.part), "s"(pa.t), "s"(pa.rho), "s"(ctrl));
   const int32_t stop = ctrl->stop;
   const int64_t it = a.iter;
   const double aprev = ctrl->acurr;
