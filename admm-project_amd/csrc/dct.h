@@ -6,6 +6,8 @@
 
 namespace admm {
 
+struct FinArgs;
+
 struct DctTables {        // device tables of one transform length n = 2^log2n
   int32_t n, log2n;
   const admm_double2* tw;   // e^{-2 pi i k / n},     k < n/2        (FFT twiddles)
@@ -21,6 +23,9 @@ bool dct_length_ok(int64_t n);
 // img (H x W, column-major, ld = H), in place: every column -> its DCT-II (unnormalised), two columns per workgroup
 void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
                              hipStream_t stream);
+// ... with one extra workgroup that runs the finalize logic `f` of the previous iteration (when fin_pending)
+void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
+                                 bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
 // inverse of the above (DCT-III with the 1/H factor): src -> dst (may alias)
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream);

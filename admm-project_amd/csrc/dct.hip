@@ -10,6 +10,7 @@
 #include <cmath>
 
 #include "dct.h"
+#include "finalize_device.h"
 #include "kernels.h"
 
 namespace admm {
@@ -148,12 +149,11 @@ __device__ __forceinline__ void dct_to_spectrum(double xak, double xan, double x
 constexpr double kSqrtHalf = 0.70710678118654752440;
 constexpr double kSqrt2 = 1.41421356237309504880;
 
-__global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __restrict__ img, int64_t H, DctTables t,
-                                                                  const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
+__device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, int64_t H, const DctTables& t,
+                                                      unsigned pair) {
   extern __shared__ c64 zs[];
   const int n = t.n, p = t.log2n;
-  double* a = img + static_cast<int64_t>(2 * blockIdx.x) * H;
+  double* a = img + static_cast<int64_t>(2 * pair) * H;
   double* b = a + H;
   load_pair(zs, a, b, n);
   __syncthreads();
@@ -176,6 +176,27 @@ __global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __rest
       b[n - k] = xbn;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __restrict__ img, int64_t H, DctTables t,
+                                                                  const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  dct_cols_forward_body(img, H, t, blockIdx.x);
+}
+
+// The same with a passenger: workgroup 0 (dispatched first) runs the finalize logic of the PREVIOUS 2-D TV iteration
+// while the others transform the new right-hand side in place.  Nothing in this launch depends on that decision, and
+// the three launches behind it (row stage, inverse transform, fused z/u pass) start after it and no-op when it has
+// raised ctrl->stop -- x and the dual state of the last real iteration stay as they are (engine_run_tv.hip).
+__global__ __launch_bounds__(kBlock) void dct_cols_forward_fin_kernel(double* __restrict__ img, int64_t H, DctTables t,
+                                                                      FinArgs f, int32_t fin_pending,
+                                                                      const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  if (blockIdx.x == 0) {
+    if (fin_pending) finalize_body<false>(f);
+    return;
+  }
+  dct_cols_forward_body(img, H, t, blockIdx.x - 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* __restrict__ src,
@@ -361,6 +382,13 @@ void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables&
   dct_allow_lds(dct_cols_forward_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, img, H, th, ctrl);
+}
+
+void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
+                                 bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+  dct_allow_lds(dct_cols_forward_fin_kernel, dct_lds_bytes(th.n));
+  hipLaunchKernelGGL(dct_cols_forward_fin_kernel, dim3(static_cast<unsigned>(W / 2) + 1u), dim3(kBlock),
+                     dct_lds_bytes(th.n), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
 }
 
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,

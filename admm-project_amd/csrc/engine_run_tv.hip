@@ -64,10 +64,12 @@ static bool tv2d_rows_green_ok(const admm_engine* e, double rho) {
   return taps <= 96 && e->tv2_W >= 4 * taps;
 }
 
-static int dct_solve_tv2d(admm_engine* e, double* y) {
+// fin != nullptr: the forward transform's launch carries the finalize logic of the previous iteration (when pending)
+static int dct_solve_tv2d(admm_engine* e, double* y, const FinArgs* fin = nullptr, bool fin_pending = false) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   const int64_t H = e->tv2_H, W = e->tv2_W;
-  launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);                 // along i, in place
+  if (fin) launch_dct_cols_forward_fin(y, H, W, e->dctH, *fin, fin_pending, e->ctrl, e->stream);
+  else launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);            // along i, in place
   if (tv2d_rows_green_ok(e, e->last_opts.rho) &&
       (!e->tv2_rows_dct || (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
                             std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr))) {
@@ -204,6 +206,11 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   // alg == 0 carries the compact state v = z + u between iterations (tv2d.hip): iteration 0 reads z, u from buffer A
   // and writes v into V0 = tv_zB, iteration k reads V((k-1)&1) and writes V(k&1), V1 = tv_uB; the last executed
   // iteration's v is expanded into buffer A after the loop.
+  // Deferred tail (spectral x-update): the finalize logic of iteration i rides in the first launch of iteration i + 1
+  // (dct_cols_forward_fin_kernel); a batch's last iteration gets the stand-alone launch.  A stop it raises turns the
+  // rest of iteration i + 1 into no-ops -- only the in-place transform of the right-hand side has run by then.
+  const bool tv2_defer = spectral && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  bool tv2_pending = false;
   while (alg == 0 && done < N && !stop_seen) {
     double* const vbuf[2] = {e->tv_zB, e->tv_uB};
     ta.z = done == 0 ? e->tv_zA : vbuf[(done - 1) & 1];
@@ -214,15 +221,18 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
       launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
     }
     // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
-    if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs));
+    if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs, tv2_defer ? &fa : nullptr, tv2_pending));
     else ADMM_TRY(cg_solve(e, e->rhs));
+    tv2_pending = false;
     int nblk = 1;
     {
       TimerScope ts(e, ADMM_K_PROX);
       launch_tv2d_fused(ta, done > 0, e->rhs, e->ctrl, &nblk, e->stream);
     }
     fa.nblk = nblk;
-    {
+    if (tv2_defer && (done + 1) % check_tv2 != 0 && done + 1 != N) {
+      tv2_pending = true;  // finalized by the next iteration's first launch
+    } else {
       TimerScope ts(e, ADMM_K_FINALIZE);
       launch_finalize(fa, e->stream);
     }
