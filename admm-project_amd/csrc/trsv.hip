@@ -175,6 +175,10 @@ __device__ __forceinline__ void tri_tile(const TriStepArgs& a, const double* __r
 // One workgroup = one 128 x 128 tile, WAVES waves of 128 x (128 / WAVES) columns each.
 template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * kWave) void tri_step_kernel(TriStepArgs a) {
+  // (the control block's address together with the tile path's arguments: one scalar round trip less in front of the
+  // loads of a workgroup that lives for one tile)
+  asm volatile("" ::"s"(a.M), "s"(a.ncached), "s"(a.n), "s"(a.Pprev), "s"(a.Pcur), "s"(a.ldp), "s"(a.dt0), "s"(a.dt1),
+               "s"(a.rt0), "s"(a.rt1), "s"(a.upper), "s"(a.ctrl));
   if (a.ctrl && a.ctrl->stop) return;
   constexpr int WC = kTsTile / WAVES;  // columns per wave
   __shared__ double2_t red[WAVES > 1 ? WAVES : 1][kWave];
