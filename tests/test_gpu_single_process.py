@@ -46,6 +46,27 @@ def test_world8_lad_matches_unsharded_oracle(gpu, group8):
         assert _rel(g["zopt"], ref["zopt"][lo:hi]) < 1e-9 and _rel(g["uopt"], ref["uopt"][lo:hi]) < 1e-9
 
 
+@pytest.mark.parametrize("objgram", [0, 1])
+def test_world8_row_sharded_lasso_objective_forms(gpu, group8, objgram):
+    """Row-sharded lasso (transpose reduction): x, z, u replicated.  objgram = 1: the objective's data term comes out of
+    the x-update's right-hand side on every rank (no pass over the row shards, no collective; 1/2*s's summed over the
+    shards once at create); objgram = 0: sharded engines keep the literal form (one scalar all-reduce per iteration)."""
+    from admm_project_amd import parallel
+    m, n = 1003, 60
+    p = gpu.synth.lasso_problem(2, m, n)
+    ref = S.lasso(p["D"], p["s"], p["lam"], dict(objevals=1))
+
+    def rank(r, comm):
+        lo, hi = parallel.my_rows(m, comm)
+        return gpu.lasso(p["D"][lo:hi], p["s"][lo:hi], p["lam"], dict(objevals=1, comm=comm, objgram=objgram))
+
+    for g in group8.on_ranks(rank):
+        assert g["steps"] == ref["steps"]
+        for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "xopt"):
+            assert _rel(g[k], ref[k]) < 1e-8, k
+        assert np.max(np.abs(g["objevals"] - ref["objevals"])) <= 1e-12 * float(p["s"] @ p["s"])
+
+
 def test_world8_consensus_lasso_matches_8_slice_oracle(gpu, group8):
     """config 4's layout: one row slice per rank, ONE all-reduce of [sum x_k; sum u_k; q] per iteration"""
     from admm_project_amd import parallel
