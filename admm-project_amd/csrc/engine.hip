@@ -814,32 +814,33 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
           if (!Wpre) launch_gemm(1, 0, n, n, m, 1.0, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           // W = sum_g D_g'*D_g  (unwrappedadmm.m:118-122); one-time, bandwidth-bound all-reduce
           if (sharded) E_TRY(comm_allreduce_device(e->comm, W, static_cast<size_t>(ld) * n, e->stream));
-          const bool gram_auto = desc->obj_gram == 0;  // (any size: the form costs nothing, and is calibrated first)
-          if ((desc->obj_gram > 0 || gram_auto) && e->s) {
-            // The objective's data term without a pass over D: x solves (G + rho*I) x = y, so G x = y - rho*x and
-            // 1/2*||D x - s||^2 = 1/2*x'(y - rho*x) - x'D's + 1/2*s's comes out of the element update's own operands
-            // (OBJX_SOLVE, prox_device.h).  Needs 1/2*s's, over all shards, once.  (Up to r2i this kept a packed
-            // copy of G and spent one more symmetric-half pass per iteration on x'Gx.)
-            e->obj_alt = true;
-            e->obj_auto = desc->obj_gram == 0;
-            E_TRY(e->mem.alloc(&e->gobjpart, kMaxPartBlocks + 2));
-            std::vector<double> hs(static_cast<size_t>(m));
-            E_HIP(hipMemcpyAsync(hs.data(), e->s, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
-            E_HIP(hipStreamSynchronize(e->stream));
-            double ssq = 0.0;
-            for (double v : hs) ssq += v * v;
-            if (sharded) {
-              E_HIP(hipMemcpyAsync(e->gobjpart, &ssq, sizeof(double), hipMemcpyHostToDevice, e->stream));
-              E_TRY(comm_allreduce_device(e->comm, e->gobjpart, 1, e->stream));
-              E_HIP(hipMemcpyAsync(&ssq, e->gobjpart, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-              E_HIP(hipStreamSynchronize(e->stream));
-            }
-            e->half_ssq = 0.5 * ssq;
-          }
           launch_add_diag(W, n, ld, desc->rho, e->stream);
         } else {  // lasso.m:172  chol(1/rho*(D*D') + I)
           launch_gemm(0, 1, m, m, n, 1.0 / desc->rho, e->D, e->ldD, e->D, e->ldD, 0.0, W, ld, true, e->stream);
           launch_add_diag(W, m, ld, 1.0, e->stream);
+        }
+        const bool gram_auto = desc->obj_gram == 0;  // (any size: the form costs nothing, and is calibrated first)
+        if ((desc->obj_gram > 0 || gram_auto) && e->s) {
+          // The objective's data term without a pass over D: x solves (G + rho*I) x = y (directly, or through the
+          // matrix-inversion lemma of the fat case, lasso.m:172), so G x = y - rho*x and
+          // 1/2*||D x - s||^2 = 1/2*x'(y - rho*x) - x'D's + 1/2*s's comes out of the element update's own operands
+          // (OBJX_SOLVE, prox_device.h).  Needs 1/2*s's, over all shards, once.  (Up to r2i this kept a packed
+          // copy of G and spent one more symmetric-half pass per iteration on x'Gx.)
+          e->obj_alt = true;
+          e->obj_auto = desc->obj_gram == 0;
+          E_TRY(e->mem.alloc(&e->gobjpart, kMaxPartBlocks + 2));
+          std::vector<double> hs(static_cast<size_t>(m));
+          E_HIP(hipMemcpyAsync(hs.data(), e->s, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+          E_HIP(hipStreamSynchronize(e->stream));
+          double ssq = 0.0;
+          for (double v : hs) ssq += v * v;
+          if (sharded) {
+            E_HIP(hipMemcpyAsync(e->gobjpart, &ssq, sizeof(double), hipMemcpyHostToDevice, e->stream));
+            E_TRY(comm_allreduce_device(e->comm, e->gobjpart, 1, e->stream));
+            E_HIP(hipMemcpyAsync(&ssq, e->gobjpart, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            E_HIP(hipStreamSynchronize(e->stream));
+          }
+          e->half_ssq = 0.5 * ssq;
         }
       }
       E_TRY(factorize(e, W, nF, ld, desc->L, mk));

@@ -121,7 +121,8 @@ def test_total_variation_compact_state_with_arbitrary_start(gpu, n, iters):
 @pytest.mark.parametrize("xsolve", ["inverse", "trsv"])
 @pytest.mark.parametrize("rows,cols,opts", [(256, 64, dict()), (2500, 1600, dict(maxiters=12, domaxiters=1)),
                                             (700, 130, dict(rho=2.5, relax=1.4)), (400, 90, dict(fast=1, fasttype="strong", maxiters=40)),
-                                            (400, 90, dict(fast=1, fasttype="weak", maxiters=30))])
+                                            (400, 90, dict(fast=1, fasttype="weak", maxiters=30)),
+                                            (60, 300, dict(maxiters=80)), (90, 700, dict(rho=0.3, relax=1.5, maxiters=60))])  # fat: lasso.m:172
 def test_lasso_objective_through_the_gram_matrix(gpu, rows, cols, opts, xsolve):
     """objgram=1 (engine-side option): 1/2*||D*x - s||^2 evaluated as 1/2*x'Gx - x'D's + 1/2*s's with G x = y - rho*x
     from the right-hand side y the x-update solved with (no pass over D or G; plain, relaxed and accelerated ADMM, both
