@@ -988,6 +988,13 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       // the objective 1/2 x'Px + q'x + r needs P*x
       e->planSq = gemv_t_plan(n, n, ld);
       if (!e->partSq) E_TRY(e->mem.alloc(&e->partSq, e->planSq.part_elems(1)));
+      // ... or, with the engine's own factor, nothing: P x = y - rho*x from the right-hand side the x-update solved
+      // with (OBJX_SOLVE_QP), calibrated against the P*x form in the first batch like the lasso objective
+      if (!desc->L && desc->obj_gram >= 0) {
+        e->obj_alt = true;
+        e->obj_auto = desc->obj_gram == 0;
+        E_TRY(e->mem.alloc(&e->gobjpart, kMaxPartBlocks + 2));
+      }
       break;
     }
     case ADMM_PROB_BASISPURSUIT: {

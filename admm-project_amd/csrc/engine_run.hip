@@ -656,20 +656,23 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // batch has shown it agrees with the literal D*x form to 1e-11 (obj_gram = 0; admm_engine.h)
   // (the form: 1/2*x'(y - rho*x) - x'D's + 1/2*s's with y the right-hand side x was solved from -- OBJX_SOLVE, summed by
   // the element update itself: no objective kernel at all, and the one-launch tail stays available with objevals = 1)
-  const bool alt_ok = obj_lasso_gemv && e->obj_alt && e->a_identity && !e->xcb && e->xsolve != ADMM_XSOLVE_CG &&
-                      e->rhs_kind == RHS_RHO_DTS;
+  const bool alt_qp = obj_qp_gemv && e->problem == ADMM_PROB_QP_BOUNDED && e->rhs_kind == RHS_RHO_MINUS_Q;
+  const bool alt_ok = ((obj_lasso_gemv && e->rhs_kind == RHS_RHO_DTS) || alt_qp) && e->obj_alt && e->a_identity &&
+                      !e->xcb && e->xsolve != ADMM_XSOLVE_CG;
+  const double alt_const = alt_qp ? e->rconst : e->half_ssq;
   bool gram_now = alt_ok && (!e->obj_auto || e->obj_gram_ok);
   bool gram_calibrating = alt_ok && e->obj_auto && !e->obj_gram_ok && !e->obj_gram_bad;
   if (use_graph || sharded) gram_calibrating = false;  // (a captured batch cannot switch; shards would have to agree)
   if (gram_calibrating)
     ADMM_HIP_TRY(hipMemsetAsync(e->gobjpart + kMaxPartBlocks, 0, sizeof(double), e->stream));
-  if (gram_now || gram_calibrating) pa.objx = OBJX_SOLVE;
+  if (gram_now || gram_calibrating) pa.objx = alt_qp ? OBJX_SOLVE_QP : OBJX_SOLVE;
   if (gram_now) {
     fa.obj_scale_part = 0.0;
     fa.obj_scale_x = 1.0;
-    fa.obj_const = e->half_ssq;
+    fa.obj_const = alt_const;
   }
-  const bool obj_kernels = o.objevals && ((obj_lasso_gemv && !gram_now) || obj_qp_gemv || obj_model_gemv || e->ocb);
+  const bool obj_kernels =
+      o.objevals && (((obj_lasso_gemv || obj_qp_gemv) && !gram_now) || obj_model_gemv || e->ocb);
   // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
   // without it the finalize logic needs none of the D' products that follow the prox kernel
   // (row-sharded A = I engines keep x, z, u replicated and exchange nothing per iteration unless the x-solve's tiles
@@ -829,10 +832,10 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
       }
       fa.objpart = nullptr;
       fa.nobjpart = 0;
-      if (obj_lasso_gemv && gram_now) {  // the element update's S_OBJX slot holds 1/2*x'Gx - x'D's already
+      if ((obj_lasso_gemv || obj_qp_gemv) && gram_now) {  // the element update's S_OBJX slot holds the data term already
         fa.obj_scale_part = 0.0;
         fa.obj_scale_x = 1.0;
-        fa.obj_const = e->half_ssq;
+        fa.obj_const = alt_const;
       } else if (obj_lasso_gemv) {  // 0.5*||D*x - s||^2  (lasso.m:227)
         TimerScope ts(e, ADMM_K_GEMV_N);
         int nob = 0;
@@ -875,6 +878,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         launch_qp_objective(e->partSq, p.nchunk, p.ldg, e->x, e->q, e->n, e->objpart, &nob, e->ctrl, e->stream);
         fa.objpart = e->objpart;
         fa.nobjpart = nob;
+        if (gram_calibrating)  // the right-hand-side form beside it
+          launch_obj_compare(e->objpart, nob, 1.0, e->rconst, e->part + static_cast<size_t>(S_OBJX) * kMaxPartBlocks, nblk,
+                             1.0, e->rconst, e->gobjpart + kMaxPartBlocks, e->ctrl, e->stream);
       }
       {
         TimerScope ts(e, ADMM_K_FINALIZE);

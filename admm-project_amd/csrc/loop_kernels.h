@@ -33,7 +33,10 @@ enum ObjXKind : int32_t { OBJX_NONE = 0, OBJX_HINGE = 1, OBJX_ZEROONE = 2, OBJX_
                           // lasso, A = I: x solves (G + rho*I) x = y with y = rho*(zx-ux) + D's still in a.rhs, so
                           // G x = y - rho*x and 1/2*x'Gx - x'D's = sum x_i*(1/2*(y_i - rho*x_i) - (D's)_i): the data
                           // term of lasso.m:227 (plus 1/2*s's) without touching D or G
-                          OBJX_SOLVE = 5 };
+                          OBJX_SOLVE = 5,
+                          // bounded QP: (P + rho*I) x = y = rho*(zx-ux) - q, so 1/2*x'Px + q'x (quadraticprogram.m:242)
+                          // = sum x_i*(1/2*(y_i - rho*x_i) + q_i)
+                          OBJX_SOLVE_QP = 6 };
 
 // reduction slots (per-block partials, summed in block order by the finalize kernel)
 enum Slot : int32_t {

@@ -87,7 +87,7 @@ void launch_prox(const ProxArgs& args, const Ctrl* ctrl, int* nblk_out, hipStrea
   if (a.prox != PROX_GIVEN) a.zgiven = nullptr;
   if (a.prox != PROX_BOX) a.lb = a.ub = nullptr;
   const bool need_add = (a.alg != 2 && a.rhs && (a.rhs_kind == RHS_RHO_DTS || a.rhs_kind == RHS_RHO_MINUS_Q)) ||
-                        a.objx == OBJX_SOLVE;
+                        a.objx == OBJX_SOLVE || a.objx == OBJX_SOLVE_QP;
   if (!need_add) a.rhs_add = nullptr;
   int64_t blocks = ceil_div(a.len, kBlock);
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
@@ -368,7 +368,7 @@ void launch_prox_fin(const ProxArgs& args, const FinArgs& f, Ctrl* ctrl, int* nb
   if (a.prox != PROX_GIVEN) a.zgiven = nullptr;
   if (a.prox != PROX_BOX) a.lb = a.ub = nullptr;
   const bool need_add = (a.alg != 2 && a.rhs && (a.rhs_kind == RHS_RHO_DTS || a.rhs_kind == RHS_RHO_MINUS_Q)) ||
-                        a.objx == OBJX_SOLVE;
+                        a.objx == OBJX_SOLVE || a.objx == OBJX_SOLVE_QP;
   if (!need_add) a.rhs_add = nullptr;
   const int64_t blocks = ceil_div(a.len, kTailTile);
   *nblk_out = static_cast<int>(blocks);

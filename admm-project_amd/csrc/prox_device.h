@@ -36,7 +36,7 @@ __device__ __forceinline__ ProxIn prox_load(const ProxArgs& a, int64_t i) {
   const double* pub = a.ub ? a.ub : a.z;
   const double* pv = (a.alg == 2) ? a.v : a.z;
   const double* padd = a.rhs_add ? a.rhs_add : a.z;
-  const double* prhs = (a.objx == OBJX_SOLVE) ? a.rhs : a.z;  // the right-hand side the x-update just solved with
+  const double* prhs = (a.objx == OBJX_SOLVE || a.objx == OBJX_SOLVE_QP) ? a.rhs : a.z;  // the right-hand side the x-update just solved with
   ProxIn in;
   in.zp = a.z[i];
   in.u_old = a.u[i];
@@ -120,6 +120,7 @@ __device__ __forceinline__ void prox_apply(const ProxArgs& a, int64_t i, double 
   } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
   else if (a.objx == OBJX_DOT) acc[S_OBJX] += ell_i * ax;
   else if (a.objx == OBJX_SOLVE) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho_solve * ax) - add_i);
+  else if (a.objx == OBJX_SOLVE_QP) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho_solve * ax) + add_i);
 
   a.z[i] = zn;
   a.u[i] = un;

@@ -149,7 +149,8 @@ typedef struct admm_problem_desc {
   admm_comm* comm;     /* NULL = single device; else rows are sharded across the ranks */
   double cg_tol;       /* ADMM_XSOLVE_CG: relative residual tolerance (default 1e-12) */
   int32_t cg_maxit;    /* ADMM_XSOLVE_CG: iteration cap per x-update (default 200) */
-  int32_t obj_gram;    /* lasso, factor built by the engine: how the objective's 1/2*||D*x - s||^2 (lasso.m:227) is
+  int32_t obj_gram;    /* lasso (and, in the same way, the bounded QP's 1/2*x'Px + q'x, quadraticprogram.m:242), factor
+                          built by the engine: how the objective's 1/2*||D*x - s||^2 (lasso.m:227) is
                           evaluated.  The Gram form is 1/2*x'Gx - x'D's + 1/2*s's with G = D'D; since x solves
                           (G + rho*I) x = y (y = rho*(z - u) + D's, getProxOps.m:1195), G x = y - rho*x and the form
                           is a sum over the element update's own operands -- no pass over D (8mn B) or G at all.  Its

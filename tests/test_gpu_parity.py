@@ -371,6 +371,26 @@ def test_qp_bounded(gpu, xsolve):
     assert np.all(got["zopt"] >= p["lb"] - 1e-15) and np.all(got["zopt"] <= p["ub"] + 1e-15)
 
 
+def test_qp_bounded_objective_from_the_right_hand_side(gpu):
+    """quadraticprogram.m:242 evaluates 1/2*x'Px + q'x + r with a pass over P; the engine's own factor gives P x = y - rho*x
+    from the right-hand side y of the x-update: calibrated against the P*x form in the first batch, then used alone."""
+    L = gpu._lib
+    p = gpu.synth.qp_bounded_problem(3, 300)
+    kw = dict(P=p["P"], q=p["q"], lb=p["lb"], ub=p["ub"], rho=1.0, r=float(p["r"]))
+    auto, lit = gpu.Engine(L.PROB_QP_BOUNDED, **kw), gpu.Engine(L.PROB_QP_BOUNDED, obj_gram=-1, **kw)
+    try:
+        run = dict(maxiters=40, domaxiters=1, objevals=1, check_every=8)
+        sa, sl = auto.run(**run), lit.run(**run)
+        assert sa.obj_gram_used == 1 and sl.obj_gram_used == 0
+        oa, ol = auto.fetch(L.F_OBJEVALS, 40), lit.fetch(L.F_OBJEVALS, 40)
+        assert np.array_equal(oa[:8], ol[:8])  # the calibration batch records the P*x values
+        scale = np.abs(ol) + abs(float(p["r"])) + 1.0
+        assert np.max(np.abs(oa - ol) / scale) < 1e-10
+        np.testing.assert_array_equal(auto.fetch(L.F_XOPT, 300), lit.fetch(L.F_XOPT, 300))
+    finally:
+        auto.close(), lit.close()
+
+
 def test_basispursuit(gpu):
     p = gpu.synth.basispursuit_problem(0, 32, 96)
     o = dict(objevals=1)
