@@ -658,7 +658,14 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   asm volatile("" ::"s"(a.n), "s"(a.z), "s"(a.u), "s"(a.s), "s"(a.zo), "s"(a.part), "s"(a.ftile), "s"(a.margin),
                "s"(a.halo), "s"(a.deferred), "s"(a.part_stride), "s"(a.thresh), "s"(a.rho), "s"(a.bstar), "s"(a.green),
                "s"(a.objevals), "s"(a.xhist), "s"(ctrl));
-  if (ctrl->stop) return;
+  // the stop flag is asked for here and tested behind the tile's loads (nothing is stored before that): in front of
+  // them the test costs every tile one more memory round trip
+  // (a scalar load issued by hand and waited for by hand: written as `ctrl->stop` the compiler fetches it through the
+  // vector memory path and moves it to a scalar register at once, i.e. waits for it right here.  Between this statement
+  // and the wait below the tile path issues only global loads and scalar arithmetic; any s_waitcnt lgkmcnt(0) the compiler
+  // adds in between is merely early, and its counted lgkmcnt(n) waits belong to LDS traffic, which starts after the wait.)
+  int32_t stop;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(stop) : "s"(ctrl));
   constexpr int E = kTvDirectE;
   constexpr int kCap = E * kBlock;
   constexpr int kSh = (E == 8) ? 3 : 2;            // pad one slot per E positions: E-strided thread positions hit
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   __shared__ double sred[4][S_COUNT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (a.deferred && blockIdx.x == 0) {  // the passenger (dispatched first): tail of the PREVIOUS iteration
-    if (!a.fin_pending) return;
+    if (ctrl->stop || !a.fin_pending) return;  // (its own read: `stop` must not be needed before the tiles' loads)
     {
       const int slot = tid >> 4, sub = tid & 15;
       double v = 0.0;
@@ -721,24 +728,20 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
   const double th = a.thresh;
   {
     admm_double2 sr[E / 2];
+    // Branch-free: every lane loads a whole pair (lanes past the window, and the single last element of an odd-length
+    // signal, from the window's last full pair).  With the loads inside `if (live1) ... else if (live0) ...` hipcc merged
+    // the two branches through register copies placed right behind each group of loads -- an s_waitcnt per group, i.e.
+    // the four groups of a tile fetched one memory round trip after the other.
+    const int64_t wlast = w0 + ((count - 2) & ~1);
 #pragma unroll
     for (int k = 0; k < E / 2; ++k) {
       const int j = tid + k * kBlock;
       const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
       const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
-      admm_double2 zz{0.0, 0.0}, uu{0.0, 0.0}, ss{0.0, 0.0};
-      if (live1) {
-        zz = load2<true>(a.z + i0);
-        if (!VIN) uu = load2<true>(a.u + i0);
-        ss = load2<false>(a.s + i0);
-      } else if (live0) {
-        zz.x = a.z[i0];
-        if (!VIN) uu.x = a.u[i0];
-        ss.x = a.s[i0];
-      }
-      zr[k] = zz;
-      ur[k] = uu;
-      sr[k] = ss;
+      const int64_t ip = live1 ? i0 : wlast;
+      zr[k] = load2<true>(a.z + ip);
+      ur[k] = VIN ? admm_double2{0.0, 0.0} : load2<true>(a.u + ip);
+      sr[k] = load2<false>(a.s + ip);
       zb[k] = 0.0;
       ub[k] = 0.0;
       if (lane == 0) {
@@ -747,11 +750,18 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
         if (!VIN) ub[k] = a.u[ib];
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(stop));
+    if (stop) return;  // (uniform)
 #pragma unroll
     for (int k = 0; k < E / 2; ++k) {
       const int j = tid + k * kBlock;
       const int64_t i0 = w0 + 2 * static_cast<int64_t>(j);
       const bool live0 = 2 * j < count, live1 = 2 * j + 1 < count;
+      if (live0 && !live1) {  // the last element of an odd-length signal (one lane of the last tile)
+        zr[k] = admm_double2{a.z[i0], 0.0};
+        if (!VIN) ur[k] = admm_double2{a.u[i0], 0.0};
+        sr[k] = admm_double2{a.s[i0], 0.0};
+      }
       const admm_double2 zz = zr[k], uu = ur[k], ss = sr[k];
       // z - u;  VIN: (v - c) - c with c = clamp(v), the two roundings of z = v - c and z - u
       const double t0 = VIN ? (zz.x - tv_clamp(zz.x, th)) - tv_clamp(zz.x, th) : zz.x - uu.x;
@@ -955,7 +965,7 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
 }
 
 int tv_direct_margin(const TvArgs& a) { return static_cast<int>(round_up(static_cast<int64_t>(a.halo) + 8, 8)); }
-bool tv_direct_ok(const TvArgs& a) { return a.elems == 8 && a.halo >= 2 && tv_direct_margin(a) <= 256; }
+bool tv_direct_ok(const TvArgs& a) { return a.elems == 8 && a.halo >= 2 && tv_direct_margin(a) <= 256 && a.n >= 2; }
 
 // a.ftile = 2048 - 2*a.margin, a.green = 1/(b*(1 - r^2)); grid = tiles (+ 1 passenger when a.deferred)
 void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hipStream_t stream) {
