@@ -456,14 +456,20 @@ __global__ __launch_bounds__(kBlock, 2) void tv2d_rows_green_kernel(const double
     return row[jm * H];
   };
   // causal sum just left of the segment: cprev = sum_{m=0..K} r^m b(jseg - 1 - m)   (then c_j = r*c_(j-1) + b_j)
+  // Loads are unconditional (taps past the sum re-read tap 0 / the run's last column) and a group of kTapGroup is issued
+  // before any is used: written as `cond ? load : 0` hipcc puts every load into its own basic block behind a scalar
+  // branch and waits per group of 8 -- six dependent round trips per side and run instead of three.
+  constexpr int kTapGroup = 16;
   double cprev = 0.0;
-  for (int m0 = K; m0 >= 0; m0 -= 8) {
-    double v[8];
+  for (int m0 = K; m0 >= 0; m0 -= kTapGroup) {
+    double v[kTapGroup];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = (m0 - q >= 0) ? at(jseg - 1 - (m0 - q)) : 0.0;
+    for (int q = 0; q < kTapGroup; ++q) v[q] = at(jseg - 1 - (m0 - q >= 0 ? m0 - q : 0));
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (m0 - q >= 0) cprev = __builtin_fma(r, cprev, v[q]);
+    for (int q = 0; q < kTapGroup; ++q) {
+      const double c2 = __builtin_fma(r, cprev, v[q]);
+      cprev = (m0 - q >= 0) ? c2 : cprev;
+    }
   }
 #pragma unroll 1
   for (int run = 0; run < kRowRuns; ++run) {
@@ -472,19 +478,24 @@ __global__ __launch_bounds__(kBlock, 2) void tv2d_rows_green_kernel(const double
     const int nrun = (W - j0 < kRowRun) ? static_cast<int>(W - j0) : kRowRun;
     // anticausal sum at the last column of the run: a = sum_{m=1..K} r^m b(jl + m)
     const int64_t jl = j0 + nrun - 1;
-    double ac = 0.0;
-    for (int m0 = K; m0 >= 1; m0 -= 8) {
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = (m0 - q >= 1) ? at(jl + (m0 - q)) : 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (m0 - q >= 1) ac = __builtin_fma(r, ac, v[q]);
-    }
-    ac *= r;
     double bs[kRowRun], cs[kRowRun];
 #pragma unroll
-    for (int t = 0; t < kRowRun; ++t) bs[t] = (t < nrun) ? row[(j0 + t) * H] : 0.0;
+    for (int t = 0; t < kRowRun; ++t) {  // the run's own columns first: in flight together with the first tap group
+      const double val = row[(t < nrun ? j0 + t : jl) * H];
+      bs[t] = (t < nrun) ? val : 0.0;
+    }
+    double ac = 0.0;
+    for (int m0 = K; m0 >= 1; m0 -= kTapGroup) {
+      double v[kTapGroup];
+#pragma unroll
+      for (int q = 0; q < kTapGroup; ++q) v[q] = at(jl + (m0 - q >= 1 ? m0 - q : 1));
+#pragma unroll
+      for (int q = 0; q < kTapGroup; ++q) {
+        const double a2 = __builtin_fma(r, ac, v[q]);
+        ac = (m0 - q >= 1) ? a2 : ac;
+      }
+    }
+    ac *= r;
     cs[0] = __builtin_fma(r, cprev, bs[0]);
 #pragma unroll
     for (int t = 1; t < kRowRun; ++t) cs[t] = __builtin_fma(r, cs[t - 1], bs[t]);
