@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # error codes
 OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
@@ -88,7 +88,7 @@ class EngineInfo(C.Structure):
         ("pinv_used", C.c_int32), ("probed", C.c_int32), ("trsv_blocks", C.c_int32), ("jacobi_sweeps", C.c_int32),
         ("unwrapped_fused", C.c_int32), ("factor_n", C.c_int64), ("rank", C.c_int64),
         ("cond_estimate", C.c_double), ("probe_err_inverse", C.c_double), ("probe_err_trsv", C.c_double),
-        ("probe_diff", C.c_double),
+        ("probe_diff", C.c_double), ("xsolve_cacheable_bytes", C.c_int64), ("xsolve_stream_bytes", C.c_int64),
     ]
 
 

@@ -1504,6 +1504,29 @@ int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
   info->probe_err_inverse = f->probed ? f->err_inv : NAN;
   info->probe_err_trsv = f->probed ? f->err_trsv : NAN;
   info->probe_diff = f->probed ? f->probe_diff : NAN;
+  // what one iteration's x-solve reads, by cache policy (symv.hip / trsv.hip: tiles below ncached use default loads)
+  auto tally = [&](const SliceFactor& s) {
+    const int64_t tile_bytes = int64_t{8} * 128 * 128;  // kSyTile = kTsTile = 128
+    if (s.mode == ADMM_XSOLVE_INVERSE && s.Minv && s.n >= kSymvHalfMin) {
+      const int64_t tiles = symv_tiles(s.planSy);
+      const int64_t cached = std::min<int64_t>(tiles, std::max<int64_t>(0, s.planSy.ncached));
+      info->xsolve_cacheable_bytes += cached * tile_bytes;
+      info->xsolve_stream_bytes += (tiles - cached) * tile_bytes;
+    } else if (s.mode == ADMM_XSOLVE_INVERSE && s.Minv) {
+      info->xsolve_cacheable_bytes += int64_t{8} * s.n * s.n;  // one wave per column, cache-resident
+    } else if (s.mode == ADMM_XSOLVE_TRSV && s.trsv.Fm) {
+      const int64_t nt = s.trsv.ntile, tiles = nt * (nt + 1) / 2;  // per triangle
+      const int64_t cached = s.trsv.streaming ? std::min<int64_t>(tiles, std::max<int64_t>(0, s.trsv.ncached)) : tiles;
+      info->xsolve_cacheable_bytes += 2 * cached * tile_bytes;
+      info->xsolve_stream_bytes += 2 * (tiles - cached) * tile_bytes;
+    }
+  };
+  info->xsolve_cacheable_bytes = info->xsolve_stream_bytes = 0;
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS) {
+    for (const ConsSlice& sl : e->cslices) tally(sl.fac);
+  } else if (has) {
+    tally(*f);
+  }
   return ADMM_OK;
 }
 

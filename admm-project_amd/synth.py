@@ -15,6 +15,29 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
+def host_cores():
+    """CPU cores this process may really use: the scheduler affinity, capped by the cgroup's CPU quota when there is
+    one (a BLAS pool sized from os.cpu_count() on a box with a smaller share oversubscribes itself)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def _randn_cols(rng_seed, rows, cols, threads=None):
     """randn(rows, cols) in Fortran order, generated column-block-wise in parallel."""
     out = np.empty((rows, cols), dtype=np.float64, order="F")

@@ -40,6 +40,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the objevals=1 and A-streaming side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parity-iters", type=int, default=25,
+                    help="iterations of the headline problem compared per iteration with the oracle (cpu_baseline leg)")
+    ap.add_argument("--cpu-factor", default="own", choices=["own", "gpu"],
+                    help="own: the CPU baseline forms D'D and its Cholesky factor itself (lasso.m:160-176, timed as "
+                         "its setup); gpu: it takes the factor the device built")
     ap.add_argument("--one-gpu", action="store_true",
                     help="rehearsal on a single-GPU box: every rank uses HIP device 0, torch.distributed runs "
                          "over gloo and the engine over the shm transport (RCCL refuses two ranks on one device)")
@@ -109,50 +114,130 @@ def make_problem(ap_mod, dist, m, n, lo, hi):
     return p
 
 
-def cpu_baseline(p, factor, seconds, rho):
-    """The oracle's lasso loop (same algorithm and operation order as the reference: two
-    triangular solves with the cached factor per iteration) on the host cores.  The factor is the
-    one built on the GPU, handed over through args.L exactly as lasso.m:183 hands it to getproxops."""
-    from oracle import admm as ref_admm
-    from oracle import getproxops as ref_getproxops
-
+def cpu_info():
+    """CPU model, physical cores and BLAS vendor of the host the baseline runs on."""
+    info = {"cpu_model": None, "physical_cores": None, "logical_cpus": os.cpu_count(), "blas": None}
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "model name" and info["cpu_model"] is None:
+                    info["cpu_model"] = val
+                elif key == "physical id":
+                    phys = val
+                elif key == "core id":
+                    core = val
+                elif not key and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
     try:
         from threadpoolctl import threadpool_info
-        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+        libs = [d for d in threadpool_info() if d.get("user_api") == "blas"]
+        info["blas"] = "; ".join(f"{d.get('internal_api')} {d.get('version')} ({d.get('threading_layer', 'threads')}, "
+                                 f"{d.get('num_threads')} threads, {d.get('architecture', '?')})" for d in libs) or None
     except Exception:
-        threads = os.cpu_count() or 1
+        pass
+    return info
+
+
+def _hist_err(got, ref):
+    """max-norm relative error of one history (vectors: against the largest reference entry; scalars: entrywise)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    if got.shape != ref.shape:
+        return float("inf")
+    if ref.ndim == 1:
+        scale = np.maximum(np.abs(ref), 1e-12 + 1e-3 * np.max(np.abs(ref)))
+        return float(np.max(np.abs(got - ref) / scale))
+    return float(np.max(np.abs(got - ref)) / max(1e-300, np.max(np.abs(ref))))
+
+
+def cpu_baseline(ap_mod, p, gpu_factor, gpu_hist, seconds, rho, own_factor=True):
+    """The oracle's lasso loop (same algorithm and operation order as the reference: lasso.m:160-245, two triangular
+    solves with the cached factor per iteration) on the host cores -- AFTER and OUTSIDE every timed GPU region.
+
+    (1) setup as lasso.m:160-176 does it, on the host: D'D by BLAS, chol by LAPACK (`setup_seconds`, all cores);
+    (2) parity: the oracle's first iterations with that factor -- nothing taken from the device -- against the
+        histories the engine recorded for the same iterations (x, z, u, residuals, tolerances, objective);
+    (3) the loop's rate, pinned to ONE BLAS thread (MATLAB applies the factor it stored sparse with single-threaded
+        triangular solves, lasso.m:175-176) and with the whole pool."""
+    import scipy.linalg as sla
+    from oracle import admm as ref_admm
+    from oracle import getproxops as ref_getproxops
+    from threadpoolctl import threadpool_limits
+
+    cores = ap_mod.synth.host_cores()
     D, s, lam = p["D"], p["s"], p["lam"]
     m, n = D.shape
-    args = dict(D=D, Dts=D.T @ s, L=factor, U=factor.T, m=m, n=n, parallel=0, rho=rho)
-    args["lambda"] = lam
-    minx, minz, _ = ref_getproxops("LASSO", args)
+    out = dict(value=None, unit="iterations/s", cores=1, kind="port", usable_cores=cores, **cpu_info())
     base = dict(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, domaxiters=1, rho=rho)
-    t0 = time.perf_counter()
-    ref_admm(minx, minz, dict(base, maxiters=2))
-    per = (time.perf_counter() - t0) / 2
-    # The reference applies the factor it stored SPARSE (lasso.m:175-176) with MATLAB's single-threaded triangular
-    # solves, and LAPACK's dense triangular solve (BLAS-2) does not thread either: the headline CPU number is the loop
-    # pinned to ONE BLAS thread (cores = 1); the same loop with the whole BLAS pool is reported beside it.
-    out = {}
-    try:
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1):
-            k1 = int(max(3, min(400, 0.6 * seconds / max(per, 1e-6))))
-            r1 = ref_admm(minx, minz, dict(base, maxiters=k1))
-        out = dict(value=k1 / r1["runtime"], unit="iterations/s", cores=1, kind="port",
-                   sample=f"{k1} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
-                          f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves, factor taken from the GPU setup), "
-                          f"BLAS limited to one thread; loop only, as results.runtime")
-    except Exception as exc:  # threadpoolctl missing: the pool-wide number below is all there is
-        out = dict(value=None, unit="iterations/s", cores=1, kind="port", error=repr(exc))
-    k = int(max(3, min(300, 0.4 * seconds / max(per, 1e-6))))
-    r = ref_admm(minx, minz, dict(base, maxiters=k))
-    out["blas_pool"] = dict(value=k / r["runtime"], unit="iterations/s", threads=int(threads),
-                            sample=f"{k} iterations with the BLAS pool of {int(threads)} threads: the triangular solves "
+    with threadpool_limits(limits=cores):
+        t0 = time.perf_counter()
+        Dts = D.T @ s
+        if own_factor:
+            factor = sla.cholesky(D.T @ D + rho * np.eye(n), lower=True, check_finite=False)  # lasso.m:168
+            out["setup_seconds"] = time.perf_counter() - t0
+            out["setup_note"] = f"D'D + chol on the host, BLAS pool limited to the {cores} usable cores (lasso.m:160-176)"
+        else:
+            factor = gpu_factor
+        args = dict(D=D, Dts=Dts, L=factor, U=factor.T, m=m, n=n, parallel=0, rho=rho)
+        args["lambda"] = lam
+        minx, minz, _ = ref_getproxops("LASSO", args)
+        if gpu_hist is not None:
+            k = int(gpu_hist["steps"])
+            obj = lambda x, z: 0.5 * float(np.sum((D @ x - s) ** 2)) + lam * float(np.sum(np.abs(z)))  # lasso.m:227
+            ref = ref_admm(minx, minz, dict(base, maxiters=k, objevals=1, obj=obj))
+            keys = ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals")
+            errs = {key: _hist_err(gpu_hist[key], ref[key]) for key in keys}
+            out["_parity"] = {"iters": k, "max_rel": errs, "max": max(errs.values()), "tolerance": 1e-6,
+                              "factor": "oracle's own (host BLAS/LAPACK)" if own_factor else "taken from the GPU setup",
+                              "what": "engine histories of the first iterations (objevals=1) against the oracle's "
+                                      "loop on the same D, s, lambda; max-norm relative error per history"}
+        t0 = time.perf_counter()
+        ref_admm(minx, minz, dict(base, maxiters=2))
+        per = (time.perf_counter() - t0) / 2
+    with threadpool_limits(limits=1):
+        k1 = int(max(3, min(400, 0.6 * seconds / max(per, 1e-6))))
+        r1 = ref_admm(minx, minz, dict(base, maxiters=k1))
+    out.update(value=k1 / r1["runtime"],
+               sample=f"{k1} iterations of the same {m}x{n} lasso loop (oracle restatement of admm.m:496-743 + "
+                      f"getProxOps.m:1192-1206, SciPy/LAPACK triangular solves), BLAS limited to one thread; loop "
+                      f"only, as results.runtime; restatement, not MATLAB")
+    with threadpool_limits(limits=cores):
+        k = int(max(3, min(300, 0.4 * seconds / max(per, 1e-6))))
+        r = ref_admm(minx, minz, dict(base, maxiters=k))
+    out["blas_pool"] = dict(value=k / r["runtime"], unit="iterations/s", threads=int(cores),
+                            sample=f"{k} iterations with a BLAS pool of {int(cores)} threads: the triangular solves "
                                    f"barely thread, so this is about the single-thread number")
-    if out.get("value") is None:
-        out["value"], out["cores"] = out["blas_pool"]["value"], int(threads)
     return out
+
+
+def profile_classes(eng, L, run):
+    """HIP-event time of every kernel class (admm_engine_kernel_time) over one short extra run with profiling on --
+    separate from the timed run, so the event records never sit inside a leg's timing."""
+    eng.set_profiling(True)
+    run()
+    eng.set_profiling(False)
+    names = {L.K_XSOLVE: "xsolve", L.K_GEMV_N: "gemv_n", L.K_GEMV_T: "gemv_t", L.K_PROX: "prox", L.K_FINALIZE: "finalize"}
+    out = {}
+    for k, name in names.items():
+        ms, cnt = eng.kernel_time(k)
+        if cnt:
+            out[name] = {"avg_ms": ms / cnt, "launch_groups": cnt}
+    return out
+
+
+def leg_roofline(kernel, alg_bytes, avg_ms, bound="hbm", **extra):
+    gbs = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
+    return dict({"bound": bound, "kernel": kernel, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": gbs / HBM_PEAK_GBS if gbs else None}, **extra)
 
 
 def other_configs(ap, L, device, steps):
@@ -172,6 +257,12 @@ def other_configs(ap, L, device, steps):
                                       "algorithmic_GB_per_iter": passes * 8.0 * n / 1e9,
                                       "achieved_GBs": passes * 8.0 * n * s.steps / dt / 1e9,
                                       "frac": passes * 8.0 * n * s.steps / dt / 1e9 / HBM_PEAK_GBS}
+    cls = profile_classes(tv, L, lambda: tv.run(maxiters=64, domaxiters=1, record_history=0))
+    res["totalvariation_16777216"]["kernel_classes"] = cls
+    if "xsolve" in cls:
+        res["totalvariation_16777216"]["roofline"] = leg_roofline(
+            "tv_direct_kernel (one launch per iteration: x-solve, z/u update on the compact state, partial norms)",
+            passes * 8.0 * n, cls["xsolve"]["avg_ms"])
     tv.close()
     # config 5 as literally written: anisotropic TV of a 4096 x 4096 IMAGE, no cached factor -- an engine-side
     # extension (the reference's solver is 1-D); own oracle, see tests/test_gpu_tv2d.py.  Two x-updates:
@@ -205,27 +296,57 @@ def other_configs(ap, L, device, steps):
         res["totalvariation2d_4096x4096" + tag] = dict(
             {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3, "algorithmic_GB_per_iter": gb,
              "achieved_GBs": gb * s2.steps / dt2, "frac": gb * s2.steps / dt2 / HBM_PEAK_GBS}, **extra)
+        if xs != L.XSOLVE_CG:
+            cls = profile_classes(tv2, L, lambda: tv2.run(maxiters=32, domaxiters=1, record_history=0))
+            res["totalvariation2d_4096x4096" + tag]["kernel_classes"] = cls
+            if "xsolve" in cls and "prox" in cls:
+                res["totalvariation2d_4096x4096" + tag]["roofline"] = {
+                    "spectral_solve": leg_roofline("dct_cols_forward + tv2d_rows_green + dct_cols_inverse (3 launches)",
+                                                   6.0 * 8.0 * npix, cls["xsolve"]["avg_ms"], bound="hbm+infinity_cache"),
+                    "fused_pass": leg_roofline("tv2d_fused_kernel", 7.0 * 8.0 * npix, cls["prox"]["avg_ms"])}
         tv2.close()
     return res
 
 
-def consensus_config4(ap, L, p, rho, device, steps):
-    """BASELINE config 4's data layout on ONE GPU: the config-2 matrix split by slicemaker(0, 8, m) into 8 row slices
-    (lasso.m:196-208), all local -- 8 cached factors, 8 lower-triangle x-solves per iteration, no collective."""
-    m = p["D"].shape[0]
-    sl = ap.errorcheck.slicemaker(0, 8, m)
-    cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, slices=sl, device=device)
-    k = max(50, steps // 4)
-    cons.run(maxiters=3, domaxiters=1, record_history=0, rho=rho, stopcond="both")
-    t0 = time.perf_counter()
-    s = cons.run(maxiters=k, domaxiters=1, record_history=0, rho=rho, stopcond="both")
-    dt = time.perf_counter() - t0
+def consensus_leg(ap, L, a, dist, p, rho, device, comm, rank, world, m_global, xs):
+    """BASELINE config 4: consensus lasso over the 8 row slices slicemaker(0, 8, m) gives (lasso.m:196-208,
+    getProxOps.m:383-442, 1217-1343) -- the SAME 8-slice problem at every N: rank r holds 8/N local slices, each with its
+    own x_k, u_k and cached factor; per iteration 8/N lower-triangle x-solves per GPU and (N > 1) ONE all-reduce of
+    [sum x_k; sum u_k; q] = 2n + 1 doubles."""
     n = p["D"].shape[1]
-    gb = 8 * 4.0 * n * (n + 1) / 1e9  # 8 slices x lower triangle of an n x n inverse
-    out = {"workload": f"consensus lasso, 8 local row slices of {int(sl[0])} x {n} (config 4 on one GPU)",
-           "iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3, "algorithmic_GB_per_iter": gb,
-           "achieved_GBs": gb * s.steps / dt, "frac": gb * s.steps / dt / HBM_PEAK_GBS,
-           "setup_seconds": cons.setup_seconds}
+    sl8 = [int(v) for v in ap.errorcheck.slicemaker(0, 8, m_global)]
+    if 8 % world != 0:
+        return {"skipped": f"8 slices do not divide over {world} ranks"}
+    per = 8 // world
+    mine = sl8[rank * per:(rank + 1) * per]
+    assert sum(mine) == p["D"].shape[0], (mine, p["D"].shape)
+    cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, slices=mine, xsolve=xs,
+                     device=device, comm=comm)
+    k = max(50, a.steps // 4)
+    timed_run(cons, dist, 3, rho=rho, stopcond="both")
+    dt, _ = timed_run(cons, dist, k, rho=rho, stopcond="both")
+    cons.set_profiling([L.K_XSOLVE, L.K_PROX])
+    timed_run(cons, dist, 20, rho=rho, stopcond="both")
+    cons.set_profiling(False)
+    xs_ms, xs_cnt = cons.kernel_time(L.K_XSOLVE)
+    px_ms, px_cnt = cons.kernel_time(L.K_PROX)
+    info = cons.info()
+    gb_gpu = per * 4.0 * n * (n + 1) / 1e9  # per GPU: 8/N slices x lower triangle of an n x n inverse
+    xs_avg = xs_ms / max(1, xs_cnt)
+    out = {"workload": f"consensus lasso, 8 row slices of {sl8[0]} x {n} in total, {per} per GPU (config 4)",
+           "slices_total": 8, "slices_per_gpu": per, "iters_per_s": k / dt, "ms_per_step": dt / k * 1e3,
+           "algorithmic_GB_per_iter_per_gpu": gb_gpu, "achieved_GBs_per_gpu": gb_gpu * k / dt,
+           "frac": gb_gpu * k / dt / HBM_PEAK_GBS,
+           "collectives_per_iter": 1 if world > 1 else 0, "allreduce_doubles_per_iter": (2 * n + 1) if world > 1 else 0,
+           "roofline": {"bound": "hbm+infinity_cache", "kernel": "symv_lower_batch_fin_kernel (the local slices' x-solves "
+                        "as one launch)", "avg_launch_ms": xs_avg, "launches": xs_cnt,
+                        "algorithmic_bytes_per_launch": gb_gpu * 1e9,
+                        "achieved": gb_gpu / (xs_avg * 1e-3) if xs_cnt else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gb_gpu / (xs_avg * 1e-3) / HBM_PEAK_GBS if xs_cnt else None,
+                        "llc_resident_bytes": info["xsolve_cacheable_bytes"],
+                        "tail_ms_per_iter": dt / k * 1e3 - xs_avg if xs_cnt else None,
+                        "update_kernels_avg_ms": px_ms / max(1, px_cnt)},
+           "setup_seconds": max_over_ranks(dist, cons.setup_seconds)}
     cons.close()
     return out
 
@@ -241,9 +362,17 @@ def _svm_configs(ap, L, device, res):
         t0 = time.perf_counter()
         s = svm.run(**kw)
         dt = time.perf_counter() - t0
+        mb = 16.0 * m * 400 / 1e6
         res[f"linearsvm_{m}x400"] = {"iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3,
-                                     "algorithmic_MB_per_iter": 16.0 * m * 400 / 1e6,
-                                     "note": "L2/MALL-resident: latency-bound, HBM fraction not meaningful"}
+                                     "algorithmic_MB_per_iter": mb,
+                                     "achieved_GBs": mb * 1e6 * s.steps / dt / 1e9,
+                                     "frac": mb * 1e6 * s.steps / dt / 1e9 / HBM_PEAK_GBS,
+                                     "two_launch_iteration": bool(svm.info()["unwrapped_fused"]),
+                                     "note": ("D and pinv(D) (2 x %.0f MB) sit in the 256 MB Infinity Cache: latency-bound, "
+                                              "the fraction is an effective rate" % (mb / 2)) if mb < 200 else
+                                             ("D (%.0f MB) is read twice per iteration (D*x, D'*[..]) and only partly "
+                                              "cache-resident: effective rate of both passes" % (mb / 2))}
+        res[f"linearsvm_{m}x400"]["kernel_classes"] = profile_classes(svm, L, lambda: svm.run(**dict(kw, maxiters=64)))
         svm.close()
 
 
@@ -252,7 +381,7 @@ def _leg(name):
     print(f"bench.py: leg {name}", file=sys.stderr, flush=True)
 
 
-def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out):
+def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out, m_global):
     """The A-streaming legs (lad.m, matrix-free lasso) on the same D, s, and configs 3 / 5 at N = 1."""
     _leg("a_streaming (lad)")
     # A-streaming iteration on the same D, s: lad.m (x = R'\(R\(D'(s+z-u))), z = soft(Dx+u-s)) --
@@ -337,25 +466,15 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
                           "setup_seconds": max_over_ranks(dist, mf.setup_seconds)}
     mf.close()
 
-    if world > 1:
-        # config 4: consensus lasso (getProxOps.m:383-442, 1217-1343), one row slice per GPU: own x_k, u_k and
-        # factor chol(D_k'D_k + rho I) per rank, ONE all-reduce of [sum x_k; sum u_k] (2n doubles) per iteration
-        cons = ap.Engine(L.PROB_LASSO_CONSENSUS, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=xs, device=local,
-                         comm=comm, slices=[hi - lo])
-        k4 = max(50, a.steps // 4)
-        timed_run(cons, dist, 2, rho=rho, stopcond="both")
-        dt4, _ = timed_run(cons, dist, k4, rho=rho, stopcond="both")
-        out["consensus_lasso"] = {"workload": f"consensus lasso, {world} row slices of {hi - lo} x {n}, one per GPU",
-                                  "iters_per_s": k4 / dt4, "ms_per_step": dt4 / k4 * 1e3,
-                                  "allreduce_doubles_per_iter": 2 * n + 1, "collectives_per_iter": 1,
-                                  "setup_seconds": max_over_ranks(dist, cons.setup_seconds)}
-        cons.close()
+    _leg("consensus_lasso (config 4: 8 slices in total at every N)")
+    rank = comm.rank if comm is not None else 0
+    out["consensus_lasso"] = consensus_leg(ap, L, a, dist, p, rho, local, comm, rank, world, m_global, xs)
     if world == 1:
         _leg("other_configs (tv, tv2d, svm)")
         out["other_configs"] = other_configs(ap, L, local, a.steps)
         _svm_configs(ap, L, local, out["other_configs"])
-        _leg("consensus_lasso_8_local_slices (config 4 on one GPU)")
-        out["other_configs"]["consensus_lasso_8x12500x10000"] = consensus_config4(ap, L, p, rho, local, a.steps)
+        # the same object under its round-2 name
+        out["other_configs"][f"consensus_lasso_8x{m_global // 8}x{n}"] = out["consensus_lasso"]
 
 
 def main():
@@ -389,6 +508,13 @@ def main():
             transport = "shm"
             comm = parallel.init_from_torch(dist, device=local, transport=transport)
         lo, hi = parallel.my_rows(m, comm)
+        if 8 % world == 0:
+            # config 4 is an 8-slice consensus problem at EVERY N: rank r owns slices [r*8/N, (r+1)*8/N) of
+            # slicemaker(0, 8, m) (errorcheck.m:249-259) and, for every other leg, exactly those rows
+            sl8 = [int(v) for v in ap.errorcheck.slicemaker(0, 8, m)]
+            per = 8 // world
+            lo = sum(sl8[:rank * per])
+            hi = lo + sum(sl8[rank * per:(rank + 1) * per])
         # what the engine's communicator itself reports (a SCALE record is self-checking: ranks and transport)
         import ctypes as _C
         _r, _n, _t = _C.c_int(), _C.c_int(), _C.c_int()
@@ -447,6 +573,16 @@ def main():
                    if a.xsolve == "inverse" else None)
     xs_avg_ms = xs_ms / max(1, xs_cnt)
     achieved = alg_bytes / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
+    # The Infinity Cache's share, said out loud: the engine reads `llc` bytes of the matrix with default loads so that
+    # they stay in the 256 MB last-level cache from one iteration to the next (symv.hip: split cache policy) and streams
+    # the rest non-temporally.  `achieved` / `frac` are the effective rate of the kernel against the HBM peak;
+    # `frac_hbm_only` prices only the bytes that can come from HBM itself.
+    einfo = eng.info()
+    llc = int(einfo["xsolve_cacheable_bytes"])
+    streamed = int(einfo["xsolve_stream_bytes"])
+    scale = alg_bytes / max(1.0, float(llc + streamed))  # tile padding: stored bytes -> algorithmic bytes
+    hbm_est = streamed * scale if llc + streamed > 0 else alg_bytes
+    hbm_only = hbm_est / (xs_avg_ms * 1e-3) / 1e9 if xs_cnt else 0.0
     out = {
         "metric": "ADMM iterations/sec (lasso 100k x 10k, fp64)", "value": value, "unit": "iterations/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -455,13 +591,36 @@ def main():
                                f"domaxiters=1, objevals=0, xsolve={a.xsolve}",
                    "rows": m, "cols": n, "rho": rho, "parallelism": f"rows{world}", "collective": transport,
                    "communicator": comm_report},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm+infinity_cache" if llc > 0 and streamed > 0 else "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": xs_avg_ms, "launches": xs_cnt},
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": xs_avg_ms, "launches": xs_cnt,
+                     "llc_resident_bytes": llc, "hbm_bytes_est": hbm_est, "achieved_hbm_only": hbm_only,
+                     "frac_hbm_only": hbm_only / HBM_PEAK_GBS,
+                     "traffic_source": "profiles/*_traffic.json (committed rocprofv3 --pmc passes of this script; the "
+                                       "FETCH counter sits between L2 and the fabric and counts Infinity-Cache hits)"},
+        "scaling_basis": {
+            "value": "flat in N by design: the cached-factor lasso loop replicates x, z, u and the n x n factor on every "
+                     "rank and exchanges nothing per iteration (D enters only the setup and the objective)",
+            "strong_scaling_legs": ["a_streaming", "objevals1_literal", "matrix_free"],
+            "per_gpu_bytes_per_iter": "16*(m/N)*n (a_streaming, matrix_free per inner iteration), 8*(m/N)*n "
+                                      "(objevals1_literal)",
+            "consensus_lasso": "the same 8-slice problem at every N, 8/N slices per GPU: per-GPU bytes 8/N * 4n(n+1)",
+            "collectives_per_iter": {"headline": 0, "a_streaming": 1 if world > 1 else 0,
+                                     "objevals1_literal": 1 if world > 1 else 0,
+                                     "matrix_free": "1 per inner CG iteration" if world > 1 else 0,
+                                     "consensus_lasso": 1 if world > 1 else 0},
+            "allreduce_doubles": {"a_streaming": 3 * n + 16, "objevals1_literal": 1, "matrix_free": n,
+                                  "consensus_lasso": 2 * n + 1}},
         "setup_seconds": setup_s, "datagen_seconds": t_gen,
         "iters_per_s_without_event_timing": a.steps / dt_plain,
         "achieved_hbm_GBs_whole_iteration": (alg_bytes + 8.0 * 21 * n) * a.steps / dt / 1e9,
     }
+
+    if a.steps < 100:  # the driver's --steps 20 times 1.5 ms, of which 43 us are per-run fixed cost: also the 200-step rate
+        dt200, _ = timed_run(eng, dist, 200, rho=rho)
+        out["value_200"] = 200 / dt200
+        out["ms_per_step_200"] = dt200 / 200 * 1e3
 
     # the same loop with the reference's histories on (admm.m:608-610 always records xvals/zvals/uvals)
     kh = max(20, min(a.steps, 200))
@@ -490,20 +649,38 @@ def main():
                                     "if they agreed to 1e-11 relative"}
 
     factor = None
+    gpu_hist = None
     if not a.no_cpu_baseline and world == 1:
-        factor = eng.fetch(L.F_FACTOR, n * n, (n, n))
+        if a.cpu_factor == "gpu":
+            factor = eng.fetch(L.F_FACTOR, n * n, (n, n))
+        if a.parity_iters > 0:  # histories of the first iterations from x = z = u = 0, for the parity object
+            kp = a.parity_iters
+            sp_ = eng.run(maxiters=kp, domaxiters=1, record_history=1, rho=rho, objevals=1)
+            gpu_hist = {"steps": int(sp_.steps),
+                        "xvals": eng.fetch(L.F_XVALS, n * kp, (n, kp)), "zvals": eng.fetch(L.F_ZVALS, n * kp, (n, kp)),
+                        "uvals": eng.fetch(L.F_UVALS, n * kp, (n, kp)), "pnorm": eng.fetch(L.F_PNORM, kp),
+                        "dnorm": eng.fetch(L.F_DNORM, kp), "perr": eng.fetch(L.F_PERR, kp),
+                        "derr": eng.fetch(L.F_DERR, kp), "objevals": eng.fetch(L.F_OBJEVALS, kp)}
     eng.close()
 
     if n == 10000 and m == 100000 and world == 1:  # PMC bytes of one D*x + one D'*[3 rhs] launch
         out["_pmc_pair"] = pmc_bytes("void admm::gemv_n_kernel", "void admm::gemv_t_kernel<3")
     if not a.no_extras:
         try:
-            side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out)
+            side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out, m)
         except Exception as exc:  # the side measurements must never cost the headline line
             out["extras_error"] = repr(exc)
 
     if not a.no_cpu_baseline and world == 1 and rank == 0:
-        out["cpu_baseline"] = cpu_baseline(p, factor, a.cpu_seconds, rho)
+        _leg("cpu_baseline + parity (host)")
+        try:
+            cb = cpu_baseline(ap, p, factor, gpu_hist, a.cpu_seconds, rho, own_factor=(a.cpu_factor == "own"))
+            par = cb.pop("_parity", None)
+            out["cpu_baseline"] = cb
+            if par is not None:
+                out["parity"] = par
+        except Exception as exc:  # a host-side failure must not cost the measured GPU line
+            out["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": 1, "kind": "port", "error": repr(exc)}
     out.pop("_pmc_pair", None)
     if rank == 0:
         print(json.dumps(out))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADMM_ABI_VERSION 3
+#define ADMM_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -291,6 +291,11 @@ typedef struct admm_engine_info_t {
   double probe_err_inverse;  /* max-norm relative forward error of each form on (L L') x = L (L' x0); NaN if not probed */
   double probe_err_trsv;
   double probe_diff;         /* max-norm relative difference of the two forms on an unstructured right-hand side */
+  /* bytes of the x-solve's matrix operand one iteration reads, split by cache policy (ABI 4): read with default loads
+   * (meant to stay in the 256 MB Infinity Cache from one iteration to the next) / streamed non-temporally from HBM.
+   * Consensus lasso: summed over the local slices.  0 / 0 where no n x n operand exists. */
+  int64_t xsolve_cacheable_bytes;
+  int64_t xsolve_stream_bytes;
 } admm_engine_info_t;
 int admm_engine_info(admm_engine* eng, admm_engine_info_t* info);
 /* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */

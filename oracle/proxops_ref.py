@@ -65,8 +65,17 @@ def getproxops(problem, args):
         D, Dt, DtD, s, lam = args["D"], args["Dt"], args["DtD"], args["s"], args["lambda"]
         Id = sp.identity(DtD.shape[0], format="csc")
 
-        def xmin(_x, z, u, rho):
-            return spla.spsolve((Id + rho * DtD).tocsc(), s + rho * (Dt @ (z - u)))
+        def xmin(_x, z, u, rho):  # 1044-1048: (I + rho*DtD) \ (s + rho*Dt*(z - u)), re-assembled on every call
+            rhs = s + rho * (Dt @ (z - u))
+            if args.get("banded", 0):
+                # oracle-side switch for n ~ 1e7: MATLAB's backslash on this SPD tridiagonal matrix IS a banded
+                # Cholesky solve; SuperLU (spsolve) computes the same x but needs minutes and tens of GB there.
+                M = (Id + rho * DtD).tocsc()
+                ab = np.zeros((2, M.shape[0]))
+                ab[0] = M.diagonal(0)
+                ab[1, :-1] = M.diagonal(-1)
+                return sla.solveh_banded(ab, rhs, lower=True, check_finite=False)
+            return spla.spsolve((Id + rho * DtD).tocsc(), rhs)
 
         return xmin, (lambda x, _z, u, rho: soft_threshold(u + D @ x, lam / rho)), extra
 
@@ -206,9 +215,13 @@ def _consensus_lasso(args):
         P = flat.reshape(P.shape, order="F")
         Li[k] = sla.cholesky(P, lower=True)
 
+    pre = args.get("_DtDi")  # oracle-side: slice Gram matrices a test has already formed on the host (same products)
     for k in range(N):  # 419-436
         mi = Di[k].shape[0]
-        DtDi[k] = Di[k].T @ Di[k] if mi >= n else Di[k] @ Di[k].T
+        if pre is not None:
+            DtDi[k] = pre[k]
+        else:
+            DtDi[k] = Di[k].T @ Di[k] if mi >= n else Di[k] @ Di[k].T
         refactor(k, st["rhoprev"])
 
     def xmin(_x, _z, _u, rho):  # 1217-1260

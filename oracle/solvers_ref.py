@@ -151,7 +151,7 @@ def totalvariation(s, lam, options=None):
     Dt = D.T.tocsr()
     DtD = (Dt @ D).tocsc()
     objective = lambda x, z: 0.5 * float(np.sum((x - s) ** 2)) + lam * float(np.sum(np.abs(x[1:] - x[:-1])))  # 134-135
-    args = dict(D=D, Dt=Dt, DtD=DtD, s=s)
+    args = dict(D=D, Dt=Dt, DtD=DtD, s=s, banded=options.pop("banded", 0))  # banded: oracle-side, see proxops_ref
     args["lambda"] = lam
     xmin, zmin, _ = getproxops("TotalVariation", args)
     options.update(A=D, At=Dt, B=-1, nB=n, c=0, m=n)  # 151-157
