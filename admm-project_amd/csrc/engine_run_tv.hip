@@ -331,6 +331,8 @@ int run_total_variation(admm_engine* e, RunState& rs, admm_run_summary* summary)
     ta.ftile = 256 * kTvDirectE - 2 * ta.margin;
     const double rr = o.rho / bstar;
     ta.green = 1.0 / (bstar * (1.0 - rr * rr));
+    ta.rpow[0] = rr;
+    for (int k = 1; k < 8; ++k) ta.rpow[k] = ta.rpow[k - 1] * rr;
   }
   double* tv_part = nullptr;  // per-tile partials of the fused kernel (one column per tile)
   bool tv_one_launch = false;

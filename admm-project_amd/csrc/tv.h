@@ -54,6 +54,8 @@ struct TvArgs {
   // direct form, compact dual state: z (read) and zo (written) hold v = z + u; state_in = 0 on a run's first iteration,
   // which reads z and u as given.  uo is not used.
   int32_t state_in;
+  // tv_direct2.h: r^1 .. r^8 (r = rho/b*), computed on the host so that they reach the kernel as scalar registers
+  double rpow[8];
 };
 constexpr int kTvGroup = 64;
 constexpr int kTvDirectE = 8;  // positions per thread of tv_direct_kernel (tile = 256 * kTvDirectE window positions)

@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "tv.h"
+#include "tv_direct2.h"
 #include "finalize_device.h"
 
 namespace admm {
@@ -964,12 +965,90 @@ __global__ __launch_bounds__(kBlock, 4) void tv_direct_kernel(TvArgs a, FinArgs 
     a.part[tid * a.part_stride + tile_id] = ((sred[0][tid] + sred[1][tid]) + sred[2][tid]) + sred[3][tid];
 }
 
+// ---------------------------------------------------------------- the same iteration, thread-owned 8-position runs
+// tv_direct2.h: hierarchical exponential sums (2G + 4 LDS doubles per thread instead of ~130), 26 KB of LDS per tile,
+// 73 VGPRs: six tiles per CU, 72 us per iteration at n = 4096^2 where tv_direct_kernel takes 113 (dev/tv1d_bench.hip).
+// Both ends of the signal by mirror images -- no scan path.  Grid: [passenger] + tiles, the tiles that reach past an end
+// of the signal (element-wise loads: slow) dispatched first.  EXTRA = objective and / or history columns compiled in.
+template <bool NTS, bool VIN, bool EXTRA>
+__global__ __launch_bounds__(kBlock, (EXTRA || !VIN) ? 4 : 6) void tv_direct2_kernel(TvArgs a, FinArgs fin,
+                                                                            const Ctrl* __restrict__ ctrl) {
+  // every kernel argument the tile path reads, requested together with the control block's address (see tv_direct_kernel)
+  asm volatile("" ::"s"(a.n), "s"(a.z), "s"(a.u), "s"(a.s), "s"(a.zo), "s"(a.part), "s"(a.ftile), "s"(a.margin),
+               "s"(a.deferred), "s"(a.part_stride), "s"(a.thresh), "s"(a.rho), "s"(a.green), "s"(a.rpow[0]),
+               "s"(a.rpow[7]), "s"(a.objevals), "s"(a.xhist), "s"(ctrl));
+  // The stop flag is asked for here and tested behind the tile's loads (nothing is stored before that): in front of them
+  // the test costs every tile one more memory round trip.  A scalar load issued and waited for by hand; the register
+  // holds garbage between the two statements, and nothing may read it there -- tests/test_abi_and_host.py checks the
+  // disassembly of the shipped library for exactly that, tests/test_gpu_ops.py runs the kernel with the flag set.
+  int32_t stop;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(stop) : "s"(ctrl));
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  if (a.deferred && blockIdx.x == 0) {  // the passenger (dispatched first): tail of the PREVIOUS iteration
+    if (ctrl->stop || !a.fin_pending) return;  // (its own read: `stop` must not be needed before the tiles' loads)
+    {
+      const int slot = tid >> 4, sub = tid & 15;
+      double v = 0.0;
+      if (slot < S_COUNT) {
+        const double* __restrict__ ps = a.prev_part + slot * a.part_stride;
+        for (int32_t b0 = 0; b0 < a.prev_ntiles; b0 += 256) {
+          double w[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int32_t b = b0 + sub + 16 * k;
+            w[k] = ps[b < a.prev_ntiles ? b : a.prev_ntiles - 1];
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (b0 + sub + 16 * k < a.prev_ntiles) v += w[k];
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (slot < S_COUNT && sub == 0) a.slots16[slot] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    finalize_body<false>(fin);  // fin.slots_reduced = a.slots16
+    return;
+  }
+  const unsigned bid = a.deferred ? blockIdx.x - 1u : blockIdx.x;
+  const unsigned ntiles = a.deferred ? gridDim.x - 1u : gridDim.x;
+  // the last two tiles, then tile 0, then the rest in order
+  const unsigned tile_id = bid < 2u && ntiles > 2u ? ntiles - 1u - bid : (ntiles > 2u ? bid - 2u : bid);
+  const int64_t it = a.deferred ? a.iter_host : ctrl->iter;
+  tv2_tile<4, VIN, NTS, EXTRA>(a, tile_id, it, lds, [&]() -> bool {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(stop));
+    return stop != 0;  // (uniform)
+  });
+}
+
 int tv_direct_margin(const TvArgs& a) { return static_cast<int>(round_up(static_cast<int64_t>(a.halo) + 8, 8)); }
 bool tv_direct_ok(const TvArgs& a) { return a.elems == 8 && a.halo >= 2 && tv_direct_margin(a) <= 256 && a.n >= 2; }
 
 // a.ftile = 2048 - 2*a.margin, a.green = 1/(b*(1 - r^2)); grid = tiles (+ 1 passenger when a.deferred)
 void launch_tv_direct(const TvArgs& a, const FinArgs& fin, const Ctrl* ctrl, hipStream_t stream) {
   const int64_t ntiles = ceil_div(a.n, a.ftile);
+  // thread-owned runs (tv_direct2.h) unless the signal is shorter than two margins (the mirror images of an end would
+  // reach past the other end) or ADMM_HIP_TV_DIRECT1 asks for the first form
+  const bool first_form = std::getenv("ADMM_HIP_TV_DIRECT1") != nullptr;
+  if (!first_form && a.n >= 2 * static_cast<int64_t>(a.margin)) {
+    const size_t lds2 = sizeof(double) * tv2_lds_doubles<4>();
+    const dim3 grid2(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block2(kBlock);
+    const bool nts2 = stream_hint(8 * 8 * a.n), extra = a.objevals || a.xhist;
+#define ADMM_TV2(NTS_, VIN_, EXTRA_) \
+  hipLaunchKernelGGL((tv_direct2_kernel<NTS_, VIN_, EXTRA_>), grid2, block2, lds2, stream, a, fin, ctrl)
+    if (a.state_in) {
+      if (nts2) { if (extra) ADMM_TV2(true, true, true); else ADMM_TV2(true, true, false); }
+      else { if (extra) ADMM_TV2(false, true, true); else ADMM_TV2(false, true, false); }
+    } else {
+      if (nts2) { if (extra) ADMM_TV2(true, false, true); else ADMM_TV2(true, false, false); }
+      else { if (extra) ADMM_TV2(false, false, true); else ADMM_TV2(false, false, false); }
+    }
+#undef ADMM_TV2
+    return;
+  }
   constexpr int kCap = kTvDirectE * kBlock;
   const size_t lds = 2 * static_cast<size_t>(kCap + (kCap >> (kTvDirectE == 8 ? 3 : 2)) + 1) * sizeof(double);
   const dim3 grid(static_cast<unsigned>(ntiles) + (a.deferred ? 1u : 0u)), block(kBlock);

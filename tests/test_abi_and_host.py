@@ -212,3 +212,59 @@ def test_solver_argument_errors_mirror_the_reference(ap):
         ap.totalvariation2d(z(7), 1.0, {})
     with pytest.raises(TypeError, match="not a struct"):
         ap.linearprogram(z(3), z((2, 3)), z(2), "options")
+
+
+def _gfx950_disassembly(tmp_path, symbol_part):
+    """Disassembly (llvm-objdump) of the shipped library's gfx950 kernels whose mangled name contains `symbol_part`."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    so = tmp_path / "libadmm_hip.so"
+    shutil.copy(os.path.join(ROOT, "admm-project_amd", "libadmm_hip.so"), so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    kernels = {}
+    for f in sorted(tmp_path.iterdir()):
+        if "amdgcn" not in f.name:
+            continue
+        out = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True).stdout
+        name = None
+        for line in out.splitlines():
+            if line.endswith(">:"):
+                name = line.split("<")[1][:-2]
+                name = name if symbol_part in name else None
+                if name:
+                    kernels[name] = []
+            elif name and line.strip():
+                kernels[name].append(line.split("//")[0].strip())
+    return kernels
+
+
+def test_hand_issued_stop_load_is_not_read_before_its_wait(tmp_path):
+    """tv.hip: the 1-D TV kernels ask for ctrl->stop with a hand-written `s_load_dword` at the top and wait for it
+    (`s_waitcnt lgkmcnt(0)`) behind the tile's vector loads; in between the compiler believes the register holds a
+    value.  The hardware does not interlock a scalar load: any instruction that READ the register in between (a copy,
+    a spill) would see garbage and could make a whole tile return without storing its iterate.  Checked on the code
+    that ships: between the load and the first full scalar-memory wait nothing mentions the register."""
+    import re
+
+    kernels = _gfx950_disassembly(tmp_path, "tv_direct")
+    assert any("tv_direct2_kernel" in k for k in kernels) and any("tv_direct_kernel" in k for k in kernels)
+    checked = 0
+    for name, ins in kernels.items():
+        loads = [(i, s) for i, s in enumerate(ins[:120]) if re.match(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0$", s)]
+        assert loads, f"{name}: the hand-issued stop load was not found"
+        for i, s in loads:
+            reg = int(re.match(r"s_load_dword s(\d+),", s).group(1))
+            for later in ins[i + 1:]:
+                if later.startswith("s_waitcnt") and ("lgkmcnt(0)" in later or later == "s_waitcnt 0"):
+                    break
+                singles = [int(v) for v in re.findall(r"\bs(\d+)\b", later)]
+                ranges = [(int(a), int(b)) for a, b in re.findall(r"s\[(\d+):(\d+)\]", later)]
+                assert reg not in singles and not any(a <= reg <= b for a, b in ranges), (name, s, later)
+            else:
+                raise AssertionError(f"{name}: no scalar-memory wait behind the stop load")
+            checked += 1
+    assert checked >= len(kernels)

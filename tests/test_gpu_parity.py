@@ -589,6 +589,36 @@ def test_tv_fused_equals_three_kernel_form_large(gpu, monkeypatch):
         _close(k, a[k], b[k], 1e-11)
 
 
+@pytest.mark.parametrize("n", [112, 113, 127, 1935, 1936, 1937, 3 * 1936 - 1, 3 * 1936, 3 * 1936 + 1, 3 * 1936 + 7,
+                               3 * 1936 + 8, 3 * 1936 + 9, 5 * 1936 + 57, 40009])
+@pytest.mark.parametrize("rho", [1.0, 7.0])
+def test_total_variation_thread_run_kernel_tile_boundaries(gpu, n, rho):
+    """tv_direct2_kernel (tv_direct2.h): signal lengths around the tile size (1936 owned positions at rho = 1), around
+    the 8-position runs of a thread (the one run the end of the signal cuts), and down to two window margins -- both
+    ends by mirror images, one tile or several; with and without history / objective (two instantiations), stopping by
+    tolerance (launches enqueued behind the stop must leave the state alone) and after a fixed count."""
+    p = gpu.synth.tv_problem(n % 89, n)
+    for o in (dict(objevals=1, rho=rho, maxiters=9, domaxiters=1), dict(rho=rho)):
+        ref = S.totalvariation(p["s"], p["lam"], dict(o))
+        _compare(gpu.totalvariation(p["s"], p["lam"], dict(o)), ref)
+        got = gpu.totalvariation(p["s"], p["lam"], dict(o, record_history=0))
+        assert got["steps"] == ref["steps"]
+        for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr"):
+            _close(k, got[k], ref[k], TOL, None)
+
+
+def test_total_variation_thread_run_kernel_equals_first_form(gpu, monkeypatch):
+    """the two direct kernels on 3e6 + 1 elements (odd: the cut run; 1550 tiles), 1e-11"""
+    n = 3_000_001
+    p = gpu.synth.tv_problem(5, n)
+    o = dict(maxiters=12, domaxiters=1, objevals=1, record_history=0)
+    a = gpu.totalvariation(p["s"], p["lam"], dict(o))
+    monkeypatch.setenv("ADMM_HIP_TV_DIRECT1", "1")
+    b = gpu.totalvariation(p["s"], p["lam"], dict(o))
+    for k in ("pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, a[k], b[k], 1e-11)
+
+
 # ---------------------------------------------------------------------------- golden fixtures
 def _opts(npz):
     o = {}
