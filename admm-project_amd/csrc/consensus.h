@@ -70,5 +70,9 @@ int launch_cons_gather_sum(int64_t n, int64_t ldn, int32_t K, const double* npar
 int launch_cons_sum(int64_t n, int64_t ldn, int32_t K, const double* X, const double* U, double* sums,
                     const double* center, double* qpart, const Ctrl* ctrl, hipStream_t stream);
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+// gather + update in one launch (unsharded runs whose slices all left partial rows; a.K <= 16)
+bool cons_gather_update_ok(const ConsArgs& a);
+void launch_cons_gather_update(const ConsArgs& a, const double* npart, const double* tpart, int64_t pstride, int64_t ldp,
+                               int32_t ntile, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 
 }  // namespace admm

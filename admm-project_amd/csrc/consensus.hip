@@ -181,6 +181,140 @@ __global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const C
   }
 }
 
+// Unsharded consensus iteration tail as ONE launch: the slices' x_k are assembled from the partial rows the batched
+// lower-triangle x-solve left behind (as cons_gather_sum_kernel does), and the means, z, the u_k, the next right-hand
+// sides y_k and every partial sum follow in the same workgroup (as cons_update_kernel does) -- the K x n sums never
+// travel through memory and one launch boundary disappears.  Round 2 ran the gather as 79 workgroups (128 elements x 4
+// row slots at n = 10^4: a third of the CUs, 22.9 us for 52 MB); here a workgroup takes 32 elements and its 16 slots
+// are dealt to (slice, row range) pairs: 313 workgroups at n = 10^4, 20 loads in flight per thread -- 21.4 us for
+// gather + update (rocprof; 16 elements x 32 slots, one round of loads per thread on 625 workgroups: 25.7 us -- the
+// rows' 128-byte segments are too short for the memory system), and 579 -> 570 us per iteration with the launch gone.
+constexpr int kCuTile = 32, kCuSlots = 16;
+__global__ __launch_bounds__(kCuTile* kCuSlots) void cons_gather_update_kernel(
+    ConsArgs a, const double* __restrict__ npart, const double* __restrict__ tpart, int64_t pstride, int64_t ldp,
+    int32_t ntile, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double part[kCuSlots][kCuTile];
+  __shared__ double xs[kCuSlots][kCuTile], us[kCuSlots][kCuTile];
+  __shared__ double sred[kCuTile * kCuSlots / 64][S_COUNT];
+  const int64_t it = ctrl->iter;
+  const int e = threadIdx.x & (kCuTile - 1), slot = threadIdx.x / kCuTile;
+  const int32_t K = a.K;                  // <= kCuSlots (the launcher checks)
+  const int32_t SUB = kCuSlots / K;       // row ranges per slice
+  const int32_t kk = slot / SUB, sb = slot - kk * SUB;
+  const bool active = kk < K;
+  const int32_t P = ntile + 1, per = (P + SUB - 1) / SUB;
+  const int32_t p0 = sb * per, p1 = (p0 + per < P) ? p0 + per : P;
+  const double Nd = static_cast<double>(a.Ntot);
+  const double t = a.lambda / (a.rho * Nd);  // q11
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  const int64_t ntiles = (a.n + kCuTile - 1) / kCuTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t i = tile * kCuTile + e;
+    const int64_t ic = i < a.n ? i : a.n - 1;
+    const int32_t d = static_cast<int32_t>(ic / kCgTile);  // the x-solve's tile row of this element
+    // 1. this slot's share of the partial rows of its slice
+    double s = 0.0;
+    if (active) {
+      const double* __restrict__ nk = npart + static_cast<int64_t>(kk) * pstride;
+      const double* __restrict__ tk = tpart + static_cast<int64_t>(kk) * pstride;
+      for (int32_t p = p0; p < p1; p += kCgRows) {
+        double v[kCgRows];
+#pragma unroll
+        for (int r = 0; r < kCgRows; ++r) {
+          const int32_t pq = (p + r < p1) ? p + r : p1 - 1;
+          const double* src = (pq <= d) ? nk + static_cast<int64_t>(pq) * ldp : tk + static_cast<int64_t>(pq - 1) * ldp;
+          v[r] = src[ic];
+        }
+#pragma unroll
+        for (int r = 0; r < kCgRows; ++r)
+          if (p + r < p1) s += v[r];
+      }
+    }
+    const bool lead = active && sb == 0;  // the thread that owns (element, slice)
+    const double uold = lead ? a.U[kk * a.ldn + ic] : 0.0;
+    const double dts = lead ? a.Dts[kk * a.ldn + ic] : 0.0;
+    part[slot][e] = s;
+    __syncthreads();
+    // 2. x_k of every slice
+    double xk = 0.0;
+    if (lead) {
+      xk = part[slot][e];
+      for (int32_t j = 1; j < SUB; ++j) xk += part[slot + j][e];
+      xs[kk][e] = xk;
+      us[kk][e] = uold;
+    }
+    __syncthreads();
+    // 3. means and z (every thread, slice order: getProxOps.m:1281-1292)
+    double sx = 0.0, su = 0.0;
+    for (int32_t k = 0; k < K; ++k) {
+      su = su + us[k][e];
+      sx = sx + xs[k][e];
+    }
+    const double xave = sx / Nd, uave = su / Nd;
+    const double v = uave + xave;
+    const double q = fabs(v) - t;
+    const double pz = q > 0.0 ? q : 0.0;
+    const double z = (v > 0.0) ? pz : ((v < 0.0) ? -pz : 0.0 * pz);
+    // 4. u_k += x_k - z, the next y_k   (getProxOps.m:1296-1298, 1240)
+    if (lead && i < a.n) {
+      const double uk = uold + (xk - z);
+      a.X[kk * a.ldn + i] = xk;
+      a.U[kk * a.ldn + i] = uk;
+      a.Y[kk * a.ldn + i] = a.rho * (z - uk) + dts;
+      const double dd = xk - xave;
+      acc[S_R2] += dd * dd;  // lassonorms v(1)
+    }
+    // 5. the element's own state (getProxOps.m:1312-1326, 1335-1343)
+    if (slot == 0 && i < a.n) {
+      const double xprev = a.xave[i];
+      const double ub_old = a.ubar[i];
+      const double ub = (uave + xave) - z;  // mean over all slices of u_k + (x_k - z)
+      acc[S_AX2] += xave * xave;
+      const double dx = xave - xprev;
+      acc[S_G2] += dx * dx;
+      acc[S_U2] += ub * ub;
+      const double du = ub - ub_old;
+      acc[S_DU2] += du * du;
+      a.zc[i] = z;
+      a.xaveprev[i] = xprev;
+      a.xave[i] = xave;
+      a.ubar[i] = ub;
+      if (a.xhist) a.xhist[it * a.n + i] = xave;
+      if (a.zhist) a.zhist[it * a.n + i] = 0.0;  // q9
+      if (a.uhist) a.uhist[it * a.n + i] = ub;
+    }
+    __syncthreads();  // part / xs / us are reused by the next tile
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    double w = sred[0][s];
+#pragma unroll
+    for (int q = 1; q < kCuTile * kCuSlots / 64; ++q) w += sred[q][s];
+    a.part[s * kMaxPartBlocks + blockIdx.x] = w;
+  }
+}
+
+bool cons_gather_update_ok(const ConsArgs& a) { return a.K >= 1 && a.K <= kCuSlots; }
+
+void launch_cons_gather_update(const ConsArgs& a, const double* npart, const double* tpart, int64_t pstride, int64_t ldp,
+                               int32_t ntile, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  int64_t blocks = ceil_div(a.n, kCuTile);
+  if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
+  *nblk_out = static_cast<int>(blocks);
+  hipLaunchKernelGGL(cons_gather_update_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kCuTile * kCuSlots), 0, stream,
+                     a, npart, tpart, pstride, ldp, ntile, ctrl);
+}
+
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
   int64_t blocks = ceil_div(a.n, kBlock);
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;

@@ -99,7 +99,12 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
         }
       }
       const SymvPlan* gp = e->csyN ? &e->cslices[0].fac.planSy : nullptr;
-      if (shard) {
+      int nblk = 1;
+      const bool one_tail = !shard && gp && cons_gather_update_ok(ca) && std::getenv("ADMM_HIP_CONS_TWO_TAIL") == nullptr;
+      if (one_tail) {
+        TimerScope ts(e, ADMM_K_PROX);
+        launch_cons_gather_update(ca, e->csyN, e->csyT, e->cpstride, gp->ldp, gp->ntile, e->ctrl, &nblk, e->stream);
+      } else if (shard) {
         // X1 + X2 in ONE collective: [sum x_k; sum u_k; q] with q = sum_k ||x_k - xave_prev||^2 (consensus.hip)
         const int nq = gp ? launch_cons_gather_sum(n, ldn, K, e->csyN, e->csyT, e->cpstride, gp->ldp, gp->ntile, e->cX,
                                                    e->cU, e->csums, e->cxave, e->objpart, e->ctrl, e->stream)
@@ -112,8 +117,7 @@ int run_consensus_lasso(admm_engine* e, RunState& rs, admm_run_summary* summary)
       } else {
         launch_cons_sum(n, ldn, K, e->cX, e->cU, e->csums, nullptr, nullptr, e->ctrl, e->stream);
       }
-      int nblk = 1;
-      {
+      if (!one_tail) {
         TimerScope ts(e, ADMM_K_PROX);
         launch_cons_update(ca, e->ctrl, &nblk, e->stream);
       }
