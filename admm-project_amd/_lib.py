@@ -60,6 +60,10 @@ PROX_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_voi
                             C.c_int64, C.c_void_p)
 OPERATOR_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p)
 OBJ_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+ALTU_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                            C.c_void_p)
+NORMS_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                             C.c_double, C.c_void_p, C.c_void_p)
 
 
 class Options(C.Structure):
@@ -114,6 +118,7 @@ _SIGNATURES = {
                                                C.c_double, OPERATOR_CALLBACK, C.c_void_p]),
     "admm_engine_run": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary)]),
     "admm_engine_fetch": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "admm_engine_set_hooks": (C.c_int, [C.c_void_p, ALTU_CALLBACK, C.c_void_p, NORMS_CALLBACK, C.c_void_p]),
     "admm_engine_info": (C.c_int, [C.c_void_p, C.POINTER(EngineInfo)]),
     "admm_engine_setup_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "admm_engine_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -412,7 +412,7 @@ def _admm_adaptive(xminf, zming, options, prob):
 
     for i in range(1, N + 1):
         # closures without a "rho ~= rhoprev" branch keep their factor (xminLASSO, getProxOps.m:1192-1206)
-        o = dict(options, adaptive=0, convtest=0, stopcond="standard", maxiters=1, domaxiters=1, quiet=1, rho=rho,
+        o = dict(options, adaptive=0, convtest=0, stopcond="standard", maxiters=1, domaxiters=1, quiet=1, rho=rho, preprocess=None,
                  x0=x, z0=z, u0=u, record_history=0, stale_factor_ok=int(prob.rebuild is None))
         step = admm(xminf, zming, o)
         runtime += step["runtime"]
@@ -500,12 +500,28 @@ def admm(xminf, zming, options):
         user_obj = None  # the solver-supplied objective of this problem is engine-native (objevals switch)
     callbacks = dict(xmin=None if x_lib else xminf, zmin=None if z_lib else zming, obj=user_obj)
     use_callbacks = any(v is not None for v in callbacks.values())
-    for hook in ("altu", "specialnorms", "preprocess"):
+    # options.altu / options.specialnorms (admm.m:553-559, 612-616): getproxops' own hooks (consensus lasso) are
+    # engine-native; a caller's handle becomes a device callback (Engine.set_hooks)
+    hooks = {}
+    for hook in ("altu", "specialnorms"):
         h = options.get(hook)
         if h is None:
             continue
-        if not (isinstance(h, EngineHook) and h.problem is prob and h.name == hook):
-            raise NotImplementedError(f"options.{hook} (host callback) is not supported by the device loop")
+        if isinstance(h, EngineHook):
+            if not (h.problem is prob and h.name == hook):
+                raise ValueError(f"options.{hook} belongs to another getproxops call")
+        elif callable(h):
+            hooks[hook] = h
+        elif hook == "altu":  # admm.m:538 tests isfield only: anything else would fail at the call (553-559)
+            raise TypeError("options.altu is not a function handle")
+        # (a non-handle options.specialnorms is ignored: admm.m:612-613 tests isa(..., 'function_handle'))
+    if hooks and prob.kind == "lasso-consensus":
+        raise NotImplementedError("consensus lasso runs with the hooks of its own getproxops call (lasso.m:222-223)")
+    pre = options.get("preprocess")  # admm.m:473-476: called once, before the loop
+    if pre is not None and not isinstance(pre, EngineHook):
+        if not callable(pre):
+            raise TypeError("options.preprocess is not a function handle")
+        pre()
     if prob.kind == "lasso-consensus" and not ("altu" in options and "specialnorms" in options):
         raise ValueError("consensus lasso needs options.altu and options.specialnorms from getproxops' extra "
                          "(lasso.m:222-223)")
@@ -587,6 +603,8 @@ def admm(xminf, zming, options):
 
     if use_callbacks:
         eng.set_callbacks(**callbacks)
+    if hooks:
+        eng.set_hooks(**hooks)
     try:
         summ = eng.run(rho=rho, maxiters=N, domaxiters=_setopt(options, "domaxiters", 0),
                        relax=_setopt(options, "relax", 1), fast=alg, objevals=objevals, convtest=convtest,
@@ -600,6 +618,8 @@ def admm(xminf, zming, options):
     finally:
         if use_callbacks:
             eng.set_callbacks()  # the library operators are the engine's default again
+        if hooks:
+            eng.set_hooks()
     steps = int(summ.steps)
     results = {}
     results["x0"] = np.zeros(nA) if x0 is None else np.array(x0, dtype=np.float64).reshape(-1)

@@ -323,6 +323,16 @@ struct Thunk {
   std::string failure;
 };
 
+// feval(handle, ...) with MATLAB's error trapped: an error inside the handle must come back HERE as a status, not unwind
+// (long-jump in real MATLAB) through admm_engine_run's frames with the engine mid-iteration
+int call_handle(Thunk* t, int nlhs, mxArray* lhs[], int nrhs, mxArray* rhs[]) {
+  mxArray* exc = mexCallMATLABWithTrap(nlhs, lhs, nrhs, rhs, "feval");
+  if (!exc) return 0;
+  if (t->failure.empty()) t->failure = "a MATLAB function handle raised an error inside the ADMM loop";
+  mxDestroyArray(exc);
+  return 1;
+}
+
 mxArray* staged_vector(const double* dev, size_t n, void* stream) {
   mxArray* a = mxCreateDoubleMatrix(n, 1, mxREAL);
   if (admm_memcpy_d2h(mxGetPr(a), dev, n * sizeof(double), stream) != ADMM_OK) {
@@ -338,7 +348,7 @@ int prox_thunk(void* user, const double* x, const double* z, const double* u, do
   mxArray* rhs[5] = {t->fh, staged_vector(x, t->nfirst, stream), staged_vector(z, t->nB, stream),
                      staged_vector(u, t->nU, stream), mxCreateDoubleScalar(rho)};
   mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2] && rhs[3]) ? mexCallMATLAB(1, lhs, 5, rhs, "feval") : 1;
+  int rc = (rhs[1] && rhs[2] && rhs[3]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
   if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
     t->failure = "a proximal-operator handle returned something that is not a full real vector of the expected length";
     rc = 1;
@@ -355,7 +365,7 @@ int op_thunk(void* user, const double* in, int64_t nin, double* out, int64_t nou
   Thunk* t = static_cast<Thunk*>(user);
   mxArray* rhs[2] = {t->fh, staged_vector(in, static_cast<size_t>(nin), stream)};
   mxArray* lhs[1] = {nullptr};
-  int rc = rhs[1] ? mexCallMATLAB(1, lhs, 2, rhs, "feval") : 1;
+  int rc = rhs[1] ? call_handle(t, 1, lhs, 2, rhs) : 1;
   if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
     t->failure = "a constraint-operator handle (A, At or B) returned something that is not a full real vector of the "
                  "expected length";
@@ -367,11 +377,49 @@ int op_thunk(void* user, const double* in, int64_t nin, double* out, int64_t nou
   return rc;
 }
 
+// options.altu(u, Ax, Bz, c) and options.specialnorms(x, z, u, rho) as MATLAB handles (admm.m:553-559, 612-616)
+int altu_thunk(void* user, const double* u, const double* ax, const double* bz, const double* c, int64_t m, double* out,
+               void* stream) {
+  Thunk* t = static_cast<Thunk*>(user);
+  const size_t n = static_cast<size_t>(m);
+  mxArray* rhs[5] = {t->fh, staged_vector(u, n, stream), staged_vector(ax, n, stream), staged_vector(bz, n, stream),
+                     staged_vector(c, n, stream)};
+  mxArray* lhs[1] = {nullptr};
+  int rc = (rhs[1] && rhs[2] && rhs[3] && rhs[4]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
+  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != n)) {
+    t->failure = "options.altu returned something that is not a full real vector of the length of u";
+    rc = 1;
+  }
+  if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), n * sizeof(double), stream);
+  for (int k = 1; k < 5; ++k)
+    if (rhs[k]) mxDestroyArray(rhs[k]);
+  if (lhs[0]) mxDestroyArray(lhs[0]);
+  return rc;
+}
+
+int norms_thunk(void* user, const double* x, int64_t nA, const double* z, int64_t nB, const double* u, int64_t m,
+                double rho, double* out2, void* stream) {
+  Thunk* t = static_cast<Thunk*>(user);
+  mxArray* rhs[5] = {t->fh, staged_vector(x, static_cast<size_t>(nA), stream), staged_vector(z, static_cast<size_t>(nB), stream),
+                     staged_vector(u, static_cast<size_t>(m), stream), mxCreateDoubleScalar(rho)};
+  mxArray* lhs[1] = {nullptr};
+  int rc = (rhs[1] && rhs[2] && rhs[3]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
+  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) < 2)) {
+    t->failure = "options.specialnorms must return a vector of two values (admm.m:613-616)";
+    rc = 1;
+  }
+  if (rc == 0) rc = admm_memcpy_h2d(out2, mxGetPr(lhs[0]), 2 * sizeof(double), stream);
+  for (int k = 1; k < 5; ++k)
+    if (rhs[k]) mxDestroyArray(rhs[k]);
+  if (lhs[0]) mxDestroyArray(lhs[0]);
+  return rc;
+}
+
 int obj_thunk(void* user, const double* x, int64_t nA, const double* z, int64_t nB, double* out, void* stream) {
   Thunk* t = static_cast<Thunk*>(user);
   mxArray* rhs[3] = {t->fh, staged_vector(x, static_cast<size_t>(nA), stream), staged_vector(z, static_cast<size_t>(nB), stream)};
   mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2]) ? mexCallMATLAB(1, lhs, 3, rhs, "feval") : 1;
+  int rc = (rhs[1] && rhs[2]) ? call_handle(t, 1, lhs, 3, rhs) : 1;
   if (rc == 0 && (!lhs[0] || mxGetNumberOfElements(lhs[0]) != 1)) rc = 1;
   if (rc == 0) {
     const double v = mxGetScalar(lhs[0]);
@@ -434,45 +482,66 @@ void read_options(const mxArray* op, admm_options& o) {
                                                                                    : ADMM_STOP_STANDARD;
 }
 
-// a scalar or matrix B is copied into the engine once, right after create (a function-handle B is set per run)
-void attach_constraint_b(admm_engine* e, const Desc& ds) {
-  if (ds.b_kind == 1 || ds.b_kind == 2)
-    check(admm_engine_set_constraint_b(e, ds.b_matrix, ds.b_ld, ds.b_kind == 2 ? ds.nB : 0, ADMM_MEM_HOST, ds.b_scalar,
-                                       nullptr, nullptr));
+// Everything about a run that can be refused WITHOUT an engine: called before admm_engine_create in 'solve', so that a
+// bad options struct never leaves device memory behind (at config 2's size an engine holds 8.4 GB).
+void validate_run(const Desc& ds, const mxArray* op, const mxArray* handles) {
+  if (!mxIsStruct(op)) mexErrMsgIdAndTxt("admm:arg", "Given options is not a struct! At least pass empty struct!");
+  const size_t nA = static_cast<size_t>(ds.nA), nB = static_cast<size_t>(ds.nB);
+  const size_t nU = ds.mC ? static_cast<size_t>(ds.mC) : nB;  // u, c, A*x (admm.m:252-254: zeros(m, 1))
+  size_t k0 = 0;
+  if (opt_vec(op, "x0", &k0) && k0 != nA) mexErrMsgIdAndTxt("admm:arg", "options.x0 has the wrong length");
+  if (opt_vec(op, "z0", &k0) && k0 != nB) mexErrMsgIdAndTxt("admm:arg", "options.z0 has the wrong length");
+  if (opt_vec(op, "u0", &k0) && k0 != nU) mexErrMsgIdAndTxt("admm:arg", "options.u0 has the wrong length");
+  if (ds.a_handle && (!is_handle(field(handles, "A")) || !is_handle(field(handles, "At"))))
+    mexErrMsgIdAndTxt("admm:arg", "this engine was created for function-handle operators: pass handles.A and handles.At");
+  if (ds.b_kind == 3 && !is_handle(field(handles, "B")))
+    mexErrMsgIdAndTxt("admm:arg", "this engine was created for a function-handle B: pass handles.B");
+  for (const char* name : {"altu", "specialnorms"})  // the consensus hooks are descriptors, not handles (getproxops.m)
+    if (is_handle(field(handles, name)) && ds.d.problem == ADMM_PROB_LASSO_CONSENSUS)
+      mexErrMsgIdAndTxt("admm:unsupported", "consensus lasso runs with the hooks of its own getproxops call");
 }
 
-// the loop and the whole results struct of admm.m:257-767 (options / solverruntime are added by the callers)
-mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxArray* handles) {
-  if (!mxIsStruct(op)) mexErrMsgIdAndTxt("admm:arg", "Given options is not a struct! At least pass empty struct!");
+struct RunError {  // a failure after an engine exists: reported by the caller once the engine is dealt with
+  std::string id, msg;
+  bool set(const char* i, const std::string& m) {
+    id = i;
+    msg = m;
+    return false;
+  }
+};
+
+// the loop and the whole results struct of admm.m:257-767 (options / solverruntime are added by the callers).
+// Never raises a MATLAB error itself: nullptr + err on failure (validate_run has vetted the arguments).
+mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxArray* handles, RunError& err) {
   admm_options o;
   read_options(op, o);
   const size_t nA = static_cast<size_t>(ds.nA), nB = static_cast<size_t>(ds.nB);
   const size_t nU = ds.mC ? static_cast<size_t>(ds.mC) : nB;  // u, c, A*x (admm.m:252-254: zeros(m, 1))
   size_t k0 = 0;
   o.x0 = opt_vec(op, "x0", &k0);
-  if (o.x0 && k0 != nA) mexErrMsgIdAndTxt("admm:arg", "options.x0 has the wrong length");
   o.z0 = opt_vec(op, "z0", &k0);
-  if (o.z0 && k0 != nB) mexErrMsgIdAndTxt("admm:arg", "options.z0 has the wrong length");
   o.u0 = opt_vec(op, "u0", &k0);
-  if (o.u0 && k0 != nU) mexErrMsgIdAndTxt("admm:arg", "options.u0 has the wrong length");
-  for (const char* name : {"altu", "specialnorms"})
-    if (is_handle(field(op, name)))
-      mexErrMsgIdAndTxt("admm:unsupported", "options.%s as a caller-supplied handle is not engine-native", name);
+  auto engine_ok = [&](int rc) { return rc == ADMM_OK || err.set("admm:engine", admm_last_error()); };
 
   // caller-supplied handles replace the engine-native operators (admm.m:502, 521-530, 603-605)
-  Thunk tx, tz, tobj, ta, tat, tb;
+  Thunk tx, tz, tobj, ta, tat, tb, taltu, tnorms;
   if (ds.a_handle) {  // the thunks live as long as this run; a persistent engine gets fresh ones every run
     ta.fh = const_cast<mxArray*>(field(handles, "A"));
     tat.fh = const_cast<mxArray*>(field(handles, "At"));
-    if (!is_handle(ta.fh) || !is_handle(tat.fh))
-      mexErrMsgIdAndTxt("admm:arg", "this engine was created for function-handle operators: pass handles.A and handles.At");
-    check(admm_engine_set_operators(e, op_thunk, &ta, op_thunk, &tat));
+    if (!engine_ok(admm_engine_set_operators(e, op_thunk, &ta, op_thunk, &tat))) return nullptr;
   }
   if (ds.b_kind == 3) {
     tb.fh = const_cast<mxArray*>(field(handles, "B"));
-    if (!is_handle(tb.fh)) mexErrMsgIdAndTxt("admm:arg", "this engine was created for a function-handle B: pass handles.B");
-    check(admm_engine_set_constraint_b(e, nullptr, 0, ds.nB, ADMM_MEM_HOST, 0.0, op_thunk, &tb));
+    if (!engine_ok(admm_engine_set_constraint_b(e, nullptr, 0, ds.nB, ADMM_MEM_HOST, 0.0, op_thunk, &tb))) return nullptr;
   }
+  // options.altu / options.specialnorms as MATLAB handles (admm.m:553-559, 612-616): matlab/admm.m hands them over in
+  // `handles` (the consensus descriptors of getproxops' extra stay in options and are the engine's own)
+  if (is_handle(field(handles, "altu"))) taltu.fh = const_cast<mxArray*>(field(handles, "altu"));
+  if (is_handle(field(handles, "specialnorms"))) tnorms.fh = const_cast<mxArray*>(field(handles, "specialnorms"));
+  const bool hooks = taltu.fh || tnorms.fh;
+  if (hooks && !engine_ok(admm_engine_set_hooks(e, taltu.fh ? altu_thunk : nullptr, &taltu,
+                                                tnorms.fh ? norms_thunk : nullptr, &tnorms)))
+    return nullptr;
   const mxArray* fx = field(handles, "xminf");
   const mxArray* fz = field(handles, "zming");
   const mxArray* fo = field(handles, "obj");
@@ -495,16 +564,23 @@ mxArray* run_engine(admm_engine* e, const Desc& ds, const mxArray* op, const mxA
   } else if (o.objevals && !obj_native) {
     o.objevals = 0;  // admm.m:603: objevals without options.obj records nothing
   }
-  if (tx.fh || tz.fh || tobj.fh)
-    check(admm_engine_set_callbacks(e, tx.fh ? prox_thunk : nullptr, &tx, tz.fh ? prox_thunk : nullptr, &tz,
-                                    tobj.fh ? obj_thunk : nullptr, &tobj));
   admm_run_summary s;
-  const int rc = admm_engine_run(e, &o, &s);
+  int rc = ADMM_OK;
+  if (tx.fh || tz.fh || tobj.fh)
+    rc = admm_engine_set_callbacks(e, tx.fh ? prox_thunk : nullptr, &tx, tz.fh ? prox_thunk : nullptr, &tz,
+                                   tobj.fh ? obj_thunk : nullptr, &tobj);
+  if (rc == ADMM_OK) rc = admm_engine_run(e, &o, &s);
+  const std::string engine_msg = rc == ADMM_OK ? std::string() : std::string(admm_last_error());
   if (tx.fh || tz.fh || tobj.fh) (void)admm_engine_set_callbacks(e, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (hooks) (void)admm_engine_set_hooks(e, nullptr, nullptr, nullptr, nullptr);
   if (rc != ADMM_OK) {
-    for (const Thunk* t : {&tx, &tz, &tobj, &ta, &tat, &tb})
-      if (!t->failure.empty()) mexErrMsgIdAndTxt("admm:handle", "%s", t->failure.c_str());
-    check(rc);
+    for (const Thunk* t : {&tx, &tz, &tobj, &ta, &tat, &tb, &taltu, &tnorms})
+      if (!t->failure.empty()) {
+        err.set("admm:handle", t->failure);
+        return nullptr;
+      }
+    err.set("admm:engine", engine_msg);
+    return nullptr;
   }
 
   const size_t k = static_cast<size_t>(s.steps);
@@ -577,6 +653,7 @@ struct Live {
   Desc* ds;
 };
 std::vector<Live> g_handles;
+Desc* g_solve = nullptr;  // the description of the 'solve' call in flight
 
 mxArray* handle_to_mx(admm_engine* e) {
   mxArray* a = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
@@ -595,6 +672,8 @@ Live* find_live(const mxArray* a) {
 
 void at_exit_all() {
   at_exit();
+  delete g_solve;
+  g_solve = nullptr;
   for (Live& l : g_handles) {
     admm_engine_destroy(l.e);
     delete l.ds;
@@ -613,26 +692,44 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     plhs[0] = mxCreateLogicalScalar(admm_device_count(&n) == ADMM_OK && n > 0);
     return;
   }
+  if (cmd == "livecount") {  // engines this gateway currently holds (tests: nothing may survive a failed solve)
+    plhs[0] = mxCreateDoubleScalar(static_cast<double>(g_live.size() + g_handles.size()));
+    return;
+  }
   if (cmd == "solve") {
     if (nrhs < 4) mexErrMsgIdAndTxt("admm:arg", "admm_mex('solve', problem, args, options [, handles])");
     if (!mxIsStruct(prhs[2]))
       mexErrMsgIdAndTxt("admm:arg", "Given struct args is not a struct containing arguments needed for proximal "
                                     "operators for the given problem!");
     const mxArray* handles = nrhs > 4 ? prhs[4] : nullptr;
-    Desc ds;
+    // A Desc on the heap, owned by g_solve: a MATLAB error below (describe / validate_run: no engine yet) long-jumps
+    // past every C++ destructor of this frame, and the next call (or mexAtExit) frees what it left
+    delete g_solve;
+    g_solve = new Desc();
+    Desc& ds = *g_solve;
     describe(to_string(prhs[1]), prhs[2], handles, ds);
-    admm_engine* e = nullptr;
-    check(admm_engine_create(&ds.d, &e));
-    g_live.push_back(e);  // destroyed by at_exit should a handle error out of MATLAB mid-run
-    attach_constraint_b(e, ds);
+    validate_run(ds, prhs[3], handles);
     static bool registered = false;
     if (!registered) {
       mexAtExit(at_exit_all);
       registered = true;
     }
-    mxArray* res = run_engine(e, ds, prhs[3], handles);
+    admm_engine* e = nullptr;
+    check(admm_engine_create(&ds.d, &e));  // (a failed create leaves nothing behind)
+    g_live.push_back(e);  // (only an allocation failure inside MATLAB's own mx* calls can still leave it to mexAtExit)
+    RunError err;
+    mxArray* res = nullptr;
+    if (ds.b_kind == 1 || ds.b_kind == 2) {
+      if (admm_engine_set_constraint_b(e, ds.b_matrix, ds.b_ld, ds.b_kind == 2 ? ds.nB : 0, ADMM_MEM_HOST, ds.b_scalar,
+                                       nullptr, nullptr) != ADMM_OK)
+        err.set("admm:engine", admm_last_error());
+    }
+    if (err.id.empty()) res = run_engine(e, ds, prhs[3], handles, err);
     g_live.pop_back();
-    admm_engine_destroy(e);
+    admm_engine_destroy(e);  // before any error is raised: a failed solve returns every byte of device memory
+    delete g_solve;
+    g_solve = nullptr;
+    if (!res) mexErrMsgIdAndTxt(err.id.empty() ? "admm:engine" : err.id.c_str(), "%s", err.msg.c_str());
     plhs[0] = res;
     return;
   }
@@ -665,7 +762,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (cmd == "run") {
     if (nrhs < 3) mexErrMsgIdAndTxt("admm:arg", "admm_mex('run', handle, options [, handles])");
     Live* l = find_live(prhs[1]);
-    plhs[0] = run_engine(l->e, *l->ds, prhs[2], nrhs > 3 ? prhs[3] : nullptr);
+    const mxArray* hd = nrhs > 3 ? prhs[3] : nullptr;
+    validate_run(*l->ds, prhs[2], hd);
+    RunError err;
+    mxArray* res = run_engine(l->e, *l->ds, prhs[2], hd, err);  // (the engine persists by design: 'destroy' frees it)
+    if (!res) mexErrMsgIdAndTxt(err.id.c_str(), "%s", err.msg.c_str());
+    plhs[0] = res;
     return;
   }
   if (cmd == "destroy") {

@@ -189,6 +189,11 @@ struct admm_engine {
   double *zthist = nullptr, *vthist = nullptr;
   admm_prox_callback xcb = nullptr, zcb = nullptr;
   admm_obj_callback ocb = nullptr;
+  // options.altu / options.specialnorms as the caller's handles (admm_engine_set_hooks)
+  admm_altu_callback altucb = nullptr;
+  admm_norms_callback normscb = nullptr;
+  void *altuuser = nullptr, *normsuser = nullptr;
+  double *hk_uold = nullptr, *hk_bz = nullptr, *hk_unew = nullptr, *hk_zero = nullptr, *hk_norms = nullptr;
   void *xuser = nullptr, *zuser = nullptr, *ouser = nullptr;
   double* part = nullptr;     // [S_COUNT][kMaxPartBlocks]
   double* objpart = nullptr;  // [kMaxPartBlocks]

@@ -209,6 +209,35 @@ int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xus
   return ADMM_OK;
 }
 
+int admm_engine_set_hooks(admm_engine* e, admm_altu_callback altu, void* altu_user, admm_norms_callback norms,
+                          void* norms_user) {
+  if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
+  if (altu || norms) {
+    if (e->problem == ADMM_PROB_LASSO_CONSENSUS || e->problem == ADMM_PROB_TOTALVARIATION || e->problem == ADMM_PROB_TV2D)
+      return fail(ADMM_E_UNSUPPORTED, "caller-supplied options.altu / options.specialnorms: not for the consensus-lasso "
+                                      "and total-variation loops (consensus lasso's own hooks are engine-native)");
+    if (e->comm && comm_nranks(e->comm) > 1)
+      return fail(ADMM_E_UNSUPPORTED, "caller-supplied options.altu / options.specialnorms are not supported on "
+                                      "row-sharded engines");
+    ADMM_HIP_TRY(hipSetDevice(e->device));
+    const int64_t n2 = round_up(e->len, 2);
+    if (!e->xh) ADMM_TRY(e->mem.alloc(&e->xh, n2));
+    if (!e->hk_uold) {
+      ADMM_TRY(e->mem.alloc(&e->hk_uold, n2));
+      ADMM_TRY(e->mem.alloc(&e->hk_bz, n2));
+      ADMM_TRY(e->mem.alloc(&e->hk_unew, n2));
+      ADMM_TRY(e->mem.alloc(&e->hk_zero, n2));
+      ADMM_TRY(e->mem.alloc(&e->hk_norms, 2));
+      ADMM_HIP_TRY(hipMemsetAsync(e->hk_zero, 0, sizeof(double) * n2, e->stream));
+    }
+  }
+  e->altucb = altu;
+  e->altuuser = altu_user;
+  e->normscb = norms;
+  e->normsuser = norms_user;
+  return ADMM_OK;
+}
+
 int admm_engine_set_operators(admm_engine* e, admm_operator_callback A, void* Auser, admm_operator_callback At,
                               void* Atuser) {
   if (!e) return fail(ADMM_E_INVALID, "engine is NULL");
@@ -569,6 +598,12 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
 
   const int nrhs_dual = o.nodualerror ? 1 : 3;
   const bool sharded = e->comm && comm_nranks(e->comm) > 1;
+  const bool hooks = e->altucb != nullptr || e->normscb != nullptr;
+  if (hooks && alg != 0)
+    return fail(ADMM_E_UNSUPPORTED, "caller-supplied options.altu / options.specialnorms with fast ADMM: not supported "
+                                    "(admm.m:614 overwrites fast ADMM's v with the norms: q5)");
+  if (hooks && sharded) return fail(ADMM_E_UNSUPPORTED, "options.altu / options.specialnorms on a row-sharded engine");
+  fa.norms_given = e->normscb ? e->hk_norms : nullptr;
   fa.len_global = e->len_global;
   int check_every = o.check_every > 0 ? o.check_every : (o.domaxiters ? 64 : 8);
 
@@ -611,7 +646,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // iteration (unwrapped.hip) when nothing outside the fused element update is asked for: plain ADMM, no recorded dual
   // residual (unwrappedadmm.m:92 sets nodualerror), library operators, library objective, one rank.
   const bool uw_fused = e->Dp && e->problem == ADMM_PROB_LINEARSVM && alg == 0 && o.relax == 1.0 && o.nodualerror &&
-                        !sharded && !e->xcb && !e->zcb && !e->ocb && std::getenv("ADMM_HIP_NO_UNWRAPPED_FUSED") == nullptr;
+                        !sharded && !hooks && !e->xcb && !e->zcb && !e->ocb && std::getenv("ADMM_HIP_NO_UNWRAPPED_FUSED") == nullptr;
   UwArgs ua{};
   if (uw_fused) {
     ua.D = e->D;
@@ -649,7 +684,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (hipEventElapsedTime rejects events recorded by graph nodes: "invalid resource handle").
   const int64_t heavy = std::max<int64_t>(e->m * e->n, e->nF * e->nF);
   const bool use_graph = std::getenv("ADMM_HIP_GRAPH") != nullptr && !sharded && e->profiling == 0 && !uw_fused &&
-                         e->xsolve != ADMM_XSOLVE_CG && heavy <= (int64_t{32} << 20) && !e->xcb && !e->zcb && !e->ocb;
+                         e->xsolve != ADMM_XSOLVE_CG && heavy <= (int64_t{32} << 20) && !e->xcb && !e->zcb && !e->ocb &&
+                         !hooks;
   // A = I iterations whose finalize depends on nothing but the prox kernel's partial sums end in ONE launch
   // (prox_fin_kernel): no accelerated-ADMM decision, no split z-update, no objective kernels behind the prox, one rank
   // the lasso objective through the cached Gram matrix: always (obj_gram = 1), or once the calibration of the first
@@ -678,7 +714,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (row-sharded A = I engines keep x, z, u replicated and exchange nothing per iteration unless the x-solve's tiles
   // are split over the ranks -- symv_apply's one all-reduce, before this tail: they run the same tail as one rank)
   const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && (!sharded || e->a_identity) &&
-                         !obj_kernels &&
+                         !obj_kernels && !hooks &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   // With the packed lower-triangle x-solve in front of it, the finalize logic of an A = I iteration is deferred: the
   // element update stores its block partials and ends; the next iteration's x-solve carries the finalize in one extra
@@ -789,7 +825,52 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
           launch_prox_fin(pa, fa, e->ctrl, &nblk, e->stream);
           if (e->a_identity) return ADMM_OK;  // the iteration ends here
         } else {
+          if (e->altucb) {  // options.altu needs the old u and Ax (or the relaxed Axhat) as vectors: admm.m:553-559
+            ADMM_HIP_TRY(hipMemcpyAsync(e->hk_uold, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
+            if (!split_z) {
+              PreZArgs za{};
+              za.len = len;
+              za.axsrc = axsrc;
+              za.naxpart = naxpart;
+              za.axld = axld;
+              za.c = e->c;
+              za.z = e->z;
+              za.uo = e->u;
+              za.add = nullptr;
+              za.xh = e->xh;
+              za.rz = nullptr;
+              za.rho = o.rho;
+              za.relax = o.relax;
+              launch_prez(za, e->ctrl, e->stream);
+            }
+          }
           launch_prox(pa, e->ctrl, &nblk, e->stream);
+          if (e->altucb) {
+            launch_negate(e->z, e->hk_bz, len, e->ctrl, e->stream);
+            if (e->altucb(e->altuuser, e->hk_uold, e->xh, e->hk_bz, e->c ? e->c : e->hk_zero, len, e->hk_unew,
+                          static_cast<void*>(e->stream)) != 0)
+              return fail(ADMM_E_INVALID, "the altu callback reported a failure");
+            UFixArgs ux{};
+            ux.len = len;
+            ux.unew = e->hk_unew;
+            ux.uold = e->hk_uold;
+            ux.z = e->z;
+            ux.c = e->c;
+            ux.rhs_add = e->rhs_add;
+            ux.u = e->u;
+            ux.uhist = e->uhist;
+            ux.rhs = pa.rhs;
+            ux.part = e->part;
+            ux.nblk = nblk;
+            ux.rhs_kind = pa.rhs_kind;
+            ux.rho = o.rho;
+            launch_ufix(ux, e->ctrl, e->stream);
+          }
+          if (e->normscb) {  // v = options.specialnorms(x, z, u, rho)   admm.m:612-616
+            if (e->normscb(e->normsuser, e->x, nA, e->bgen ? e->zt : e->z, e->bgen ? e->nBz : len, e->u, len, o.rho,
+                           e->hk_norms, static_cast<void*>(e->stream)) != 0)
+              return fail(ADMM_E_INVALID, "the specialnorms callback reported a failure");
+          }
         }
       }
       if (fuse_tail) {  // A = D: only the next x-update's right-hand side D'*(c + z - u) is left to do

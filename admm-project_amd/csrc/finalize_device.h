@@ -139,6 +139,10 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
       const double un = a.a_identity ? sqrt(S[S_U2]) : sqrt(ng3);
       de = sqrt(Mlen) * a.abstol + a.reltol * (a.rho * un);
     }
+    if (a.norms_given) {  // options.specialnorms, the caller's handle (admm.m:612-616)
+      pn = a.norms_given[0];
+      dn = a.norms_given[1];
+    }
     const double pe = sqrt(Mlen) * a.abstol +
                       a.reltol * fmax(fmax(sqrt(S[S_AX2]), sqrt(S[S_Z2])), a.cnorm);
     a.pnorm[it] = pn;

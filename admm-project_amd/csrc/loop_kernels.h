@@ -149,6 +149,7 @@ struct FinArgs {
   double* dvals;
   double* restarted;
   Ctrl* ctrl;
+  const double* norms_given;    // options.specialnorms as the caller's handle: pnorm, dnorm (admm.m:612-616), else null
 };
 
 // First half of a split z-update (PROX_GIVEN): what the z-prox is called with (admm.m:515-530).
@@ -168,6 +169,26 @@ struct PreZArgs {
   double rho, relax;
 };
 void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream);
+// caller-supplied options.altu (admm.m:553-559), plain ADMM: bz = -z (what the handle gets as Bz) ...
+void launch_negate(const double* z, double* bz, int64_t len, const Ctrl* ctrl, hipStream_t stream);
+// ... and, with the handle's result: u = unew, its history column, the u-dependent partial sums (||u||^2, ||u - u_old||^2)
+// in the prox kernel's block layout, and the next x-update's right-hand side from (z, unew)
+struct UFixArgs {
+  int64_t len;
+  const double* unew;
+  const double* uold;
+  const double* z;
+  const double* c;        // nullable
+  const double* rhs_add;  // nullable
+  double* u;
+  double* uhist;          // nullable
+  double* rhs;            // nullable
+  double* part;           // [S_COUNT][kMaxPartBlocks]
+  int32_t nblk;           // blocks the prox kernel wrote
+  int32_t rhs_kind;
+  double rho;
+};
+void launch_ufix(const UFixArgs& a, const Ctrl* ctrl, hipStream_t stream);
 void launch_prox(const ProxArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
 // A = I, alg 0 / 1: z/u update AND the finalize logic in one launch (the last workgroup to arrive finalizes);
 // a.len <= 128 * kMaxPartBlocks

@@ -79,6 +79,59 @@ void launch_prez(const PreZArgs& a, const Ctrl* ctrl, hipStream_t stream) {
   hipLaunchKernelGGL(prez_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, a, ctrl);
 }
 
+__global__ __launch_bounds__(kBlock) void negate_kernel(const double* __restrict__ z, double* __restrict__ bz,
+                                                        int64_t len, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    bz[i] = -z[i];  // B = -1 (a general B: the loop's z buffer holds w = -B*z, so this is B*z as well)
+}
+
+void launch_negate(const double* z, double* bz, int64_t len, const Ctrl* ctrl, hipStream_t stream) {
+  int64_t blocks = ceil_div(len, kBlock);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(negate_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, z, bz, len, ctrl);
+}
+
+// grid = the prox kernel's block count: slots S_U2 / S_DU2 of every block it wrote are rewritten
+__global__ __launch_bounds__(kBlock) void ufix_kernel(UFixArgs a, const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  __shared__ double scratch[4];
+  const int64_t it = ctrl->iter;
+  double su = 0.0, sdu = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.len;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const double un = a.unew[i], uo = a.uold[i], zn = a.z[i];
+    const double ci = a.c ? a.c[i] : 0.0;
+    const double add = a.rhs_add ? a.rhs_add[i] : 0.0;
+    a.u[i] = un;
+    if (a.uhist) a.uhist[it * a.len + i] = un;
+    su += un * un;
+    const double du = un - uo;
+    sdu += du * du;
+    if (a.rhs) {  // as prox_apply's epilogue (plain ADMM: zx = z, ux = u)
+      switch (a.rhs_kind) {
+        case RHS_RHO_DTS: a.rhs[i] = a.rho * (zn - un) + add; break;
+        case RHS_RHO_MINUS_Q: a.rhs[i] = a.rho * (zn - un) - add; break;
+        case RHS_DIFF: a.rhs[i] = zn - un; break;
+        case RHS_T1: a.rhs[i] = (ci + zn) - un; break;
+        default: break;
+      }
+    }
+  }
+  const double tu = block_sum(su, scratch);
+  const double tdu = block_sum(sdu, scratch);
+  if (threadIdx.x == 0) {
+    a.part[S_U2 * kMaxPartBlocks + blockIdx.x] = tu;
+    a.part[S_DU2 * kMaxPartBlocks + blockIdx.x] = tdu;
+  }
+}
+
+void launch_ufix(const UFixArgs& a, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(ufix_kernel, dim3(static_cast<unsigned>(a.nblk < 1 ? 1 : a.nblk)), dim3(kBlock), 0, stream, a, ctrl);
+}
+
 void launch_prox(const ProxArgs& args, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
   ProxArgs a = args;  // operands this variant does not read -> null (the kernel loads every non-null one up front)
   const bool need_ell = a.prox == PROX_HINGE || a.prox == PROX_01 || a.objx == OBJX_HINGE ||

@@ -252,6 +252,74 @@ class Engine:
         L.check(self._lib.admm_engine_set_callbacks(self._h, keep[0], None, keep[1], None, keep[2], None))
         self._cb_keep = keep  # the C side holds raw pointers to these thunks
 
+    def set_hooks(self, altu=None, specialnorms=None):
+        """options.altu / options.specialnorms as the CALLER's handles (admm.m:553-559, 612-616), callables on DEVICE
+        tensors like the prox callbacks: ``altu(u, Ax, Bz, c) -> new u`` (m elements; Ax is the relaxed Axhat when
+        relax != 1, c a zero vector when the constraint has none), ``specialnorms(x, z, u, rho) -> (pnorm, dnorm)``
+        (a 2-element tensor or two scalars).  ``None, None`` restores the engine's own u-update and norms."""
+        if altu is None and specialnorms is None:
+            L.check(self._lib.admm_engine_set_hooks(self._h, C.cast(None, L.ALTU_CALLBACK), None,
+                                                    C.cast(None, L.NORMS_CALLBACK), None))
+            self._hook_keep = None
+            return
+        import torch  # device memory / stream plumbing only
+
+        dev = torch.device("cuda", self.device)
+
+        class _View:
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                                 "version": 2}
+
+        def view(ptr, count):
+            return torch.as_tensor(_View(ptr, count), device=dev)
+
+        def wrap_altu(fn):
+            if fn is None:
+                return C.cast(None, L.ALTU_CALLBACK)
+
+            def cb(_user, u, ax, bz, c, m, out, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        res = fn(view(u, m), view(ax, m), view(bz, m), view(c, m))
+                        if not (isinstance(res, torch.Tensor) and res.is_cuda):
+                            raise TypeError("options.altu must return a CUDA tensor: host arrays would need a CPU path, "
+                                            "which this package does not have")
+                        if res.numel() != m:
+                            raise ValueError(f"options.altu returned {res.numel()} elements, expected {m}")
+                        view(out, m).copy_(res.to(torch.float64).reshape(-1))
+                    return 0
+                except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame
+                    self._cb_error = exc
+                    return 1
+
+            return L.ALTU_CALLBACK(cb)
+
+        def wrap_norms(fn):
+            if fn is None:
+                return C.cast(None, L.NORMS_CALLBACK)
+
+            def cb(_user, x, nA, z, nB, u, m, rho, out2, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                        res = fn(view(x, nA), view(z, nB), view(u, m), float(rho))
+                        if not isinstance(res, torch.Tensor):
+                            res = torch.stack([r if isinstance(r, torch.Tensor) else
+                                               torch.tensor(float(r), dtype=torch.float64, device=dev) for r in res])
+                        if res.numel() < 2:
+                            raise ValueError("options.specialnorms must return two values (admm.m:613-616)")
+                        view(out2, 2).copy_(res.to(device=dev, dtype=torch.float64).reshape(-1)[:2])
+                    return 0
+                except BaseException as exc:  # noqa: BLE001
+                    self._cb_error = exc
+                    return 1
+
+            return L.NORMS_CALLBACK(cb)
+
+        keep = (wrap_altu(altu), wrap_norms(specialnorms))
+        L.check(self._lib.admm_engine_set_hooks(self._h, keep[0], None, keep[1], None))
+        self._hook_keep = keep
+
     def set_operators(self, A, At):
         """options.A / options.At as function handles (admm.m:117-158) for an engine created without a matrix:
         callables on DEVICE tensors, ``A(x) -> nB elements``, ``At(v) -> nA elements`` (zero-copy torch views, the

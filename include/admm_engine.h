@@ -109,6 +109,15 @@ typedef int (*admm_prox_callback)(void* user, const double* x, const double* z, 
                                   double* out, int64_t nout, void* hip_stream);
 typedef int (*admm_obj_callback)(void* user, const double* x, int64_t nA, const double* z, int64_t nB, double* out,
                                  void* hip_stream);
+/* The two remaining caller-handle fields of the loop (ABI 4), same conventions (device pointers, hip_stream):
+ *   altu : out[m] = options.altu(u[m], Ax[m], Bz[m], c[m])   admm.m:553-559 -- replaces the u-update; Ax is the relaxed
+ *          Axhat when options.relax != 1 (admm.m:555), c is a zero vector when the constraint has none
+ *   norms: out[0..1] = options.specialnorms(x[nA], z[nB], u[m], rho)   admm.m:612-616 -- replaces pnorm / dnorm (perr / derr
+ *          are computed as always, admm.m:640-658) */
+typedef int (*admm_altu_callback)(void* user, const double* u, const double* Ax, const double* Bz, const double* c,
+                                  int64_t m, double* out, void* hip_stream);
+typedef int (*admm_norms_callback)(void* user, const double* x, int64_t nA, const double* z, int64_t nB, const double* u,
+                                   int64_t m, double rho, double* out2, void* hip_stream);
 /* Caller-supplied constraint operators: options.A / options.At as function handles (admm.m:117-158).
  *   out[nout] = A(in[nin])  or  At(in[nin]);  device pointers, enqueue on hip_stream, non-zero return aborts the run */
 typedef int (*admm_operator_callback)(void* user, const double* in, int64_t nin, double* out, int64_t nout,
@@ -264,6 +273,13 @@ int admm_engine_set_callbacks(admm_engine* eng, admm_prox_callback xmin, void* x
  * A*x, At*(.) of the dual residual / tolerance (admm.m:535, 624, 654) are these callbacks, both required; B = -1. */
 int admm_engine_set_operators(admm_engine* eng, admm_operator_callback A, void* Auser, admm_operator_callback At,
                               void* Atuser);
+/* options.altu / options.specialnorms as the CALLER's handles (admm.m:553-559, 612-616; the consensus-lasso hooks of
+ * getproxops' `extra` are engine-native and need none of this).  Plain ADMM only (the reference never combines them with
+ * fast / accelerated ADMM: q5), any engine of the general loop (not consensus lasso / total variation, not row-sharded).
+ * With a hook set the iteration leaves the fused one-launch tails: element update, hook, a small fix-up kernel, finalize.
+ * NULL, NULL restores the engine's own u-update and norms. */
+int admm_engine_set_hooks(admm_engine* eng, admm_altu_callback altu, void* altu_user, admm_norms_callback norms,
+                          void* norms_user);
 /* options.B other than the shorthand -1 (admm.m:198-245): a scalar (B = NULL, Bop = NULL: B = scalar*I), an m x nB
  * matrix (column-major, leading dimension ldB, host or device pointer per memkind = ADMM_MEM_*), or a function handle
  * Bop(z[nB]) -> out[m].  Only for engines whose two prox operators are BOTH the caller's (ADMM_PROB_MODEL created

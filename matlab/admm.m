@@ -20,9 +20,11 @@ function results = admm(xminf, zming, options)
 %       quadraticprogram.m:242)                                      -> the engine's own objective;
 %       any other handle                                             -> evaluated by MATLAB once per iteration.
 %
-% Not engine-native (error): options.altu / options.specialnorms as caller-supplied handles, function-handle
-% or non-trivial options.B, options.adaptive (experimental in the reference, admm.m:724-741; the Python
-% binding steps it, see INTEGRATION.md).
+%   options.altu / options.specialnorms as the caller's handles (admm.m:553-559, 612-616) -> staged like the prox
+%       handles (plain ADMM only); options.preprocess (admm.m:473-476) is called here, once, before the loop;
+%   options.adaptive with options.convtest (experimental in the reference, admm.m:724-741) -> stepped by this file:
+%       one device iteration per gateway call on a persistent engine, rho updated by the reference's rule, the
+%       engine re-created for a new rho where the reference's closure re-factors (adaptiveloop below).
 
 if ~isstruct(options)
     error('Given options is not a struct! At least pass empty struct!');    % admm.m:48
@@ -32,9 +34,7 @@ xd = isdescriptor(xminf);
 zd = isdescriptor(zming);
 handles = struct();
 
-if isfield(options, 'adaptive') && any(options.adaptive) && isfield(options, 'convtest') && any(options.convtest)
-    error('admm:unsupported', 'options.adaptive is not available through the MEX gateway.');
-end
+adaptive = isfield(options, 'adaptive') && any(options.adaptive) && isfield(options, 'convtest') && any(options.convtest);
 
 if xd && zd
     if xminf.id ~= zming.id
@@ -64,12 +64,16 @@ if xd || zd
     checkconstraint(problem, options);
 end
 
-% the consensus hooks must be the engine's own (lasso.m:222-223 copies them from extra)
+% options.altu / options.specialnorms: the consensus hooks are descriptors and stay the engine's own (lasso.m:222-223
+% copies them from extra); a caller's function handle travels to the gateway with the other handles
 hooks = {'altu', 'specialnorms'};
 for k = 1:numel(hooks)
     if isfield(options, hooks{k}) && isa(options.(hooks{k}), 'function_handle')
-        error('admm:unsupported', ['options.', hooks{k}, ' as a caller-supplied handle is not engine-native.']);
+        handles.(hooks{k}) = options.(hooks{k});
     end
+end
+if isfield(options, 'preprocess') && isa(options.preprocess, 'function_handle')      % admm.m:473-476
+    options.preprocess();
 end
 
 [args, handles] = attachobjective(problem, args, options, handles);
@@ -81,9 +85,84 @@ if isfield(options, 'rho') && ~(isfield(args, 'L') || isfield(args, 'R'))
     args.rho = options.rho;
 end
 
-results = admm_mex('solve', problem, args, options, handles);
+if adaptive
+    results = adaptiveloop(problem, args, options, handles);
+else
+    results = admm_mex('solve', problem, args, options, handles);
+end
 results.options = options;                                                  % admm.m:767
 
+end
+
+% -------------------------------------------------------------------------------------------------------
+function results = adaptiveloop(problem, args, options, handles)
+% admm.m:724-741 (experimental): after every iteration i > 2, rho <- rho*rhoprev/(H1 - H2), clamped to a factor of 5 per
+% step.  One device iteration per 'run' on a persistent engine, warm-started from the previous one; closures with a
+% "rho ~= rhoprev" branch (getProxOps.m:1222-1238, 1446-1453; the KKT solves 1363, 1410) get a new engine for a new rho,
+% xminLASSO / xminLAD keep their factor (1192-1206, 1511-1515).  tests/test_mex_gateway.py steps the gateway the same way.
+refactor = any(strcmp(problem, {'quadraticprogram', 'linearprogram', 'model'})) || ...
+    (isfield(args, 'parallel') && any(args.parallel));
+rho = 1.0;
+if isfield(options, 'rho'), rho = options.rho; end
+rhoH = rho;                                                                 % admm.m:305-309 captures rho once
+N = 1000;
+if isfield(options, 'maxiters') && options.maxiters > 0, N = ceil(options.maxiters); end
+step = rmfield(options, intersect(fieldnames(options), {'adaptive', 'preprocess'}));
+step.convtest = 0; step.stopcond = 'standard'; step.maxiters = 1; step.domaxiters = 1; step.recordhistory = 0;
+if ~refactor, step.stalefactorok = 1; end
+h = []; rhobuilt = NaN; results = struct(); H = zeros(1, 0); w = []; runtime = 0;
+cleanup = onCleanup(@() destroyengine(h));
+for i = 1:N
+    if isempty(h) || (refactor && rho ~= rhobuilt)
+        destroyengine(h);
+        args.rho = rho;
+        h = admm_mex('create', problem, args, handles);
+        cleanup = onCleanup(@() destroyengine(h)); %#ok<NASGU>
+        rhobuilt = rho;
+    end
+    step.rho = rho;
+    r = admm_mex('run', h, step, handles);
+    if i == 1
+        results.x0 = r.x0; results.z0 = r.z0; results.u0 = r.u0;
+        w = [r.x0; r.z0; rho*r.u0];
+    end
+    step.x0 = r.xopt; step.z0 = r.zopt; step.u0 = r.uopt;
+    runtime = runtime + r.runtime;
+    results.xvals(:, i) = r.xopt; results.zvals(:, i) = r.zopt; results.uvals(:, i) = r.uopt;
+    results.pnorm(i) = r.pnorm; results.dnorm(i) = r.dnorm; results.perr(i) = r.perr; results.derr(i) = r.derr;
+    if isfield(r, 'objevals'), results.objevals(i) = r.objevals; end
+    wprev = w; w = [r.xopt; r.zopt; rho*r.uopt];
+    results.wvals(:, i) = w;
+    nz = numel(r.zopt); nx = numel(r.xopt);
+    dw = wprev - w;
+    H(i) = rhoH*norm(dw(nx+1:nx+nz))^2 + rhoH*norm(dw(nx+nz+1:end))^2;      % admm.m:305-309, 681-682
+    results.Hnormsq(i) = H(i);
+    stopnow = ~(isfield(options, 'domaxiters') && any(options.domaxiters)) && r.pnorm < r.perr && ...
+        ((isfield(options, 'nodualerror') && any(options.nodualerror)) || r.dnorm < r.derr);
+    if stopnow, break; end
+    if i > 2                                                                 % admm.m:724-741
+        wdiff = H(i-1) - H(i);
+        rhoprev = rho;
+        rho = rho*(wdiff*rhoprev)/(wdiff*wdiff);
+        if abs(rho - rhoprev) >= rhoprev*5
+            rho = rho/5;
+        elseif abs(rho - rhoprev) <= rhoprev/5
+            rho = rho*5;
+        end
+    end
+end
+results.steps = i; results.xopt = r.xopt; results.zopt = r.zopt; results.uopt = r.uopt;
+if isfield(r, 'objopt'), results.objopt = r.objopt; end
+results.runtime = runtime;
+end
+
+function destroyengine(h)
+if ~isempty(h)
+    try
+        admm_mex('destroy', h);
+    catch
+    end
+end
 end
 
 % -------------------------------------------------------------------------------------------------------

@@ -58,6 +58,8 @@ mxArray* mxCreateSparse(mwSize m, mwSize n, mwSize nzmax, mxComplexity flag);
 
 void mexErrMsgIdAndTxt(const char* identifier, const char* err_msg, ...);
 int mexCallMATLAB(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const char* functionName);
+/* as mexCallMATLAB, but an error inside the callee comes back as an MException object (NULL = success) */
+mxArray* mexCallMATLABWithTrap(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const char* functionName);
 void mexLock(void);
 void mexUnlock(void);
 int mexAtExit(void (*exit_fcn)(void));

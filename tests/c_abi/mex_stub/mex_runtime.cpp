@@ -174,6 +174,10 @@ int mexCallMATLAB(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const ch
   else mxDestroyArray(out);
   return 0;
 }
+mxArray* mexCallMATLABWithTrap(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const char* functionName) {
+  if (mexCallMATLAB(nlhs, plhs, nrhs, prhs, functionName) == 0) return nullptr;
+  return mxCreateDoubleScalar(-1.0);  // stands for the MException object
+}
 void mexLock(void) { ++g_lock; }
 void mexUnlock(void) { --g_lock; }
 int mexAtExit(void (*exit_fcn)(void)) {

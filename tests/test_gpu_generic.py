@@ -600,3 +600,95 @@ def test_basispursuit_projector_built_on_device(gpu):
     assert a["steps"] == b["steps"]
     np.testing.assert_allclose(a["xvals"], b["xvals"], rtol=0, atol=1e-10)
     _compare(a, S.basispursuit(D, sv, dict(o)), tol=1e-8)
+
+
+# ---------------------------------------------------------------------------- options.altu / specialnorms / preprocess
+def _hook_closures(damp):
+    """The caller's own u-update and norms (admm.m:553-559, 612-616) as device (torch) and host (NumPy) twins:
+    altu damps the multiplier step, specialnorms reports squared norms (as lassonorms does, getProxOps.m:1335-1343)."""
+    import torch
+
+    def altu_t(u, Ax, Bz, c):
+        return u + damp * (Ax + Bz - c)
+
+    def altu_n(u, Ax, Bz, c):
+        return u + damp * (Ax + Bz - c)
+
+    def norms_t(x, z, u, rho):
+        return torch.stack([torch.sum(z * z) + 0.5 * torch.sum(x * x), rho * rho * torch.sum(u * u)])
+
+    def norms_n(x, z, u, rho):
+        return [float(np.sum(z * z) + 0.5 * np.sum(x * x)), float(rho * rho * np.sum(u * u))]
+
+    return (altu_t, norms_t), (altu_n, norms_n)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(relax=1.4), dict(objevals=1, stopcond="both", rho=2.0),
+                                  dict(convtest=1, convtol=np.inf, maxiters=12, domaxiters=1)])
+@pytest.mark.parametrize("which", ["altu", "specialnorms", "both"])
+def test_caller_altu_and_specialnorms_with_library_lasso_operators(gpu, which, opts):
+    """getproxops('LASSO') operators (A = 1) with the caller's altu / specialnorms handles against the oracle's loop with
+    the NumPy twins: u, the histories, pnorm / dnorm (the handle's values), perr / derr (admm.m:640-658, computed as
+    always), H-norms, stopping."""
+    p = gpu.synth.lasso_problem(5, 300, 80)
+    (at, nt), (an, nn) = _hook_closures(0.8)
+    o = {"maxiters": 40, **opts}
+    args = dict(D=p["D"], s=p["s"], rho=o.get("rho", 1.0))
+    args["lambda"] = p["lam"]
+    gx, gz, _ = gpu.getproxops("LASSO", dict(args))
+    n = 80
+    Dts = p["D"].T @ p["s"]
+    import scipy.linalg as sla
+    Lf = sla.cholesky(p["D"].T @ p["D"] + o.get("rho", 1.0) * np.eye(n), lower=True)
+    rargs = dict(D=p["D"], Dts=Dts, L=Lf, U=Lf.T, m=300, n=n, parallel=0, rho=o.get("rho", 1.0))
+    rargs["lambda"] = p["lam"]
+    rx, rz, _ = PR.getproxops("LASSO", rargs)
+    obj = lambda x, z: 0.5 * float(np.sum((p["D"] @ x - p["s"]) ** 2)) + p["lam"] * float(np.sum(np.abs(z)))
+    go, ro = dict(_constraint(n, **o)), dict(_constraint(n, **o), obj=obj)
+    if which in ("altu", "both"):
+        go["altu"], ro["altu"] = at, an
+    if which in ("specialnorms", "both"):
+        go["specialnorms"], ro["specialnorms"] = nt, nn
+    _compare(gpu.admm(gx, gz, go), A.admm(rx, rz, ro), tol=TOL)
+
+
+@pytest.mark.parametrize("relax", [1.0, 1.3])
+def test_caller_altu_equal_to_the_default_update_changes_nothing(gpu, relax):
+    """altu = u + (Ax + Bz - c) is admm.m:542-550 itself: the run must reproduce the plain one (LAD, A = D: the next
+    right-hand side D'(s + z - u) and the dual-tolerance product D'u are rebuilt from the handle's u)."""
+    p = gpu.synth.lad_problem(2, 400, 40)
+    o = dict(maxiters=25, domaxiters=1, objevals=1, relax=relax)
+    plain = gpu.lad(p["D"], p["s"], dict(o))
+    gx, gz, _ = gpu.getproxops("lad", dict(D=p["D"], s=p["s"], userelax=int(relax != 1.0)))
+    got = gpu.admm(gx, gz, dict(o, A=p["D"], At=p["D"].T, B=-1, c=p["s"], m=400, nA=40, nB=400,
+                                altu=lambda u, Ax, Bz, c: u + (Ax + Bz - c)))
+    _compare(got, plain, tol=1e-12)
+    _compare(got, S.lad(p["D"], p["s"], dict(o)), tol=TOL)
+
+
+def test_caller_hooks_with_the_callers_own_operators_and_preprocess(gpu):
+    """both prox handles, altu, specialnorms and preprocess the caller's (the generic loop, convergencechecking.m's
+    shape); preprocess is called exactly once, before the first iteration (admm.m:473-476)"""
+    P, Q, r, s = _model_data(gpu, 3, 64, 64)
+    (xt, zt), (xn, zn), _ = _torch_model_closures(P, Q, r, s)
+    (at, nt), (an, nn) = _hook_closures(1.1)
+    calls = {"gpu": 0, "ref": 0}
+    o = _constraint(64, maxiters=30, stopcond="both")
+    got = gpu.admm(xt, zt, dict(o, altu=at, specialnorms=nt, preprocess=lambda: calls.__setitem__("gpu", calls["gpu"] + 1)))
+    ref = A.admm(xn, zn, dict(o, altu=an, specialnorms=nn, preprocess=lambda: calls.__setitem__("ref", calls["ref"] + 1)))
+    _compare(got, ref, tol=TOL)
+    assert calls == {"gpu": 1, "ref": 1}
+
+
+def test_caller_hooks_are_rejected_where_the_reference_never_combines_them(gpu):
+    p = gpu.synth.lasso_problem(5, 120, 30)
+    args = dict(D=p["D"], s=p["s"])
+    args["lambda"] = p["lam"]
+    gx, gz, _ = gpu.getproxops("LASSO", args)
+    (at, nt), _ = _hook_closures(1.0)
+    with pytest.raises(gpu.AdmmError, match="fast ADMM"):  # q5: admm.m:614 would overwrite fast ADMM's v
+        gpu.admm(gx, gz, dict(_constraint(30, fast=1, fasttype="strong", specialnorms=nt)))
+    with pytest.raises(TypeError):  # a host result has nowhere to run
+        gpu.admm(gx, gz, dict(_constraint(30, maxiters=3), altu=lambda u, Ax, Bz, c: np.zeros(30)))
+    res = gpu.admm(gx, gz, dict(_constraint(30, maxiters=5, domaxiters=1)))  # the engine is usable afterwards, hooks gone
+    assert res["steps"] == 5 and np.all(np.isfinite(res["pnorm"]))

@@ -215,7 +215,8 @@ def test_mex_generic_admm_with_two_matlab_handles(gpu, mex):
 
     with pytest.raises(MexError) as ei:
         mex.call("solve", "generic", dict(n=n), options, dict(xminf=broken, zming=zmin))
-    assert ei.value.identifier == "admm:engine" and "xminf callback" in ei.value.message
+    # (the handle's error is trapped -- mexCallMATLABWithTrap -- and reported once the run has been wound down)
+    assert ei.value.identifier == "admm:handle" and "raised an error" in ei.value.message
 
 
 @pytest.mark.gpu
@@ -282,3 +283,107 @@ def test_mex_persistent_engine_create_run_destroy(gpu, mex):
     _same(r2, S.lasso(D, s, lam, dict(objevals=1, fast=1, fasttype="strong")), HIST + ("objevals", "avals", "vvals"))
     with pytest.raises(MexError):
         mex.call("run", h, {})
+
+
+# ---------------------------------------------------------------------------- failed solves, hooks, adaptive stepping
+@pytest.mark.gpu
+def test_mex_failed_solve_leaves_no_engine_and_no_device_memory(gpu, mex):
+    """A 'solve' that fails -- a wrong-length x0 (refused before anything is created), a throwing MATLAB handle and a
+    handle returning the wrong length (both after create, mid-run) -- must hand back every byte of device memory: the
+    gateway holds no engine afterwards and the free device memory is where it was."""
+    import torch
+
+    p = gpu.synth.lasso_problem(3, 2000, 1200)  # the engine of a failed call would hold ~40 MB
+    args = dict(D=p["D"], s=p["s"], parallel=0, rho=1.0)
+    args["lambda"] = p["lam"]
+    options = dict(A=1, At=1, m=1200, nA=1200, nB=1200, B=-1, c=0, maxiters=5)
+    mex.call("solve", "lasso", args, options)  # warm: the runtime's own pools are allocated
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    assert mex.call("livecount") == 0
+
+    def boom(x, z, u, rho):
+        raise RuntimeError("the caller's handle fails")
+
+    cases = [(dict(options, x0=np.zeros(7)), {}, "admm:arg"),
+             (options, dict(zming=boom), "admm:handle"),
+             (options, dict(zming=lambda x, z, u, rho: np.zeros(3)), "admm:handle"),
+             (dict(options, fast=1), dict(specialnorms=lambda x, z, u, rho: np.zeros(2)), "admm:engine")]
+    for opts, handles, ident in cases * 3:
+        with pytest.raises(MexError) as ei:
+            mex.call("solve", "lasso", args, opts, handles)
+        assert ei.value.identifier == ident, (ei.value.identifier, ei.value.message)
+        assert mex.call("livecount") == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (4 << 20), (free0, torch.cuda.mem_get_info()[0])
+    got = mex.call("solve", "lasso", args, options)  # ... and the gateway still works
+    assert int(got["steps"]) >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relax", [1.0, 1.5])
+def test_mex_caller_altu_and_specialnorms_handles(gpu, mex, relax):
+    """options.altu / options.specialnorms as MATLAB handles (admm.m:553-559, 612-616): matlab/admm.m passes them in
+    `handles`; staged through host memory once per iteration, everything else on the device"""
+    p = gpu.synth.lasso_problem(4, 200, 48)
+    D, s, lam = p["D"], p["s"], p["lam"]
+    altu = lambda u, Ax, Bz, c: u + 0.7 * (Ax + Bz - c)
+    norms = lambda x, z, u, rho: np.array([float(np.sum((x - z) ** 2)), float(rho * np.sum(u * u))])
+    args = dict(D=D, s=s, parallel=0, rho=1.0)
+    args["lambda"] = lam
+    options = dict(A=1, At=1, m=48, nA=48, nB=48, B=-1, c=0, maxiters=40, relax=relax, stopcond="both")
+    got = mex.call("solve", "lasso", args, options, dict(altu=altu, specialnorms=norms))
+    Lf = np.linalg.cholesky(D.T @ D + np.eye(48))
+    rargs = dict(D=D, Dts=D.T @ s, L=Lf, U=Lf.T, m=200, n=48, parallel=0, rho=1.0)
+    rargs["lambda"] = lam
+    rx, rz, _ = ref_getproxops("LASSO", rargs)
+    ref = ref_admm(rx, rz, dict(options, altu=altu, specialnorms=lambda x, z, u, rho: list(norms(x, z, u, rho))))
+    _same(got, ref, HIST + ("Hnormsq",))
+
+
+@pytest.mark.gpu
+def test_mex_adaptive_rho_stepped_through_create_run_destroy(gpu, mex):
+    """options.adaptive (admm.m:724-741) through the gateway, as matlab/admm.m steps it: one persistent engine, one
+    device iteration per 'run' warm-started from the previous one, rho updated on the host by the reference's rule;
+    the bounded QP's closure re-factors on rho ~= rhoprev (getProxOps.m:1446-1453), so the engine is re-created for a
+    new rho.  Compared with the oracle's own adaptive loop."""
+    rng = np.random.default_rng(5)  # the problem of tests/test_gpu_generic.py::test_adaptive_rho: it stays tame
+    n = 24
+    M = rng.standard_normal((n, n))
+    P, qv, r = M @ M.T + np.eye(n), rng.standard_normal(n), 0.0
+    lb, ub = -np.ones(n), np.ones(n)
+    base = dict(A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0)
+    N = 6
+    ref = S.quadraticprogram_bounded(P, qv, r, lb, ub, dict(adaptive=1, convtest=1, convtol=1e9, maxiters=N,
+                                                            domaxiters=1))
+    rho, x, z, u = 1.0, np.zeros(n), np.zeros(n), np.zeros(n)
+    rho_h = rho  # the H-norm keeps the weight of the first rho (admm.m:305-309 captures it once)
+    w = np.concatenate([x, z, rho * u])
+    H, xs = [], []
+    h, rho_built = None, None
+    for i in range(1, N + 1):
+        if rho != rho_built:
+            if h is not None:
+                mex.call("destroy", h)
+            h = mex.call("create", "quadraticprogram", dict(P=P, q=qv, lb=lb, ub=ub, rho=rho, n=n, constraint="bounded"))
+            rho_built = rho
+        step = mex.call("run", h, dict(base, rho=rho, maxiters=1, domaxiters=1, x0=x, z0=z, u0=u, recordhistory=0))
+        x, z, u = step["xopt"], step["zopt"], step["uopt"]
+        xs.append(x)
+        wprev, w = w, np.concatenate([x, z, rho * u])
+        dw = wprev - w
+        H.append(rho_h * float(dw[n:2 * n] @ dw[n:2 * n]) + rho_h * float(dw[2 * n:] @ dw[2 * n:]))
+        if i > 2:  # admm.m:724-741 with the scalar wdiff = H1 - H2
+            wdiff = np.float64(H[-2] - H[-1])
+            rprev = rho
+            rho = float(rho * (wdiff * rprev) / (wdiff * wdiff))
+            if abs(rho - rprev) >= rprev * 5:
+                rho = rho / 5
+            elif abs(rho - rprev) <= rprev / 5:
+                rho = rho * 5
+            if not rho > 0:
+                break
+    mex.call("destroy", h)
+    assert mex.call("livecount") == 0
+    assert len(xs) == N and rho != 1.0
+    assert _rel(np.stack(xs, axis=1), np.asarray(ref["xvals"])) < 1e-6
