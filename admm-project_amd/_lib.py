@@ -93,6 +93,7 @@ class EngineInfo(C.Structure):
         ("unwrapped_fused", C.c_int32), ("factor_n", C.c_int64), ("rank", C.c_int64),
         ("cond_estimate", C.c_double), ("probe_err_inverse", C.c_double), ("probe_err_trsv", C.c_double),
         ("probe_diff", C.c_double), ("xsolve_cacheable_bytes", C.c_int64), ("xsolve_stream_bytes", C.c_int64),
+        ("obj_bound_max", C.c_double), ("obj_form_literal", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -50,6 +50,8 @@ struct Ctrl {
   double d, dprev;         // accelerated ADMM restart value (admm.m:278-279, 572-588)
   double coef;             // (aprev-1)/acurr for the extrapolation in flight
   double restart_flag;     // 1 if the iteration in flight restarted
+  double obj_bound;        // largest cancellation bound of the right-hand-side objective form seen in this run
+                           // (finalize_device.h; 0 when that form is not in use)
 };
 
 // Matrices larger than this are streamed with non-temporal loads: they cannot stay in L2 / Infinity

@@ -1521,6 +1521,9 @@ int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
       info->xsolve_stream_bytes += 2 * (tiles - cached) * tile_bytes;
     }
   };
+  info->obj_bound_max = e->obj_bound_seen;
+  info->obj_form_literal = (e->obj_alt && e->obj_auto && e->obj_gram_bad) ? 1 : 0;
+  info->reserved0 = 0;
   info->xsolve_cacheable_bytes = info->xsolve_stream_bytes = 0;
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS) {
     for (const ConsSlice& sl : e->cslices) tally(sl.fac);

@@ -120,6 +120,7 @@ struct admm_engine {
   // obj_gram = 0 (automatic): calibrate against the literal form during the first batch, then decide (engine_run.hip)
   bool obj_alt = false;  // the solve-identity form of the lasso objective is available (1/2*s's is known)
   bool obj_auto = false, obj_gram_ok = false, obj_gram_bad = false;
+  double obj_bound_seen = 0.0;  // largest cancellation bound of the right-hand-side objective form over all runs
   double* gobjpart = nullptr;  // [kMaxPartBlocks + 1] Gram-form partials during calibration; last entry: max discrepancy
   bool tv2_dct = false;          // spectral x-update instead of CG: the height a power of two (dct.h)
   bool tv2_rows_dct = false;     // ... and the width too: the row DCT exists as the fall-back of the Toeplitz row stage

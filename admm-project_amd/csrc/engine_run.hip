@@ -707,13 +707,17 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     fa.obj_scale_x = 1.0;
     fa.obj_const = alt_const;
   }
-  const bool obj_kernels =
+  // the cancellation bound of that form (finalize_device.h) is tracked whenever the engine chose it itself
+  // (obj_gram = 0): past 1e-10 the run goes back to the literal pass at the next batch boundary, below
+  const bool gram_guard = alt_ok && e->obj_auto && !use_graph && !sharded;
+  fa.obj_track_bound = (gram_guard && (gram_now || gram_calibrating)) ? 1 : 0;
+  bool obj_kernels =
       o.objevals && (((obj_lasso_gemv || obj_qp_gemv) && !gram_now) || obj_model_gemv || e->ocb);
   // ... and so do A = D iterations that record no dual residual (unwrappedadmm.m:92 sets nodualerror for the SVM):
   // without it the finalize logic needs none of the D' products that follow the prox kernel
   // (row-sharded A = I engines keep x, z, u replicated and exchange nothing per iteration unless the x-solve's tiles
   // are split over the ranks -- symv_apply's one all-reduce, before this tail: they run the same tail as one rank)
-  const bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && (!sharded || e->a_identity) &&
+  bool fuse_tail = (e->a_identity || o.nodualerror) && alg != 2 && !split_z && (!sharded || e->a_identity) &&
                          !obj_kernels && !hooks &&
                          len <= int64_t{128} * kMaxPartBlocks && std::getenv("ADMM_HIP_NO_FUSED_TAIL") == nullptr;
   // With the packed lower-triangle x-solve in front of it, the finalize logic of an A = I iteration is deferred: the
@@ -723,11 +727,11 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (also with the x-solve's tiles split over the ranks: symv_apply hands the same passenger to its launch)
   const bool split_symv = sharded && e->sy_split && e->xfac.mode == ADMM_XSOLVE_INVERSE && e->xfac.Minv && !e->xcb &&
                           (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED) && !e->fat;
-  const bool defer_fin = fuse_tail && e->a_identity && (xsolve_has_partials(e) || split_symv) && e->xfac.planSy.packed && !use_graph &&
+  bool defer_fin = fuse_tail && e->a_identity && (xsolve_has_partials(e) || split_symv) && e->xfac.planSy.packed && !use_graph &&
                          std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   // A = D iterations without a dual residual (fuse_tail): the finalize logic leaves the element update's launch too and
   // runs as one extra workgroup of the partial-sum launch of D'*(c + z - u) that follows it (gemv.hip)
-  const bool defer_fin_ad = fuse_tail && !e->a_identity && e->D && !(e->atcb && !e->D) && !use_graph &&
+  bool defer_fin_ad = fuse_tail && !e->a_identity && e->D && !(e->atcb && !e->D) && !use_graph &&
                             std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   FinArgs dff{};
   e->dfin = nullptr;
@@ -1025,12 +1029,32 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         if (e->ctrl_host->stop) stopped = true;
       }
     }
+    // The right-hand-side form of the objective cancels terms of the size of 1/2*s's down to the data misfit: once
+    // eps * |terms| / |objective| (the device keeps the run's maximum in ctrl) leaves 1e-10 -- a near-interpolating fit,
+    // small lambda, little noise -- the engine goes back to the literal D*x pass (lasso.m:227), for the rest of this
+    // run and for every later one.  Nothing is pending at a batch boundary, so the launch sequence may change here.
+    if (gram_guard && gram_now && polled && e->ctrl_host->obj_bound > 1e-10) {
+      e->obj_gram_ok = false;
+      e->obj_gram_bad = true;
+      gram_now = false;
+      obj_kernels = true;
+      fuse_tail = false;
+      defer_fin = false;
+      defer_fin_ad = false;
+      fa.obj_track_bound = 0;
+      pa.objx = OBJX_NONE;
+      fa.obj_scale_x = 0.0;
+      fa.obj_const = 0.0;
+      fa.obj_scale_part = alt_qp ? 1.0 : 0.5;
+      if (alt_qp) fa.obj_const = e->rconst;
+    }
+    if (polled && e->ctrl_host->obj_bound > e->obj_bound_seen) e->obj_bound_seen = e->ctrl_host->obj_bound;
     if (gram_calibrating && loop_rc == ADMM_OK) {  // the batch evaluated both forms of the lasso objective
       double disc = 1.0;
       if (hipMemcpy(&disc, e->gobjpart + kMaxPartBlocks, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         loop_rc = fail(ADMM_E_DEVICE, "reading the objective calibration failed");
       gram_calibrating = false;
-      if (disc <= 1e-11) {
+      if (disc <= 1e-11 && !(e->ctrl_host->obj_bound > 1e-10)) {
         e->obj_gram_ok = true;
         gram_now = true;
       } else {

@@ -100,8 +100,18 @@ __device__ __forceinline__ void finalize_body(const FinArgs& a) {
     a.hnorm[it] = hn;
   }
   if (a.objevals && a.objv) {
-    a.objv[it] = a.obj_scale_part * objp + a.obj_scale_z * S[S_OBJZ] + a.obj_scale_x * S[S_OBJX] +
-                 a.obj_half_xnorm * nx2 + a.obj_const;
+    const double ov = a.obj_scale_part * objp + a.obj_scale_z * S[S_OBJZ] + a.obj_scale_x * S[S_OBJX] +
+                      a.obj_half_xnorm * nx2 + a.obj_const;
+    a.objv[it] = ov;
+    if (a.obj_track_bound) {
+      // 1/2*||D*x - s||^2 = sum_i x_i*(1/2*(y_i - rho*x_i) - (D's)_i) + 1/2*s's: terms of the size of s's that cancel down
+      // to the data misfit.  eps * (sum of their magnitudes) / |objective| bounds the relative rounding error of the
+      // recorded value; the host reads the run's maximum after every batch and goes back to the literal D*x pass when
+      // it leaves 1e-10 (engine_run.hip)
+      const double bound = 2.220446049250313e-16 * (fabs(a.obj_scale_x) * S[S_OBJA] + fabs(a.obj_const)) /
+                           fmax(fabs(ov), 1e-300);
+      if (!(bound <= ctrl->obj_bound)) ctrl->obj_bound = bound;  // NaN-safe maximum
+    }
   }
   bool stop = false;
   if (a.alg == 2) {

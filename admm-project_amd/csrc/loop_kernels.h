@@ -52,7 +52,8 @@ enum Slot : int32_t {
   S_DZV2 = 9,  // ||z - v||^2                          admm.m:573
   S_G2 = 10,   // ||D'(z - zprev)||^2 via stencil (TV)   admm.m:624
   S_G3 = 11,   // ||D'u||^2 via stencil (TV)             admm.m:654
-  S_COUNT = 12
+  S_OBJA = 12, // sum of |terms| of the S_OBJX sum (OBJX_SOLVE / _QP): the size of what cancels in it
+  S_COUNT = 13
 };
 
 struct ProxArgs {
@@ -150,6 +151,7 @@ struct FinArgs {
   double* restarted;
   Ctrl* ctrl;
   const double* norms_given;    // options.specialnorms as the caller's handle: pnorm, dnorm (admm.m:612-616), else null
+  int32_t obj_track_bound;      // the objective is the right-hand-side form (OBJX_SOLVE): track eps*|terms|/|objective|
 };
 
 // First half of a split z-update (PROX_GIVEN): what the z-prox is called with (admm.m:515-530).

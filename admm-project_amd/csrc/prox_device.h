@@ -119,8 +119,15 @@ __device__ __forceinline__ void prox_apply(const ProxArgs& a, int64_t i, double 
     acc[S_OBJX] += (q > 0.0) ? 1.0 : 0.0;  // max(sign(q),0)
   } else if (a.objx == OBJX_ABS) acc[S_OBJX] += fabs(ax);
   else if (a.objx == OBJX_DOT) acc[S_OBJX] += ell_i * ax;
-  else if (a.objx == OBJX_SOLVE) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho_solve * ax) - add_i);
-  else if (a.objx == OBJX_SOLVE_QP) acc[S_OBJX] += ax * (0.5 * (in.rhs_i - a.rho_solve * ax) + add_i);
+  else if (a.objx == OBJX_SOLVE) {
+    const double term = ax * (0.5 * (in.rhs_i - a.rho_solve * ax) - add_i);
+    acc[S_OBJX] += term;
+    acc[S_OBJA] += fabs(ax * (0.5 * (in.rhs_i - a.rho_solve * ax))) + fabs(ax * add_i);  // what cancels in it
+  } else if (a.objx == OBJX_SOLVE_QP) {
+    const double term = ax * (0.5 * (in.rhs_i - a.rho_solve * ax) + add_i);
+    acc[S_OBJX] += term;
+    acc[S_OBJA] += fabs(ax * (0.5 * (in.rhs_i - a.rho_solve * ax))) + fabs(ax * add_i);
+  }
 
   a.z[i] = zn;
   a.u[i] = un;

@@ -366,6 +366,10 @@ __device__ __forceinline__ void tv2_tile(const TvArgs& a, unsigned tile_id, int6
     const double q0 = tv2_reduce4(acc[S_R2], acc[S_AX2], acc[S_Z2], acc[S_DZ2]);      // rows: R2 | Z2 | AX2 | DZ2
     const double q1 = tv2_reduce4(acc[S_U2], acc[S_DU2], acc[S_OBJZ], acc[S_OBJX]);   // rows: U2 | OBJZ | DU2 | OBJX
     const double q2 = tv2_reduce4(acc[S_G2], acc[S_G3], 0.0, 0.0);                    // rows: G2 | 0 | G3 | 0
+    if (lane == 0) {
+#pragma unroll
+      for (int s = 12; s < S_COUNT; ++s) sred[wid * S_COUNT + s] = 0.0;  // slots this iteration does not produce
+    }
     if ((lane & 15) == 0) {
       const int row = lane >> 4;
       const int s0 = row == 0 ? S_R2 : row == 1 ? S_Z2 : row == 2 ? S_AX2 : S_DZ2;

@@ -428,7 +428,8 @@ class Engine:
                     probed=bool(i.probed), unwrapped_fused=bool(i.unwrapped_fused), trsv_blocks=i.trsv_blocks, jacobi_sweeps=i.jacobi_sweeps,
                     factor_n=i.factor_n, rank=i.rank, cond_estimate=i.cond_estimate,
                     probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_diff=i.probe_diff,
-                    xsolve_cacheable_bytes=i.xsolve_cacheable_bytes, xsolve_stream_bytes=i.xsolve_stream_bytes)
+                    xsolve_cacheable_bytes=i.xsolve_cacheable_bytes, xsolve_stream_bytes=i.xsolve_stream_bytes,
+                    obj_bound_max=i.obj_bound_max, obj_form_literal=bool(i.obj_form_literal))
 
     def set_profiling(self, on, stride=1):
         """True/False, or an iterable of kernel classes (L.K_XSOLVE, ...) to time with HIP events; stride > 1 times

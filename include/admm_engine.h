@@ -312,6 +312,12 @@ typedef struct admm_engine_info_t {
    * Consensus lasso: summed over the local slices.  0 / 0 where no n x n operand exists. */
   int64_t xsolve_cacheable_bytes;
   int64_t xsolve_stream_bytes;
+  /* lasso / bounded-QP objective through the x-update's right-hand side (desc.obj_gram): the largest value of
+   * eps * |cancelling terms| / |objective| any recorded objective of this engine has had (0: form never used); past
+   * 1e-10 the engine has gone back to the literal form (obj_form_literal = 1) */
+  double obj_bound_max;
+  int32_t obj_form_literal;
+  int32_t reserved0;
 } admm_engine_info_t;
 int admm_engine_info(admm_engine* eng, admm_engine_info_t* info);
 /* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */

@@ -834,3 +834,37 @@ def test_svm_wide_matrix_uses_the_pseudo_inverse(gpu, m, n):
         _close(k, got[k], ref[k], 1e-6)
     np.testing.assert_allclose(got["uvals"], ref["uvals"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(got["uopt"], ref["uopt"], rtol=1e-6, atol=1e-9)
+
+
+def test_lasso_objective_falls_back_to_the_literal_form_when_it_cancels(gpu):
+    """lasso.m:227 on a near-interpolating problem (s = D*x0 exactly, lambda tiny): 1/2*||D*x - s||^2 falls five orders
+    below 1/2*s's, and the right-hand-side form of the objective -- terms of the size of s's that cancel -- loses those
+    digits.  The engine tracks eps*|terms|/|objective| per recorded value and returns to the literal D*x pass once it
+    leaves 1e-10, for the rest of the run and for later runs; every recorded objective agrees with the oracle entry by
+    entry (no floor), the bar being 1e-6."""
+    L = gpu._lib
+    p = gpu.synth.lasso_problem(7, 400, 100)
+    D = p["D"]
+    s = D @ p["testx"]
+    lam = 1e-7 * float(np.max(np.abs(D.T @ s)))
+    o = dict(objevals=1, maxiters=400)
+    ref = S.lasso(D, s, lam, dict(o))
+    obj_ref = np.asarray(ref["objevals"])
+    assert obj_ref[-1] < 1e-5 * 0.5 * float(s @ s)  # the misfit really is that small
+    eng = gpu.Engine(L.PROB_LASSO, D=D, s=s, lam=lam, rho=1.0, xsolve=L.XSOLVE_INVERSE)
+    try:
+        for run in range(2):
+            st = eng.run(objevals=1, maxiters=400)
+            assert st.steps == ref["steps"]
+            got = eng.fetch(L.F_OBJEVALS, st.steps)
+            assert np.max(np.abs(got - obj_ref) / np.abs(obj_ref)) < 1e-6
+            info = eng.info()
+            assert info["obj_form_literal"] and info["obj_bound_max"] > 1e-10
+            if run == 1:
+                assert int(st.obj_gram_used) == 0  # the second run never leaves the literal form
+    finally:
+        eng.close()
+    # an ordinary problem (lassotest.m's recipe) keeps the one-pass form: bound ~ 1e-15
+    q = gpu.synth.lasso_problem(0, 256, 64)
+    res = gpu.lasso(q["D"], q["s"], q["lam"], dict(objevals=1))
+    assert not res["engine_info"]["obj_form_literal"] and 0 < res["engine_info"]["obj_bound_max"] < 1e-12
