@@ -43,6 +43,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
@@ -70,6 +71,7 @@ RcclApi& rccl() {
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce)
@@ -90,7 +92,8 @@ constexpr size_t kShmSlotElems = 1u << 20;  // 8 MiB of doubles per rank and rou
 struct ShmHeader {
   std::atomic<uint64_t> arrived;  // monotone arrival counter (barrier k completes at k*nranks)
   std::atomic<uint64_t> attached;
-  uint64_t pad[6];
+  std::atomic<uint64_t> aborted;  // a rank of the group failed outside a collective: every barrier gives up (comm_abort)
+  uint64_t pad[5];
 };
 
 struct ShmState {
@@ -132,6 +135,9 @@ int shm_barrier(admm_comm* c) {
   const auto t0 = std::chrono::steady_clock::now();
   int spins = 0;
   while (h->arrived.load(std::memory_order_acquire) < target) {
+    if (h->aborted.load(std::memory_order_acquire) != 0)
+      return fail(ADMM_E_COMM, "a peer rank reported a failure: the collective was abandoned (the communicators of "
+                               "this group are unusable now)");
     if (++spins > 2000) {
       std::this_thread::sleep_for(std::chrono::microseconds(50));
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
@@ -204,6 +210,22 @@ int shm_allreduce(admm_comm* c, double* dbuf, size_t count, hipStream_t stream) 
 
 namespace admm {
 
+// A rank failed where its peers cannot see it (a bad descriptor, an out-of-memory, a rank-local Cholesky breakdown) while
+// they sit in, or are about to enter, a collective that now never completes.  SHM: the group's shared header says so and
+// every barrier returns ADMM_E_COMM.  RCCL: ncclCommAbort (callable from another thread) tears the communicator down and
+// lets the kernel a peer is blocked in finish.  The group is unusable afterwards.
+void comm_abort(admm_comm* c) {
+  if (!c) return;
+  if (c->transport == ADMM_COMM_SHM) {
+    if (c->shm.base) static_cast<ShmHeader*>(c->shm.base)->aborted.store(1, std::memory_order_release);
+    return;
+  }
+  if (c->comm && rccl().CommAbort) {
+    (void)rccl().CommAbort(c->comm);
+    c->comm = nullptr;
+  }
+}
+
 int comm_nranks(admm_comm* c) { return c ? c->nranks : 1; }
 int comm_rank(admm_comm* c) { return c ? c->rank : 0; }
 bool comm_is_async(admm_comm* c) { return !c || c->nranks == 1 || c->transport == ADMM_COMM_RCCL; }
@@ -213,6 +235,7 @@ bool comm_is_async(admm_comm* c) { return !c || c->nranks == 1 || c->transport =
 int comm_allreduce_device(admm_comm* c, double* buf, size_t count, hipStream_t stream) {
   if (!c || c->nranks == 1 || count == 0) return ADMM_OK;
   if (c->transport == ADMM_COMM_SHM) return shm_allreduce(c, buf, count, stream);
+  if (!c->comm) return fail(ADMM_E_COMM, "the communicator was aborted after a peer rank's failure");
   ncclResult_t r = rccl().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, c->comm, stream);
   if (r != 0) return rccl_fail("ncclAllReduce", r);
   return ADMM_OK;

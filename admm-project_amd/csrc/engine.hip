@@ -419,6 +419,50 @@ static int scaled_tdot(admm_engine* e, const double* T, int64_t m, int64_t n, in
   return ADMM_OK;
 }
 
+// The affine maps built below (x = K*y + k0 of the eliminated KKT system; x = P*v + q of basis pursuit) go through
+// explicit inverses of D*inv(M)*D' resp. D*D', whose condition number is cond(D)^2 -- where the reference solves the
+// KKT system by pivoted backslash in every iteration (getProxOps.m:1363, 1410) or forms P by backslash
+// (basispursuit.m:116-120).  What must survive is the constraint: every x the map produces satisfies D*x = s.  Probe it
+// once, for an unstructured argument: relative violation max|D*x - s| / (max|s| + max|D*x|) above 1e-9 refuses the
+// problem (ADMM_E_NUMERIC) instead of iterating on iterates that silently leave the feasible set.
+static int probe_affine_map(admm_engine* e, const double* D, int64_t m, int64_t n, int64_t ldD, const double* s_dev,
+                            const double* Kmat, int64_t ldK, const double* k0, const char* what) {
+  std::vector<double> yh(static_cast<size_t>(n)), xh(static_cast<size_t>(n)), rh(static_cast<size_t>(m)),
+      sh(static_cast<size_t>(m));
+  for (int64_t i = 0; i < n; ++i) yh[i] = std::sin(0.7 * static_cast<double>(i) + 0.3) + 0.25;
+  double *y = nullptr, *x = nullptr, *r = nullptr, *partK = nullptr, *partD = nullptr;
+  ADMM_TRY(e->mem.alloc(&y, round_up(n, 2)));
+  ADMM_TRY(e->mem.alloc(&x, round_up(n, 2)));
+  ADMM_TRY(e->mem.alloc(&r, round_up(m, 2)));
+  ADMM_HIP_TRY(hipMemcpyAsync(y, yh.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+  const GemvTPlan pk = gemv_t_plan(n, n, ldK);  // K (P) is symmetric: K*y as column dots
+  ADMM_TRY(e->mem.alloc(&partK, pk.part_elems(1)));
+  launch_gemv_t(pk, Kmat, y, nullptr, nullptr, 1, partK, nullptr, e->stream);
+  launch_sum_partials_t(pk, partK, 1, x, round_up(n, 2), nullptr, e->stream);
+  launch_combine(x, 1, 0, 1.0, nullptr, 0.0, k0, x, n, nullptr, e->stream);  // x = K*y + k0
+  const GemvNPlan pd = gemv_n_plan(m, n, ldD);
+  ADMM_TRY(e->mem.alloc(&partD, pd.part_elems()));
+  launch_gemv_n(pd, D, x, partD, nullptr, e->stream);
+  launch_sum_partials(partD, pd.nchunk, pd.ldy, m, r, nullptr, e->stream);
+  ADMM_HIP_TRY(hipMemcpyAsync(rh.data(), r, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipMemcpyAsync(sh.data(), s_dev, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
+  for (double* p : {y, x, r, partK, partD}) mem_free_one(e->mem, p);
+  double viol = 0.0, scale = 0.0;
+  bool finite = true;
+  for (int64_t i = 0; i < m; ++i) {
+    finite = finite && std::isfinite(rh[i]);
+    viol = std::max(viol, std::fabs(rh[i] - sh[i]));
+    scale = std::max(scale, std::max(std::fabs(rh[i]), std::fabs(sh[i])));
+  }
+  const double rel = viol / (scale > 0.0 ? scale : 1.0);
+  if (!finite || !(rel <= 1e-9))
+    return fail(ADMM_E_NUMERIC, std::string(what) + ": the constraint matrix D is too ill-conditioned for the eliminated "
+                                    "solve (cond(D)^2 enters it): D*x = s is violated by " + std::to_string(rel) +
+                                    " (relative) for a probe vector; the reference's pivoted KKT solve would be needed");
+  return ADMM_OK;
+}
+
 // basispursuit.m:116-120: P = I - D'(DD')^-1 D, q = D'(DD')^-1 s for a fat D (m x n, m < n) -- MFMA GEMMs, the
 // Cholesky factorisation and the explicit m x m inverse on the device (the reference computes them in MATLAB)
 static int build_bp_projector(admm_engine* e, const double* D, int64_t m, int64_t n, int64_t ldD, const double* s_dev) {
@@ -441,7 +485,7 @@ static int build_bp_projector(admm_engine* e, const double* D, int64_t m, int64_
   mem_free_one(e->mem, W);
   mem_free_one(e->mem, Ginv);
   mem_free_one(e->mem, X);
-  return ADMM_OK;
+  return probe_affine_map(e, D, m, n, ldD, s_dev, e->Pmat, e->ldP, e->q, "basis pursuit");
 }
 
 // getProxOps.m:1363 / 1410 solve [M D'; D 0] [x; nu] = [y; s] every iteration, M = rho*I (linear program) or P + rho*I
@@ -491,7 +535,7 @@ static int build_kkt_map(admm_engine* e, const double* D, int64_t m, int64_t n, 
   ADMM_TRY(e->mem.alloc(&e->k0, round_up(n, 2)));
   ADMM_TRY(scaled_tdot(e, T2, m, n, ldm, s_dev, 1.0, e->k0));  // k0 = T2' s = inv(M) D' inv(S) s
   for (double* p : {MD, S, Sinv, T2, Mi}) mem_free_one(e->mem, p);
-  return ADMM_OK;
+  return probe_affine_map(e, D, m, n, ldD, s_dev, e->Kmat, ldn, e->k0, P ? "quadratic program" : "linear program");
 }
 
 // the engine's own x-update factor

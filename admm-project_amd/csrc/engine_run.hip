@@ -209,6 +209,12 @@ int admm_engine_set_callbacks(admm_engine* e, admm_prox_callback xmin, void* xus
   return ADMM_OK;
 }
 
+}  // extern "C"
+namespace admm {
+admm_comm* engine_comm(admm_engine* e) { return e ? e->comm : nullptr; }
+}  // namespace admm
+extern "C" {
+
 int admm_engine_set_hooks(admm_engine* e, admm_altu_callback altu, void* altu_user, admm_norms_callback norms,
                           void* norms_user) {
   if (!e) return fail(ADMM_E_INVALID, "engine is NULL");

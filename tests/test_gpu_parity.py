@@ -868,3 +868,37 @@ def test_lasso_objective_falls_back_to_the_literal_form_when_it_cancels(gpu):
     q = gpu.synth.lasso_problem(0, 256, 64)
     res = gpu.lasso(q["D"], q["s"], q["lam"], dict(objevals=1))
     assert not res["engine_info"]["obj_form_literal"] and 0 < res["engine_info"]["obj_bound_max"] < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["lp", "qp", "bp"])
+def test_eliminated_constraint_solves_are_probed(gpu, kind):
+    """LP / standard-form QP (getProxOps.m:1363, 1410: a pivoted KKT solve per iteration in the reference) and basis
+    pursuit (basispursuit.m:116-120) run on affine maps the engine builds ONCE through explicit inverses of D*inv(M)*D'
+    resp. D*D' -- cond(D)^2.  create() probes D*x = s on the finished map: a graded D with cond 1e2 / 1e3 stays at
+    oracle parity, cond 1e7 is refused (ADMM_E_NUMERIC) instead of iterating off the constraint."""
+    rng = np.random.default_rng(11)
+    m, n = 24, 80
+    for kappa, ok in ((1e2, True), (1e3, True), (1e7, False)):
+        D = np.asfortranarray(gpu.synth.graded_matrix(3, n, m, kappa).T)  # m x n, singular values 1 .. 1/kappa
+        truex = np.abs(rng.standard_normal(n))
+        s = D @ truex
+        o = dict(maxiters=60, domaxiters=1, objevals=1)
+        if kind == "lp":
+            b = rng.random(n) + 0.5
+            run = lambda: gpu.linearprogram(b, D, s, dict(o))
+            ref = lambda: S.linearprogram(b, D, s, dict(o))
+        elif kind == "qp":
+            G = rng.standard_normal((n, n))
+            P, q = G @ G.T / n + np.eye(n), rng.standard_normal(n)
+            run = lambda: gpu.quadraticprogram(P, q, 0.3, D, s, dict(o))
+            ref = lambda: S.quadraticprogram_standard(P, q, 0.3, D, s, dict(o))
+        else:
+            run = lambda: gpu.basispursuit(D, s, dict(o))
+            ref = lambda: S.basispursuit(D, s, dict(o))
+        if ok:
+            got = run()
+            _compare(got, ref(), tol=1e-6)
+            assert np.max(np.abs(D @ got["xopt"] - s)) <= 1e-8 * np.max(np.abs(s))
+        else:
+            with pytest.raises(gpu.AdmmError, match="ill-conditioned"):
+                run()

@@ -115,3 +115,42 @@ def test_native_create_all_run_all(gpu):
         assert "rank 1" in str(ei.value)
     finally:
         grp.close()
+
+
+def test_a_rank_failing_outside_a_collective_releases_its_peers(gpu):
+    """admm_engine_create_all with ONE rank whose description is unusable (no matrix): that rank fails before its first
+    collective while the other seven have entered the all-reduce of D_g'D_g.  The failing rank's thread abandons the
+    group (comm_abort: the shm header's flag; ncclCommAbort on RCCL), so the call returns the first failure in seconds
+    instead of sitting in the barrier until its 120 s timeout (for ever, inside RCCL).  A fresh group works."""
+    import time
+
+    from admm_project_amd import parallel
+    L = gpu._lib
+    m, n = 1003, 40
+    p = gpu.synth.lad_problem(0, m, n)
+    g = parallel.LocalGroup(8, devices=[0] * 8, transport="shm")
+    try:
+        kw = []
+        for r in range(8):
+            lo, hi = parallel.my_rows(m, g.comms[r])
+            kw.append(dict(D=p["D"][lo:hi], s=p["s"][lo:hi], comm=g.comms[r]))
+        kw[3] = dict(s=p["s"][:5], comm=g.comms[3], nvec=n)  # no D: admm_engine_create refuses it on the spot
+        t0 = time.perf_counter()
+        with pytest.raises(gpu.AdmmError) as ei:
+            gpu.Engine.create_all(L.PROB_LAD, kw)
+        assert time.perf_counter() - t0 < 30.0
+        assert "rank 3" in str(ei.value)
+    finally:
+        g.close()
+    g2 = parallel.LocalGroup(2, devices=[0, 0], transport="shm")
+    try:
+        ref = S.lad(p["D"], p["s"], dict(maxiters=5, domaxiters=1))
+
+        def rank(r, comm):
+            lo, hi = parallel.my_rows(m, comm)
+            return gpu.lad(p["D"][lo:hi], p["s"][lo:hi], dict(maxiters=5, domaxiters=1, comm=comm))
+
+        for res in g2.on_ranks(rank):
+            assert _rel(res["xvals"], ref["xvals"]) < 1e-9
+    finally:
+        g2.close()
