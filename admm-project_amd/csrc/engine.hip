@@ -165,7 +165,7 @@ static int probe_and_choose(admm_engine* e, SliceFactor& f) {
     ADMM_HIP_TRY(hipMemcpyAsync(xi.data(), dxi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
     ADMM_HIP_TRY(hipMemcpyAsync(xt.data(), dxt, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
     ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
-    return ADMM_OK;
+    return trsv_check_error(f.trsv, e->stream);
   };
   rc = run();
   double ei = 0.0, et = 0.0;

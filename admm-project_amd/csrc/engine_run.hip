@@ -598,7 +598,14 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   xa.rhs_kind = e->xcb ? RHS_NONE : e->rhs_kind;
 
   RunState rs{o, alg, N, len, pa, fa, xa};
-  if (e->problem == ADMM_PROB_LASSO_CONSENSUS) return run_consensus_lasso(e, rs, summary);
+  auto trsv_ok = [&](int rc) -> int {  // the one-launch triangular solves report a lost tile through their plan
+    if (rc != ADMM_OK) return rc;
+    ADMM_TRY(trsv_check_error(e->xfac.trsv, e->stream));
+    ADMM_TRY(trsv_check_error(e->zfac.trsv, e->stream));
+    for (const ConsSlice& sl : e->cslices) ADMM_TRY(trsv_check_error(sl.fac.trsv, e->stream));
+    return ADMM_OK;
+  };
+  if (e->problem == ADMM_PROB_LASSO_CONSENSUS) return trsv_ok(run_consensus_lasso(e, rs, summary));
   if (e->problem == ADMM_PROB_TV2D) return run_total_variation_2d(e, rs, summary);
   if (e->problem == ADMM_PROB_TOTALVARIATION) return run_total_variation(e, rs, summary);
 
@@ -1109,7 +1116,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   }
   e->has_run = true;
   if (summary) *summary = e->last;
-  return ADMM_OK;
+  return trsv_ok(ADMM_OK);
 }
 
 }  // extern "C"

@@ -109,6 +109,15 @@ struct TrsvPlan {
   double* P[2];              // [bt][npad] column-tile partials: the step in flight and the previous one
   double *v, *w;             // running right-hand sides (npad)
   bool streaming;            // non-temporal matrix loads (matrix larger than the caches)
+  // one-launch form (trsv.hip: tri_persist_kernel): every step's partials and running right-hand side in buffers of
+  // their own (written once per launch), per-(step, row tile) completion counters, the ordered work list
+  bool persist;              // available (built) and not disabled by ADMM_TRSV_STEPS
+  double* PP;                // [2*nblk][bt][npad] column-tile partials of every step
+  double* BB;                // [2*nblk][npad] running right-hand side as every step leaves it
+  int32_t* sync;             // [0] ticket, [1] done, [2] error, [3] pad, then counters [2*nblk][ntile]
+  const void* items;         // device: TpItem[nitems]
+  const int32_t* chunks;     // device: first item of every ticket, [nchunks + 1]
+  int32_t nitems, nchunks, grid;
 };
 // doubles the plan needs in one caller-owned device buffer
 size_t trsv_plan_elems(int64_t n);
@@ -116,6 +125,8 @@ size_t trsv_plan_elems(int64_t n);
 int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
                hipStream_t stream);
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream);
+// the one-launch form's error word (synchronises the stream): ADMM_OK, or ADMM_E_DEVICE after a poll gave up
+int trsv_check_error(const TrsvPlan& p, hipStream_t stream);
 
 // ---------------------------------------------------------------- symmetric eigen-decomposition (jacobi.hip)
 // W (n x n symmetric PSD, FULL storage) is overwritten by W*V; V gets the eigenvectors, lam_host the eigenvalues

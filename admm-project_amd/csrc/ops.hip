@@ -143,6 +143,7 @@ int admm_op_trsv_pair(const double* L, int64_t n, int64_t ldL, const double* y, 
   ADMM_TRY(sc.alloc(&buf, trsv_plan_elems(n)));
   ADMM_TRY(trsv_build(dL, n, ld, dinv, buf, &plan, nullptr));
   launch_trsv_pair(plan, dy, dx, nullptr, nullptr);
+  ADMM_TRY(trsv_check_error(plan, nullptr));
   ADMM_HIP_TRY(hipDeviceSynchronize());
   ADMM_HIP_TRY(hipMemcpy(x, dx, sizeof(double) * n, hipMemcpyDeviceToHost));
   return ADMM_OK;

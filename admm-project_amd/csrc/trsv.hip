@@ -24,7 +24,10 @@
 // only of the K diagonal blocks (forward error eps*cond(L_kk), like any blocked TRSV with pre-inverted diagonal
 // blocks), so this is the numerically safe fallback of the `inverse` form.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "kernels.h"
 
@@ -216,6 +219,243 @@ __global__ __launch_bounds__(kWave) void tri_fold_kernel(TriStepArgs a) {
   ts_store_vec(a.diag_out, e, a.n, ts_sum_prev(a, q0, q1, e));
 }
 
+// ---------------------------------------------------------------- the same solve pair as ONE launch
+// The 2K + 1 launches above cost ~6 us each beyond their streaming (boundary, ramp-up, the fold of the previous step's
+// partials in front of every tile, the tail): 55 of 187 us at n = 10^4.  tri_persist_kernel runs the whole pair -- the
+// same tiles, the same panels, the same fixed-order sums -- from an ordered work list:
+//   * a workgroup (4 waves: 32 columns of a 128 x 128 tile each, summed through LDS) takes the next ticket, i.e. the
+//     next tile of the list, as soon as it is free -- whatever workgroups the device has resident make progress, and a
+//     tile's producers always hold earlier tickets, so nobody waits for work that has not been handed out;
+//   * step s writes its column-tile partials and its running right-hand side into buffers of its OWN (write-once per
+//     launch: no reuse hazards, nothing stale to find in a cache), published with write-through (sc1) stores; the
+//     storing wave drains them (s_waitcnt vmcnt(0)) and one lane adds 1 to the counter of (step, row tile);
+//   * a tile whose input block is row tile T of the previous step polls that counter (one lane, sc1 loads, s_sleep),
+//     the workgroup meets at a barrier, and every load of the handed-over bytes is an sc1 load
+//     (MI355X_MICROARCH.md, inter-workgroup visibility: the flag-table protocol);
+//   * within a step the list puts the row tiles the NEXT step's inputs come from first (column-tile major), then the
+//     diagonal block, then the rest: while the next block's input is completing, the rest of this step's panel streams.
+// The last workgroup to finish zeroes counters and tickets for the next launch.  A poll that does not complete within
+// ~2 s (a lost producer: should not happen) raises the plan's error word instead of hanging the device.
+// MEASURED (round 3, n = 10^4, K = 5): 294 us per pair, against 171 us for the stepwise launches -- opt-in only, see
+// launch_trsv_pair for the accounting.
+struct TpItem {
+  int16_t step, R, c, kind;  // kind 0: tile (R, c) of step; 1: x of row tile R from the partials of (backward) step
+};
+
+struct TpArgs {
+  const double* Fm;
+  const double* Um;
+  uint32_t ncached;
+  int32_t streaming;
+  int64_t n;
+  const double* y;
+  double* x;
+  double* PP;
+  double* BB;
+  int32_t* sync;  // [0] ticket, [1] done, [2] error, [3] pad, counters from [4]
+  const TpItem* items;
+  const int32_t* chunks;
+  int32_t nchunks;
+  int64_t ldp;
+  int32_t ntile, bt, nblk;
+  const Ctrl* ctrl;
+};
+
+constexpr int kTpWaves = 4;
+constexpr int kTpSpinMax = 1 << 20;
+
+__device__ __forceinline__ void tp_block(const TpArgs& a, int s, int& dt0, int& dt1, int& upper) {
+  upper = s >= a.nblk ? 1 : 0;
+  const int k = upper ? 2 * a.nblk - 1 - s : s;
+  dt0 = k * a.bt;
+  dt1 = (dt0 + a.bt < a.ntile) ? dt0 + a.bt : a.ntile;
+}
+// partials row tile T has in step p (T inside p's panel)
+__device__ __forceinline__ void tp_range(const TpArgs& a, int p, int T, int& q0, int& q1) {
+  int dt0, dt1, upper;
+  tp_block(a, p, dt0, dt1, upper);
+  q0 = 0;
+  q1 = dt1 - dt0;
+  if (T >= dt0 && T < dt1) {
+    if (!upper) q1 = T - dt0 + 1;
+    else q0 = T - dt0;
+  }
+}
+__device__ __forceinline__ double tp_ld(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: past this CU's L1
+}
+__device__ __forceinline__ void tp_st(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
+}
+// sum over the partials q0 .. q1-1 of step p at element pair e (fixed order, sixteen loads of each half in flight)
+__device__ __forceinline__ double2_t tp_sum(const TpArgs& a, int p, int q0, int q1, int64_t e) {
+  constexpr int G = 16;
+  double2_t t{0.0, 0.0};
+  const double* __restrict__ base = a.PP + static_cast<int64_t>(p) * a.bt * a.ldp + e;
+  for (int q = q0; q < q1; q += G) {
+    double v0[G], v1[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int qq = (q + k < q1) ? q + k : q1 - 1;
+      v0[k] = tp_ld(base + static_cast<int64_t>(qq) * a.ldp);
+      v1[k] = tp_ld(base + static_cast<int64_t>(qq) * a.ldp + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (q + k < q1) t += double2_t{v0[k], v1[k]};
+  }
+  return t;
+}
+// one lane waits until row tile T of step p has all its partials
+__device__ __forceinline__ void tp_wait(const TpArgs& a, int p, int T) {
+  int q0, q1;
+  tp_range(a, p, T, q0, q1);
+  const int32_t target = q1 - q0;
+  const int32_t* cnt = a.sync + 4 + p * a.ntile + T;
+  for (int spin = 0;; ++spin) {
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+    if (spin > kTpSpinMax || ((spin & 255) == 255 &&
+                              __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      __hip_atomic_store(a.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void tp_stream(const double* __restrict__ Mr, int lc0, double2_t xp, double& a0, double& a1) {
+  constexpr int WC = kTsTile / kTpWaves;  // 32 columns per wave
+  double2_t bufA[kTsPanel], bufB[kTsPanel];
+  ts_load<NT>(Mr, kTsTile, lc0, bufA);
+#pragma unroll 1
+  for (int co = 0; co < WC; co += 2 * kTsPanel) {
+    ts_load<NT>(Mr, kTsTile, lc0 + co + kTsPanel, bufB);
+    ts_fma(xp, co, bufA, a0, a1);
+    if (co + 2 * kTsPanel < WC) ts_load<NT>(Mr, kTsTile, lc0 + co + 2 * kTsPanel, bufA);
+    ts_fma(xp, co + kTsPanel, bufB, a0, a1);
+  }
+}
+
+__global__ __launch_bounds__(kTpWaves* kWave) void tri_persist_kernel(TpArgs a) {
+  if (a.ctrl && a.ctrl->stop) return;  // (the same answer in every workgroup: written by an earlier launch)
+  constexpr int WC = kTsTile / kTpWaves;
+  __shared__ double2_t red[kTpWaves][kWave];
+  __shared__ int32_t sh_t, sh_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.nblk;
+  int32_t* const ticket = a.sync;
+  if (tid == 0) sh_t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int32_t t = sh_t;
+  while (t < a.nchunks) {
+    int32_t next_t = 0;  // the next ticket is asked for now and looked at when this one is done
+    if (tid == 0) next_t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t i0 = a.chunks[t], i1 = a.chunks[t + 1];
+    for (int32_t it = i0; it < i1; ++it) {
+      const TpItem item = a.items[it];
+      const int s = item.step, R = item.R, c = item.c;
+      int dt0, dt1, upper;
+      tp_block(a, s, dt0, dt1, upper);
+      const int64_t r = static_cast<int64_t>(R) * kTsTile + 2 * lane;  // this lane's row pair
+      if (item.kind == 1) {  // x of row tile R: the sum of its partials in (backward) step s
+        if (tid == 0) tp_wait(a, s, R);
+        __syncthreads();
+        if (wave == 0) {
+          int q0, q1;
+          tp_range(a, s, R, q0, q1);
+          double2_t v = tp_sum(a, s, q0, q1, r);
+          if (__hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            v = double2_t{__builtin_nan(""), __builtin_nan("")};  // a poll gave up: make the failure loud
+          ts_store_vec(a.x, r, a.n, v);
+        }
+        continue;
+      }
+      const bool diag = R >= dt0 && R < dt1;
+      const int T = dt0 + c;                       // the input block of this tile: row tile T of the previous step
+      const bool fold_base = c == 0 && !diag;      // this tile also carries the running right-hand side of row tile R
+      const int pin = (s == 0) ? -1 : s - 1;       // step whose partials feed the input (s == K: the last forward step)
+      const int pbase = (s == 0) ? -1 : (s == K ? R / a.bt : s - 1);  // ... and the base of row tile R
+      if (tid == 0) {
+        if (pin >= 0) tp_wait(a, pin, T);
+        if (fold_base && pbase >= 0) tp_wait(a, pbase, R);
+      }
+      __syncthreads();
+      // the input pair of this wave's columns: lane l < 16 holds columns (2l, 2l + 1) of the wave's 32
+      const int64_t cw0 = static_cast<int64_t>(T) * kTsTile + wave * WC;
+      double2_t xp{0.0, 0.0};
+      {
+        const int64_t e = cw0 + 2 * (lane < WC / 2 ? lane : 0);
+        if (s == 0) {
+          xp = ts_load_vec(a.y, e, a.n);
+        } else {
+          int q0, q1;
+          tp_range(a, pin, T, q0, q1);
+          xp = tp_sum(a, pin, q0, q1, e);
+          if (s != K) {
+            const double* __restrict__ b = a.BB + static_cast<int64_t>(pin) * a.ldp + e;
+            xp += double2_t{tp_ld(b), tp_ld(b + 1)};
+          }
+        }
+      }
+      if (fold_base && wave == 0) {  // B[s][R] = what the rows of R carry into the later steps
+        double2_t bv;
+        if (s == 0) {
+          bv = ts_load_vec(a.y, r, a.n);
+        } else {
+          int q0, q1;
+          tp_range(a, pbase, R, q0, q1);
+          bv = tp_sum(a, pbase, q0, q1, r);
+          if (s != K) {
+            const double* __restrict__ b = a.BB + static_cast<int64_t>(pbase) * a.ldp + r;
+            bv += double2_t{tp_ld(b), tp_ld(b + 1)};
+          }
+        }
+        double* __restrict__ bo = a.BB + static_cast<int64_t>(s) * a.ldp + r;
+        tp_st(bo, bv.x);
+        tp_st(bo + 1, bv.y);
+      }
+      const uint32_t Ct = static_cast<uint32_t>(T), Rt = static_cast<uint32_t>(R);
+      const uint32_t lin = upper ? Ct * (Ct + 1u) / 2u + Rt : Rt * (Rt + 1u) / 2u + Ct;
+      const double* __restrict__ Mr = (upper ? a.Um : a.Fm) + static_cast<int64_t>(lin) * (kTsTile * kTsTile) + 2 * lane;
+      double a0 = 0.0, a1 = 0.0;
+      if (a.streaming && lin >= a.ncached) tp_stream<true>(Mr, wave * WC, xp, a0, a1);
+      else tp_stream<false>(Mr, wave * WC, xp, a0, a1);
+      red[wave][lane] = double2_t{a0, a1};
+      __syncthreads();
+      if (wave == 0) {
+        double2_t acc = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < kTpWaves; ++w) acc += red[w][lane];
+        double* __restrict__ po = a.PP + (static_cast<int64_t>(s) * a.bt + c) * a.ldp + r;
+        tp_st(po, acc.x);
+        tp_st(po + 1, acc.y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial row (and the base) have left this wave ...
+        if (lane == 0)                                    // ... before the row tile's counter says so
+          __hip_atomic_fetch_add(a.sync + 4 + s * a.ntile + R, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) sh_t = next_t;
+    __syncthreads();
+    t = sh_t;
+  }
+  // the last workgroup out resets the list for the next launch (everybody else has stopped reading the counters)
+  if (tid == 0) {
+    const int32_t old = __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = (old == static_cast<int32_t>(gridDim.x) - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (sh_last) {
+    const int32_t ncnt = 2 * K * a.ntile;
+    for (int32_t i = tid; i < ncnt; i += kTpWaves * kWave) a.sync[4 + i] = 0;
+    if (tid == 0) {
+      a.sync[0] = 0;
+      a.sync[1] = 0;
+    }
+  }
+}
+
 // Um(j, i) = X(i, j) for the nb x nb lower-triangular block X (transposed copy of a diagonal block)
 __global__ __launch_bounds__(kBlock) void ts_transpose_block_kernel(const double* __restrict__ X, int64_t ldx,
                                                                     double* __restrict__ U, int64_t ldu, int64_t nb) {
@@ -259,12 +499,98 @@ static int ts_block_tiles() {
   return kTsBlockTiles;
 }
 
+// geometry shared by trsv_plan_elems and trsv_build
+struct TsGeom {
+  int64_t npad, ntile, bt, nblk;
+  int64_t nitems;      // tiles of both sweeps + one x item per row tile
+  size_t base_elems;   // Fm + Um (tile-packed triangles) + two partial buffers + v + w
+  size_t pp_elems, bb_elems, sync_elems, item_elems, chunk_elems;  // one-launch form, in doubles
+};
+static TsGeom ts_geom(int64_t n) {
+  TsGeom g{};
+  g.npad = round_up(n, kTsTile);
+  g.ntile = g.npad / kTsTile;
+  g.bt = std::min<int64_t>(ts_block_tiles(), g.ntile);
+  g.nblk = ceil_div(g.ntile, g.bt);
+  g.bt = ceil_div(g.ntile, g.nblk);  // balanced blocks (as trsv_build)
+  g.base_elems = static_cast<size_t>(g.ntile * (g.ntile + 1) * kTsTile * kTsTile + 2 * g.bt * g.npad + 2 * g.npad);
+  g.nitems = g.ntile * (g.ntile + 1) + g.ntile;
+  g.pp_elems = static_cast<size_t>(2 * g.nblk * g.bt * g.npad);
+  g.bb_elems = static_cast<size_t>(2 * g.nblk * g.npad);
+  g.sync_elems = static_cast<size_t>((4 + 2 * g.nblk * g.ntile + 1) / 2 + 1);
+  g.item_elems = static_cast<size_t>(g.nitems + 1);            // 8-byte items
+  g.chunk_elems = static_cast<size_t>((g.nitems + 2) / 2 + 64);  // 4-byte indices (at most one ticket per item + one per run)
+  return g;
+}
+
 size_t trsv_plan_elems(int64_t n) {
-  const int64_t npad = round_up(n, kTsTile);
-  const int64_t ntile = npad / kTsTile;
-  const int64_t bt = std::min<int64_t>(ts_block_tiles(), ntile);
-  // Fm + Um (tile-packed triangles) + two partial buffers + v + w
-  return static_cast<size_t>(ntile * (ntile + 1) * kTsTile * kTsTile + 2 * bt * npad + 2 * npad);
+  const TsGeom g = ts_geom(n);
+  return g.base_elems + g.pp_elems + g.bb_elems + g.sync_elems + g.item_elems + g.chunk_elems;
+}
+
+// the ordered work list of the one-launch form (tri_persist_kernel has the ordering rule)
+static void ts_work_list(const TsGeom& g, std::vector<TpItem>* items, std::vector<int32_t>* chunks) {
+  const int K = static_cast<int>(g.nblk), bt = static_cast<int>(g.bt), ntile = static_cast<int>(g.ntile);
+  auto blk = [&](int k, int& t0, int& t1) {
+    t0 = k * bt;
+    t1 = std::min(ntile, t0 + bt);
+  };
+  auto put = [&](int s, int R, int c, int kind) {
+    items->push_back(TpItem{static_cast<int16_t>(s), static_cast<int16_t>(R), static_cast<int16_t>(c),
+                            static_cast<int16_t>(kind)});
+  };
+  // A ticket (one agent-scope atomic on ONE address: ~45 ns each, serialised -- 6400 single-tile tickets cost more than
+  // the whole solve) hands out a run of consecutive items: short runs where the next step waits for the result (the
+  // chain must spread over many workgroups), long ones in the rest of a panel.  ADMM_TRSV_CHUNK="crit,rest".
+  int chunk_crit = 2, chunk_rest = 8;
+  if (const char* ev = std::getenv("ADMM_TRSV_CHUNK")) {
+    int a1 = 0, a2 = 0;
+    if (std::sscanf(ev, "%d,%d", &a1, &a2) == 2 && a1 >= 1 && a2 >= 1 && a1 <= 64 && a2 <= 64) {
+      chunk_crit = a1;
+      chunk_rest = a2;
+    }
+  }
+  chunks->clear();
+  auto close_runs = [&](size_t from, int len) {  // tickets over items [from, items->size())
+    for (size_t i = from; i < items->size(); i += static_cast<size_t>(len)) chunks->push_back(static_cast<int32_t>(i));
+  };
+  std::vector<std::pair<int, int>> pending_x;  // (step, row tile): x items, emitted behind the next step's first tiles
+  for (int s = 0; s < 2 * K; ++s) {
+    size_t mark = items->size();
+    const bool upper = s >= K;
+    const int k = upper ? 2 * K - 1 - s : s;
+    int dt0, dt1;
+    blk(k, dt0, dt1);
+    const int ncols = dt1 - dt0;
+    int n0 = 0, n1 = 0;  // the row tiles the next step's inputs come from
+    if (!upper && k + 1 < K) blk(k + 1, n0, n1);
+    if (upper && k > 0) blk(k - 1, n0, n1);
+    for (int c = 0; c < ncols; ++c)
+      for (int R = n0; R < n1; ++R) put(s, R, c, 0);
+    close_runs(mark, chunk_crit);
+    mark = items->size();
+    for (const auto& px : pending_x) put(px.first, px.second, 0, 1);
+    pending_x.clear();
+    close_runs(mark, 4);
+    mark = items->size();
+    for (int c = 0; c < ncols; ++c)  // the diagonal block: the tiles that exist
+      for (int R = dt0; R < dt1; ++R)
+        if (upper ? c >= R - dt0 : c <= R - dt0) put(s, R, c, 0);
+    // (the last forward step's diagonal block IS what the first backward step waits for)
+    close_runs(mark, (!upper && k + 1 == K) || (upper && k == 0) ? chunk_crit : chunk_rest);
+    mark = items->size();
+    const int r0 = upper ? 0 : dt1, r1 = upper ? dt0 : ntile;  // the rest of the panel
+    for (int c = 0; c < ncols; ++c)
+      for (int R = r0; R < r1; ++R)
+        if (R < n0 || R >= n1) put(s, R, c, 0);
+    close_runs(mark, chunk_rest);
+    if (upper)
+      for (int R = dt0; R < dt1; ++R) pending_x.emplace_back(s, R);
+  }
+  const size_t mark = items->size();
+  for (const auto& px : pending_x) put(px.first, px.second, 0, 1);
+  close_runs(mark, 4);
+  chunks->push_back(static_cast<int32_t>(items->size()));
 }
 
 // L: n x n lower factor (upper part ignored); dinv64: its inverted 64x64 diagonal blocks.
@@ -322,6 +648,52 @@ int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, do
   ADMM_HIP_TRY(se);
   p.Fm = packedF;
   p.Um = packedU;
+  // ---- the one-launch form: buffers behind the stepwise ones, the work list uploaded once
+  const TsGeom g = ts_geom(n);
+  p.persist = false;
+  if (g.nblk == p.nblk && g.bt == p.bt && p.ntile < 32000) {
+    double* q = buf + g.base_elems;
+    p.PP = q;
+    q += g.pp_elems;
+    p.BB = q;
+    q += g.bb_elems;
+    p.sync = reinterpret_cast<int32_t*>(q);
+    q += g.sync_elems;
+    TpItem* ditems = reinterpret_cast<TpItem*>(q);
+    q += g.item_elems;
+    int32_t* dchunks = reinterpret_cast<int32_t*>(q);
+    std::vector<TpItem> items;
+    std::vector<int32_t> chunks;
+    items.reserve(static_cast<size_t>(g.nitems));
+    ts_work_list(g, &items, &chunks);
+    if (static_cast<int64_t>(items.size()) == g.nitems) {
+      ADMM_HIP_TRY(hipMemcpyAsync(ditems, items.data(), items.size() * sizeof(TpItem), hipMemcpyHostToDevice, stream));
+      ADMM_HIP_TRY(hipMemcpyAsync(dchunks, chunks.data(), chunks.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      ADMM_HIP_TRY(hipStreamSynchronize(stream));  // (the host vectors go out of scope)
+      p.items = ditems;
+      p.chunks = dchunks;
+      p.nitems = static_cast<int32_t>(items.size());
+      p.nchunks = static_cast<int32_t>(chunks.size()) - 1;
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      p.grid = std::min<int32_t>(p.nchunks, 4 * cus);  // any size is safe (tickets); more than the device holds gains nothing
+      p.persist = p.nblk >= 2;  // one block: the stepwise form is two launches already
+    }
+  }
+  return ADMM_OK;
+}
+
+// 0 = fine; the one-launch form raises the word when a poll gives up (its x is NaN then)
+int trsv_check_error(const TrsvPlan& p, hipStream_t stream) {
+  if (!p.persist || !p.sync) return ADMM_OK;
+  int32_t err = 0;
+  ADMM_HIP_TRY(hipMemcpyAsync(&err, p.sync + 2, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  ADMM_HIP_TRY(hipStreamSynchronize(stream));
+  if (err != 0) {
+    ADMM_HIP_TRY(hipMemsetAsync(p.sync, 0, sizeof(int32_t) * (4 + 2 * static_cast<size_t>(p.nblk) * p.ntile), stream));
+    return fail(ADMM_E_DEVICE, "triangular solves (one-launch form): a workgroup waited ~2 s for a tile that never "
+                               "completed; the solve was abandoned");
+  }
   return ADMM_OK;
 }
 
@@ -348,6 +720,35 @@ static void ts_step(const TriStepArgs& a, bool nt, hipStream_t stream) {
 
 // y, x: n elements (not padded); x may alias y.
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream) {
+  // The one-launch form is correct (tests/test_gpu_ops.py::test_trsv_pair runs both) but NOT the default: at n = 10^4 it
+  // measured 294 us per pair against 171 us for the 2K + 1 launches below (profiles/r3_trsv_persist.txt).  A tile costs a
+  // resident workgroup ~10 dependent memory round trips (ticket, item, two counter polls, the fold of up to 16 partial
+  // rows + base, two rounds of panel loads, the write-through drain in front of the counter) at 4 workgroups per CU,
+  // where the stepwise launches resolve dependencies at kernel boundaries and hide the same folds behind 16-32 resident
+  // one-wave workgroups per CU.  ADMM_TRSV_ONE_LAUNCH=1 selects it.
+  if (p.persist && std::getenv("ADMM_TRSV_ONE_LAUNCH") != nullptr) {
+    TpArgs t{};
+    t.Fm = p.Fm;
+    t.Um = p.Um;
+    t.ncached = static_cast<uint32_t>(p.ncached > 0xffffffffLL ? 0xffffffffLL : p.ncached);
+    t.streaming = p.streaming ? 1 : 0;
+    t.n = p.n;
+    t.y = y;
+    t.x = x;
+    t.PP = p.PP;
+    t.BB = p.BB;
+    t.sync = p.sync;
+    t.items = static_cast<const TpItem*>(p.items);
+    t.chunks = p.chunks;
+    t.nchunks = p.nchunks;
+    t.ldp = p.ldp;
+    t.ntile = p.ntile;
+    t.bt = p.bt;
+    t.nblk = p.nblk;
+    t.ctrl = ctrl;
+    hipLaunchKernelGGL(tri_persist_kernel, dim3(static_cast<unsigned>(p.grid)), dim3(kTpWaves * kWave), 0, stream, t);
+    return;
+  }
   TriStepArgs a{};
   a.ncached = static_cast<uint32_t>(p.ncached > 0xffffffffLL ? 0xffffffffLL : p.ncached);
   a.ldp = p.ldp;

@@ -77,9 +77,11 @@ def test_cholesky_rejects_indefinite(gpu):
     assert b"positive definite" in gpu._lib.load().admm_last_error()
 
 
-@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 128, 129, 130, 400, 1000, 1280, 1281, 1409, 2560, 2700, 3333])
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 128, 129, 130, 400, 1000, 1280, 1281, 1409, 2049, 2560, 2700, 3333, 4100,
+                               6500, 10000])
 def test_trsv_pair(gpu, n):
-    """blocked substitution: one coarse block up to n = 1280, several beyond (ragged last block included);
+    """blocked substitution: one coarse block up to n = 2048, several beyond (ragged last block included; from two blocks
+    on the pair runs as ONE launch, trsv.hip: tri_persist_kernel -- 5 blocks at n = 10000);
     the strictly-upper part of the factor buffer holds garbage, as after an in-place Cholesky of a full matrix"""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n + 20, n)) / np.sqrt(n + 20)
