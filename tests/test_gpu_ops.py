@@ -114,3 +114,21 @@ def test_bad_arguments_are_errors_not_crashes(gpu):
     assert lib.admm_engine_create(C.byref(d), C.byref(h)) == gpu._lib.E_INVALID
     d.struct_size = 8
     assert lib.admm_engine_create(C.byref(d), C.byref(h)) == gpu._lib.E_INVALID
+
+
+@pytest.mark.parametrize("n", [2049, 2700, 4100, 10000])
+def test_trsv_pair_one_launch_form(gpu, n, monkeypatch):
+    """the same pair as ONE persistent launch (trsv.hip: tri_persist_kernel; opt-in, slower than the stepwise launches):
+    tickets, write-through hand-offs between workgroups, row-tile counters -- same sums in the same order"""
+    monkeypatch.setenv("ADMM_TRSV_ONE_LAUNCH", "1")
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n + 20, n)) / np.sqrt(n + 20)
+    Lf = np.asfortranarray(sla.cholesky(G.T @ G + np.eye(n), lower=True))
+    y = rng.standard_normal(n)
+    x1, x2 = np.zeros(n), np.zeros(n)
+    gpu._lib.check(gpu._lib.load().admm_op_trsv_pair(_dp(gpu, Lf), n, n, _dp(gpu, y), _dp(gpu, x1)))
+    monkeypatch.delenv("ADMM_TRSV_ONE_LAUNCH")
+    gpu._lib.check(gpu._lib.load().admm_op_trsv_pair(_dp(gpu, Lf), n, n, _dp(gpu, y), _dp(gpu, x2)))
+    ref = sla.solve_triangular(Lf.T, sla.solve_triangular(Lf, y, lower=True), lower=False)
+    assert _rel(x1, ref) < 1e-11 and _rel(x2, ref) < 1e-11
+    assert np.array_equal(x1, x2)  # same tiles, same fixed-order sums
