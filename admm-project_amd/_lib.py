@@ -33,7 +33,7 @@ FAST_OFF, FAST_STRONG, FAST_WEAK = 0, 1, 2
 
 K_XSOLVE, K_GEMV_N, K_GEMV_T, K_PROX, K_FINALIZE, K_COUNT = 0, 1, 2, 3, 4, 5
 COMM_ID_BYTES = 128
-COMM_RCCL, COMM_SHM = 0, 1
+COMM_RCCL, COMM_SHM, COMM_P2P = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 

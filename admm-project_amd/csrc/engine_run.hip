@@ -603,7 +603,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     ADMM_TRY(trsv_check_error(e->xfac.trsv, e->stream));
     ADMM_TRY(trsv_check_error(e->zfac.trsv, e->stream));
     for (const ConsSlice& sl : e->cslices) ADMM_TRY(trsv_check_error(sl.fac.trsv, e->stream));
-    return ADMM_OK;
+    return comm_check_error(e->comm, e->stream);
   };
   if (e->problem == ADMM_PROB_LASSO_CONSENSUS) return trsv_ok(run_consensus_lasso(e, rs, summary));
   if (e->problem == ADMM_PROB_TV2D) return run_total_variation_2d(e, rs, summary);

@@ -37,7 +37,7 @@ class Comm:
     def __init__(self, uid, rank, nranks, device=0, transport="rccl"):
         if len(uid) != L.COMM_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")
-        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM}[transport]
+        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM, "p2p": L.COMM_P2P}[transport]
         h = C.c_void_p()
         L.check(L.load().admm_comm_init(uid, int(rank), int(nranks), int(device), tr, C.byref(h)))
         self.handle = h
@@ -72,7 +72,7 @@ class LocalGroup:
         devices = list(devices) if devices is not None else [0] * int(nranks)
         if len(devices) != int(nranks):
             raise ValueError("one device per rank")
-        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM}[transport]
+        tr = {"rccl": L.COMM_RCCL, "shm": L.COMM_SHM, "p2p": L.COMM_P2P}[transport]
         dev = (C.c_int * int(nranks))(*devices)
         hs = (C.c_void_p * int(nranks))()
         L.check(L.load().admm_comm_init_all(int(nranks), dev, tr, hs))

@@ -36,7 +36,9 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=100000)
     ap.add_argument("--cols", type=int, default=10000)
     ap.add_argument("--xsolve", default="inverse", choices=["trsv", "inverse"])
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm"])
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "shm", "p2p"],
+                    help="rccl: ncclAllReduce on the engine's stream; p2p: the engine's one-shot peer-to-peer all-reduce "
+                         "(one kernel per rank, for the loop's 80-240 KB payloads); shm: host-staged (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the objevals=1 and A-streaming side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -480,8 +482,8 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out,
 def main():
     a = parse()
     rank, world, local, dist = dist_setup(a.one_gpu)
-    if a.one_gpu:
-        a.transport = "shm"
+    if a.one_gpu and a.transport == "rccl":
+        a.transport = "shm"  # (RCCL refuses two ranks on one device; p2p is fine with it)
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
@@ -519,7 +521,8 @@ def main():
         import ctypes as _C
         _r, _n, _t = _C.c_int(), _C.c_int(), _C.c_int()
         L.check(L.load().admm_comm_info(comm.handle, _C.byref(_r), _C.byref(_n), _C.byref(_t)))
-        comm_report = {"ranks": _n.value, "rank0_sees": _r.value, "transport": {L.COMM_RCCL: "rccl", L.COMM_SHM: "shm"}[_t.value]}
+        comm_report = {"ranks": _n.value, "rank0_sees": _r.value,
+                       "transport": {L.COMM_RCCL: "rccl", L.COMM_SHM: "shm", L.COMM_P2P: "p2p"}[_t.value]}
 
     t0 = time.perf_counter()
     p = make_problem(ap, dist, m, n, lo, hi)

@@ -367,7 +367,14 @@ int admm_op_soft_threshold(const double* v, int64_t n, double t, double* out);
 /* transports: RCCL over xGMI (collectives enqueued on the engine's stream), or a host-staged
  * all-reduce through POSIX shared memory (any number of ranks may then share one GPU; used for
  * single-GPU testing of the sharded engines and as a fallback) */
-enum { ADMM_COMM_RCCL = 0, ADMM_COMM_SHM = 1 };
+enum { ADMM_COMM_RCCL = 0, ADMM_COMM_SHM = 1,
+       /* one-shot peer-to-peer all-reduce for the loop's small payloads (80-240 KB: latency, not bandwidth): every rank
+        * stores its contribution straight into a slot of every peer's device buffer (xGMI is a full point-to-point
+        * mesh: one hop, where a ring makes 2(N-1)), raises a flag there, waits for the N flags in its own buffer and
+        * sums the N slots in rank order -- ONE kernel per rank, on the engine's stream, no host synchronisation, bitwise
+        * the same result on every rank.  Ranks of one node (processes or threads): buffers are shared through HIP IPC
+        * handles exchanged over the shared-memory rendezvous.  Never run on real links in this repository's records. */
+       ADMM_COMM_P2P = 2 };
 int admm_comm_unique_id(char id[ADMM_COMM_ID_BYTES]);
 int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int device, int transport,
                    admm_comm** out);

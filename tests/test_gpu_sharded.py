@@ -23,7 +23,7 @@ def _rank_main(rank, world, uid, case, q):
     from admm_project_amd import parallel
 
     try:
-        comm = parallel.Comm(uid, rank, world, device=0, transport="shm")
+        comm = parallel.Comm(uid, rank, world, device=0, transport=os.environ.get("ADMM_TEST_TRANSPORT", "shm"))
         out = {}
         tot = comm.allreduce_sum(np.array([1.0 + rank, 10.0]))
         out["allreduce"] = tot
@@ -73,6 +73,15 @@ def _rank_main(rank, world, uid, case, q):
         import traceback
 
         q.put((rank, {"error": f"{exc}\n{traceback.format_exc()}"}))
+
+
+@pytest.fixture(autouse=True, params=["shm", "p2p"])
+def transport(request, monkeypatch):
+    """every two-process case over the host-staged transport AND over the engine's one-shot peer-to-peer all-reduce
+    (ADMM_COMM_P2P: the two processes map each other's device buffers through HIP IPC handles; one kernel per rank
+    and collective on the engine's stream, no host synchronisation -- the stream-ordered path)"""
+    monkeypatch.setenv("ADMM_TEST_TRANSPORT", request.param)
+    return request.param
 
 
 def _run_two_ranks(case):

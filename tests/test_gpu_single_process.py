@@ -154,3 +154,39 @@ def test_a_rank_failing_outside_a_collective_releases_its_peers(gpu):
             assert _rel(res["xvals"], ref["xvals"]) < 1e-9
     finally:
         g2.close()
+
+
+@pytest.mark.parametrize("nranks", [2])
+def test_one_process_ranks_over_the_one_shot_p2p_all_reduce(gpu, nranks):
+    """ADMM_COMM_P2P between ranks that are threads of ONE process (the MEX-gateway deployment): the peers' buffers are
+    plain device pointers here, the kernels of the ranks run on their engines' streams at the same time, nothing
+    synchronises with the host inside an iteration.  (On this box all ranks share device 0, and a rank's kernel waits
+    for the kernels of the others: each needs a hardware queue of its own.  The runtime multiplexes a process's streams
+    onto 4 queues: two ranks rehearse reliably, four already share queues -- measured: the polling limit trips and the
+    call returns ADMM_E_COMM, it does not hang.  One GPU per rank has no such limit.)"""
+    from admm_project_amd import parallel
+    m, n = 1003, 40
+    p = gpu.synth.lad_problem(0, m, n)
+    ref = S.lad(p["D"], p["s"], dict(objevals=1))
+    g = parallel.LocalGroup(nranks, devices=[0] * nranks, transport="p2p")
+    try:
+        tot = g.on_ranks(lambda r, comm: comm.allreduce_sum(np.array([1.0 + r, 10.0, -2.0 * r])))
+        for t in tot:
+            np.testing.assert_array_equal(t, [sum(1.0 + r for r in range(nranks)), 10.0 * nranks,
+                                              -2.0 * sum(range(nranks))])
+
+        def rank(r, comm):
+            lo, hi = parallel.my_rows(m, comm)
+            return lo, hi, gpu.lad(p["D"][lo:hi], p["s"][lo:hi], dict(objevals=1, comm=comm))
+
+        outs = g.on_ranks(rank)
+        for lo, hi, res in outs:
+            assert res["steps"] == ref["steps"]
+            for k in ("xvals", "pnorm", "dnorm", "perr", "derr", "objevals"):
+                assert _rel(res[k], ref[k]) < 1e-9, k
+            assert _rel(res["zopt"], ref["zopt"][lo:hi]) < 1e-9
+        # every rank holds bitwise the same replicated x (rank-ordered sums)
+        for _, _, res in outs[1:]:
+            assert np.array_equal(res["xvals"], outs[0][2]["xvals"])
+    finally:
+        g.close()
