@@ -138,6 +138,7 @@ _SIGNATURES = {
     "admm_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "admm_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "admm_comm_allreduce_sum": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
+    "admm_comm_measure_latency": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "admm_comm_destroy": (None, [C.c_void_p]),
     "admm_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "admm_engine_create_all": (C.c_int, [C.c_int, C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]),

@@ -537,6 +537,30 @@ int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count) {
   return rc;
 }
 
+int admm_comm_measure_latency(admm_comm* comm, size_t count, int reps, double* microseconds) {
+  if (!comm || !microseconds || reps < 1 || count == 0) return fail(ADMM_E_INVALID, "measure_latency: bad argument");
+  ADMM_HIP_TRY(hipSetDevice(comm->device));
+  double* d = nullptr;
+  ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * count));
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipFree(d);
+    return fail(ADMM_E_DEVICE, "hipStreamCreate");
+  }
+  int rc = ADMM_OK;
+  if (hipMemsetAsync(d, 0, sizeof(double) * count, st) != hipSuccess) rc = fail(ADMM_E_DEVICE, "hipMemsetAsync");
+  for (int k = 0; k < 3 && rc == ADMM_OK; ++k) rc = comm_allreduce_device(comm, d, count, st);
+  if (rc == ADMM_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ADMM_E_DEVICE, "hipStreamSynchronize");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < reps && rc == ADMM_OK; ++k) rc = comm_allreduce_device(comm, d, count, st);
+  if (rc == ADMM_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ADMM_E_DEVICE, "hipStreamSynchronize");
+  *microseconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6 / reps;
+  if (rc == ADMM_OK) rc = comm_check_error(comm, st);
+  (void)hipStreamDestroy(st);
+  (void)hipFree(d);
+  return rc;
+}
+
 void admm_comm_destroy(admm_comm* comm) {
   if (!comm) return;
   if (comm->comm) (void)rccl().CommDestroy(comm->comm);

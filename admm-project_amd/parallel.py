@@ -49,6 +49,12 @@ class Comm:
         L.check(L.load().admm_comm_allreduce_sum(self.handle, L.as_dp(a), a.size))
         return a
 
+    def allreduce_latency_us(self, count, reps=50):
+        """average microseconds of one all-reduce of ``count`` doubles, enqueued back to back (collective call)"""
+        us = C.c_double(0.0)
+        L.check(L.load().admm_comm_measure_latency(self.handle, int(count), int(reps), C.byref(us)))
+        return us.value
+
     def close(self):
         if getattr(self, "handle", None):
             L.load().admm_comm_destroy(self.handle)

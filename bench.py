@@ -523,6 +523,9 @@ def main():
         L.check(L.load().admm_comm_info(comm.handle, _C.byref(_r), _C.byref(_n), _C.byref(_t)))
         comm_report = {"ranks": _n.value, "rank0_sees": _r.value,
                        "transport": {L.COMM_RCCL: "rccl", L.COMM_SHM: "shm", L.COMM_P2P: "p2p"}[_t.value]}
+        # what one per-iteration exchange costs on the links this group really has (the payloads of the legs below)
+        comm_report["allreduce_us"] = {f"{cnt}_doubles": max_over_ranks(dist, comm.allreduce_latency_us(cnt, 50))
+                                       for cnt in (1, n, 2 * n + 1, 3 * n + 16)}
 
     t0 = time.perf_counter()
     p = make_problem(ap, dist, m, n, lo, hi)

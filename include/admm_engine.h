@@ -380,6 +380,10 @@ int admm_comm_init(const char id[ADMM_COMM_ID_BYTES], int rank, int nranks, int 
                    admm_comm** out);
 int admm_comm_info(admm_comm* comm, int* rank, int* nranks, int* transport);
 int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count); /* host convenience/test */
+/* average wall time (microseconds) of one in-place sum all-reduce of `count` doubles on this communicator: `reps` of
+ * them enqueued back to back on a stream of their own after 3 warm-up rounds (collective: every rank calls it with the
+ * same arguments).  What the engine's per-iteration exchange costs on the links this process group really has. */
+int admm_comm_measure_latency(admm_comm* comm, size_t count, int reps, double* microseconds);
 void admm_comm_destroy(admm_comm* comm);
 
 /* One host process driving several GPUs (a MATLAB session with a MEX gateway; the reference opens its pool from one

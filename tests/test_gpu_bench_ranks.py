@@ -23,19 +23,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_two_ranks_one_gpu_json_shape(gpu):
+@pytest.mark.parametrize("transport", ["shm", "p2p"])
+def test_bench_two_ranks_one_gpu_json_shape(gpu, transport):
     rows, cols = 4100, 512  # 4100 = 8*512 + 4: slicemaker(0, 8, .) gives four slices of 513 and four of 512
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", OPENBLAS_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--one-gpu", "--steps", "5",
-           "--warmup", "2", "--no-cpu-baseline", "--rows", str(rows), "--cols", str(cols)]
+           "--warmup", "2", "--no-cpu-baseline", "--rows", str(rows), "--cols", str(cols), "--transport", transport]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
-    assert out["config"]["communicator"]["ranks"] == 2 and out["config"]["communicator"]["transport"] == "shm"
+    assert out["config"]["communicator"]["ranks"] == 2 and out["config"]["communicator"]["transport"] == transport
     assert out["config"]["rows"] == rows and out["config"]["cols"] == cols
     assert "extras_error" not in out, out.get("extras_error")
     cons = out["consensus_lasso"]
