@@ -471,6 +471,24 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out,
     _leg("consensus_lasso (config 4: 8 slices in total at every N)")
     rank = comm.rank if comm is not None else 0
     out["consensus_lasso"] = consensus_leg(ap, L, a, dist, p, rho, local, comm, rank, world, m_global, xs)
+    if world > 1 and comm is not None and comm.transport == "rccl" and not a.one_gpu:
+        # the same leg over the engine's own one-shot peer-to-peer all-reduce (comm.hip: ADMM_COMM_P2P), with what the
+        # payloads of the legs cost on it -- next to RCCL's numbers in config.communicator.allreduce_us.  Contained: this
+        # transport has never run on real links in this repository's records; its polling is bounded (error, no hang)
+        _leg("consensus_lasso over the one-shot P2P all-reduce")
+        try:
+            from admm_project_amd import parallel as _par
+            c2 = _par.init_from_torch(dist, device=local, transport="p2p")
+            try:
+                lat = {f"{cnt}_doubles": max_over_ranks(dist, c2.allreduce_latency_us(cnt, 50))
+                       for cnt in (1, n, 2 * n + 1, 3 * n + 16)}
+                leg = consensus_leg(ap, L, a, dist, p, rho, local, c2, rank, world, m_global, xs)
+                leg["allreduce_us"] = lat
+                out["consensus_lasso_p2p"] = leg
+            finally:
+                c2.close()
+        except Exception as exc:
+            out["consensus_lasso_p2p"] = {"error": repr(exc)}
     if world == 1:
         _leg("other_configs (tv, tv2d, svm)")
         out["other_configs"] = other_configs(ap, L, local, a.steps)
