@@ -471,11 +471,24 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out,
     _leg("consensus_lasso (config 4: 8 slices in total at every N)")
     rank = comm.rank if comm is not None else 0
     out["consensus_lasso"] = consensus_leg(ap, L, a, dist, p, rho, local, comm, rank, world, m_global, xs)
-    if world > 1 and comm is not None and comm.transport == "rccl" and not a.one_gpu:
+    if world > 1 and comm is not None and ((comm.transport == "rccl" and not a.one_gpu) or
+                                           os.environ.get("ADMM_BENCH_P2P_LEG")):  # (the env: rehearsal of this leg)
         # the same leg over the engine's own one-shot peer-to-peer all-reduce (comm.hip: ADMM_COMM_P2P), with what the
         # payloads of the legs cost on it -- next to RCCL's numbers in config.communicator.allreduce_us.  Contained: this
         # transport has never run on real links in this repository's records; its polling is bounded (error, no hang)
         _leg("consensus_lasso over the one-shot P2P all-reduce")
+        import threading
+
+        def _give_up():  # this leg is the LAST thing an N > 1 run measures: the line so far is the result
+            out["consensus_lasso_p2p"] = {"error": "the P2P leg did not finish within 90 s: abandoned"}
+            out.pop("_pmc_pair", None)
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(90.0, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             from admm_project_amd import parallel as _par
             c2 = _par.init_from_torch(dist, device=local, transport="p2p")
@@ -489,6 +502,8 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out,
                 c2.close()
         except Exception as exc:
             out["consensus_lasso_p2p"] = {"error": repr(exc)}
+        finally:
+            watchdog.cancel()
     if world == 1:
         _leg("other_configs (tv, tv2d, svm)")
         out["other_configs"] = other_configs(ap, L, local, a.steps)

@@ -27,6 +27,8 @@ def _free_port():
 def test_bench_two_ranks_one_gpu_json_shape(gpu, transport):
     rows, cols = 4100, 512  # 4100 = 8*512 + 4: slicemaker(0, 8, .) gives four slices of 513 and four of 512
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", OPENBLAS_NUM_THREADS="4")
+    if transport == "shm":
+        env["ADMM_BENCH_P2P_LEG"] = "1"  # the extra leg an RCCL run adds: the consensus problem once more over P2P
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--one-gpu", "--steps", "5",
            "--warmup", "2", "--no-cpu-baseline", "--rows", str(rows), "--cols", str(cols), "--transport", transport]
@@ -48,3 +50,9 @@ def test_bench_two_ranks_one_gpu_json_shape(gpu, transport):
     for leg in ("a_streaming", "objevals1_literal", "matrix_free"):
         assert out[leg]["iters_per_s"] > 0
     assert out["value"] > 0 and out["roofline"]["frac"] is not None
+    lat = out["config"]["communicator"]["allreduce_us"]
+    assert set(lat) == {"1_doubles", f"{cols}_doubles", f"{2 * cols + 1}_doubles", f"{3 * cols + 16}_doubles"}
+    if transport == "shm":
+        extra = out["consensus_lasso_p2p"]
+        assert "error" not in extra, extra
+        assert extra["slices_total"] == 8 and extra["allreduce_us"][f"{cols}_doubles"] < lat[f"{cols}_doubles"]
