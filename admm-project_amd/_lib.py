@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadmm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # error codes
 OK, E_INVALID, E_UNSUPPORTED, E_DEVICE, E_NUMERIC, E_COMM, E_CAPACITY = 0, -1, -2, -3, -4, -5, -6
@@ -94,6 +94,7 @@ class EngineInfo(C.Structure):
         ("cond_estimate", C.c_double), ("probe_err_inverse", C.c_double), ("probe_err_trsv", C.c_double),
         ("probe_diff", C.c_double), ("xsolve_cacheable_bytes", C.c_int64), ("xsolve_stream_bytes", C.c_int64),
         ("obj_bound_max", C.c_double), ("obj_form_literal", C.c_int32), ("reserved0", C.c_int32),
+        ("probe_err_trsv_one", C.c_double),
     ]
 
 

@@ -25,6 +25,7 @@ struct SliceFactor {
   double diag_min = 0.0, diag_max = 0.0, cond_diag = 0.0;  // (max L_ii / min L_ii)^2 <= cond(L L')
   bool probed = false;      // both forms were built and compared on a system with a known solution
   double err_inv = 0.0, err_trsv = 0.0, probe_diff = 0.0;
+  double err_trsv_one = __builtin_nan("");  // the one-block form's error on the same system (NaN: not built)
   int32_t chol_info = 0;
   bool pinv = false;        // Minv is the pseudo-inverse of a rank-deficient D'D (linear SVM)
   int64_t rank = 0;

@@ -142,13 +142,11 @@ static void apply_inverse(admm_engine* e, const SliceFactor& f, const double* y,
   else launch_symv_small(f.Minv, f.n, f.ldM, y, out, ctrl, e->stream);
 }
 
-// Which form applies inv(L L')?  The explicit inverse is one bandwidth-bound pass but its forward error grows like
-// cond(LL')^1.5 * eps; the blocked triangular solves stay at the cond(LL') * eps of a backward-stable solve.  The
-// engine does not guess from a condition estimate: it builds both, solves  (L L') x = L (L' x0)  for a known x0 with
-// each, compares them on a second, unstructured right-hand side, and keeps the explicit inverse only while it is
-// as accurate as the triangular solves (within 2x / 4x) or below 1e-9 (three orders under the 1e-6 parity bar);
-// otherwise the blocked triangular solves run, also when `inverse` was requested explicitly.
-static int probe_and_choose(admm_engine* e, SliceFactor& f) {
+// the probe itself: two ways of applying inv(L L') on (L L') x = L (L' x0) with a known x0 (max-norm errors relative to
+// ||x0||_inf), then on a second, unstructured right-hand side where they are compared with each other
+template <class ApplyA, class ApplyB>
+static int probe_two_forms(admm_engine* e, const SliceFactor& f, ApplyA&& apply_a, ApplyB&& apply_b, double* err_a,
+                           double* err_b, double* diff_ab) {
   const int64_t n = f.n, n2 = round_up(n, 2);
   std::vector<double> x0(static_cast<size_t>(n));
   for (int64_t i = 0; i < n; ++i) x0[i] = 1.0 + 0.5 * std::sin(1.0 + 0.7 * static_cast<double>(i));
@@ -160,8 +158,8 @@ static int probe_and_choose(admm_engine* e, SliceFactor& f) {
   auto run = [&]() -> int {
     ADMM_HIP_TRY(hipMemcpyAsync(dx0, x0.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
     launch_llt_apply(f.F, n, f.ld, dx0, dt, dy, e->stream);  // y = L (L' x0)
-    apply_inverse(e, f, dy, dxi, nullptr);
-    launch_trsv_pair(f.trsv, dy, dxt, nullptr, e->stream);
+    apply_a(dy, dxi);
+    apply_b(dy, dxt);
     ADMM_HIP_TRY(hipMemcpyAsync(xi.data(), dxi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
     ADMM_HIP_TRY(hipMemcpyAsync(xt.data(), dxt, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
     ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
@@ -185,8 +183,8 @@ static int probe_and_choose(admm_engine* e, SliceFactor& f) {
     }
     auto run2 = [&]() -> int {
       ADMM_HIP_TRY(hipMemcpyAsync(dy, x0.data(), sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
-      apply_inverse(e, f, dy, dxi, nullptr);
-      launch_trsv_pair(f.trsv, dy, dxt, nullptr, e->stream);
+      apply_a(dy, dxi);
+      apply_b(dy, dxt);
       ADMM_HIP_TRY(hipMemcpyAsync(xi.data(), dxi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipMemcpyAsync(xt.data(), dxt, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
       ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
@@ -202,14 +200,66 @@ static int probe_and_choose(admm_engine* e, SliceFactor& f) {
     dmax = (d > dmax || d != d) ? d : dmax;
     xmax = a > xmax ? a : xmax;
   }
-  f.err_inv = ei / 1.5;  // relative to ||x0||_inf
-  f.err_trsv = et / 1.5;
-  f.probe_diff = xmax > 0.0 ? dmax / xmax : dmax;
+  *err_a = ei / 1.5;  // relative to ||x0||_inf
+  *err_b = et / 1.5;
+  *diff_ab = xmax > 0.0 ? dmax / xmax : dmax;
+  return ADMM_OK;
+}
+
+// Which form applies inv(L L')?  The explicit inverse is one bandwidth-bound pass but its forward error grows like
+// cond(LL')^1.5 * eps; the blocked triangular solves stay at the cond(LL') * eps of a backward-stable solve.  The
+// engine does not guess from a condition estimate: it builds both, solves  (L L') x = L (L' x0)  for a known x0 with
+// each, compares them on a second, unstructured right-hand side, and keeps the explicit inverse only while it is
+// as accurate as the triangular solves (within 2x / 4x) or below 1e-9 (three orders under the 1e-6 parity bar);
+// otherwise the triangular solves run, also when `inverse` was requested explicitly.
+static int probe_and_choose(admm_engine* e, SliceFactor& f) {
+  ADMM_TRY(probe_two_forms(
+      e, f, [&](const double* y, double* x) { apply_inverse(e, f, y, x, nullptr); },
+      [&](const double* y, double* x) { launch_trsv_pair(f.trsv, y, x, nullptr, e->stream); }, &f.err_inv, &f.err_trsv,
+      &f.probe_diff));
   f.probed = true;
   // keep the one-pass form while it is as good as the backward-stable solves (or simply good enough)
   const bool ok1 = f.err_inv <= std::max(1e-9, 2.0 * f.err_trsv);
   const bool ok2 = f.probe_diff <= std::max(1e-9, 4.0 * f.err_trsv);
   f.mode = (ok1 && ok2) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
+  return ADMM_OK;
+}
+
+// The triangular solves themselves have two forms (trsv.hip): blocked substitution over K = ceil(n / 2048) coarse blocks
+// with pre-inverted DIAGONAL blocks (2K + 1 dependent launches per pair), and the one-block form -- the whole factor
+// pre-inverted, X = inv(L), two passes and two launches per pair, same 8 n(n+1) bytes.  X costs forward error
+// eps * cond(L) per pass where a diagonal block costs eps * cond(L_kk).  Same rule as above: the blocked form (already
+// built: f.trsv) is the yardstick, and the one-block form replaces it only while it is as accurate on both probe
+// systems (within 4x / 8x) or below 1e-11 -- five orders under the parity bar.  ADMM_TRSV_FORM=one|blocked forces it.
+static int choose_trsv_form(admm_engine* e, SliceFactor& f) {
+  f.err_trsv_one = NAN;
+  const char* forced = std::getenv("ADMM_TRSV_FORM");
+  if (trsv_resolve_form(f.n, kTrsvOne) != kTrsvOne) return ADMM_OK;
+  if (f.n < kSymvHalfMin && !(forced && forced[0] == 'o')) return ADMM_OK;  // a few tiles: the steps are cheap
+  double* work1 = nullptr;
+  ADMM_TRY(e->mem.alloc(&work1, trsv_plan_elems(f.n, kTrsvOne)));
+  TrsvPlan one{};
+  int rc = trsv_build(f.F, f.n, f.ld, f.dinv, work1, &one, e->stream, kTrsvOne);
+  double e1 = NAN, eb = NAN, diff = NAN;
+  if (rc == ADMM_OK)
+    rc = probe_two_forms(
+        e, f, [&](const double* y, double* x) { launch_trsv_pair(one, y, x, nullptr, e->stream); },
+        [&](const double* y, double* x) { launch_trsv_pair(f.trsv, y, x, nullptr, e->stream); }, &e1, &eb, &diff);
+  if (rc != ADMM_OK) {
+    mem_free_one(e->mem, work1);
+    return rc;
+  }
+  f.err_trsv_one = e1;
+  if (!f.probed) f.err_trsv = eb;
+  const bool ok = (forced && forced[0] == 'o') ||
+                  (e1 <= std::max(1e-11, 4.0 * eb) && diff <= std::max(1e-11, 8.0 * eb));
+  if (ok) {
+    mem_free_one(e->mem, f.work);
+    f.work = work1;
+    f.trsv = one;
+  } else {
+    mem_free_one(e->mem, work1);
+  }
   return ADMM_OK;
 }
 
@@ -274,6 +324,7 @@ int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int
       f.Minv = nullptr;
     }
   }
+  if (f.mode == ADMM_XSOLVE_TRSV) ADMM_TRY(choose_trsv_form(e, f));
   return ADMM_OK;
 }
 
@@ -1546,7 +1597,8 @@ int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
   info->unwrapped_fused = e->Dp ? 1 : 0;
   info->cond_estimate = has ? f->cond_diag : NAN;
   info->probe_err_inverse = f->probed ? f->err_inv : NAN;
-  info->probe_err_trsv = f->probed ? f->err_trsv : NAN;
+  info->probe_err_trsv = (f->probed || f->err_trsv_one == f->err_trsv_one) ? f->err_trsv : NAN;
+  info->probe_err_trsv_one = f->err_trsv_one;
   info->probe_diff = f->probed ? f->probe_diff : NAN;
   // what one iteration's x-solve reads, by cache policy (symv.hip / trsv.hip: tiles below ncached use default loads)
   auto tally = [&](const SliceFactor& s) {
@@ -1558,6 +1610,11 @@ int admm_engine_info(admm_engine* e, admm_engine_info_t* info) {
       info->xsolve_stream_bytes += (tiles - cached) * tile_bytes;
     } else if (s.mode == ADMM_XSOLVE_INVERSE && s.Minv) {
       info->xsolve_cacheable_bytes += int64_t{8} * s.n * s.n;  // one wave per column, cache-resident
+    } else if (s.mode == ADMM_XSOLVE_TRSV && s.trsv.one) {  // ONE triangle, read by both passes
+      const int64_t nt = s.trsv.ntile, tiles = nt * (nt + 1) / 2;
+      const int64_t cached = s.trsv.streaming ? std::min<int64_t>(tiles, std::max<int64_t>(0, s.trsv.ncached)) : tiles;
+      info->xsolve_cacheable_bytes += 2 * cached * tile_bytes;
+      info->xsolve_stream_bytes += 2 * (tiles - cached) * tile_bytes;
     } else if (s.mode == ADMM_XSOLVE_TRSV && s.trsv.Fm) {
       const int64_t nt = s.trsv.ntile, tiles = nt * (nt + 1) / 2;  // per triangle
       const int64_t cached = s.trsv.streaming ? std::min<int64_t>(tiles, std::max<int64_t>(0, s.trsv.ncached)) : tiles;

@@ -93,10 +93,17 @@ extern "C" {
 
 
 static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
-                           bool leave_partials);
+                           int32_t* axtri, bool leave_partials);
+
+// the one-block triangular solves (symv.hip: tri1_*) leave the backward pass's partial rows to the one-launch tail
+static bool xsolve_tri1_partials(const admm_engine* e) {
+  return e->xfac.mode == ADMM_XSOLVE_TRSV && e->xfac.trsv.one && !e->xcb && e->xsolve != ADMM_XSOLVE_CG && !e->fat &&
+         (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED);
+}
 
 // the lower-triangle x-solve may hand its partial rows to the one-launch tail instead of reducing them itself
 static bool xsolve_has_partials(const admm_engine* e) {
+  if (xsolve_tri1_partials(e)) return true;
   return e->xfac.mode == ADMM_XSOLVE_INVERSE && e->xfac.Minv && e->xfac.n >= kSymvHalfMin && !e->sy_split && !e->xcb &&
          e->xsolve == ADMM_XSOLVE_INVERSE && !e->fat &&
          (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED);
@@ -104,12 +111,13 @@ static bool xsolve_has_partials(const admm_engine* e) {
 
 // one x-update (admm.m:501-511) from e->rhs into e->x, or into chunk partials for the fused consumer
 static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
-                    bool leave_partials) {
+                    int32_t* axtri, bool leave_partials) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   *axsrc = e->x;
   *naxpart = 1;
   *axld = 0;
   *axt = nullptr;
+  *axtri = 0;
   if (e->xcb) {  // x = xminf(x, z, u, rho), fast ADMM: xminf(x, v, uhat, rho)   (admm.m:502, 506)
     const bool fastalg = e->last_opts.fast != ADMM_FAST_OFF;
     const double* zarg = e->bgen ? (fastalg ? e->vt : e->zt) : (fastalg ? e->v : e->z);
@@ -127,7 +135,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
   switch (e->problem) {
     case ADMM_PROB_LASSO:
       if (!e->fat) {
-        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, leave_partials));
+        ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, axtri, leave_partials));
       } else {
         // getProxOps.m:1204  x = y/rho - D'*(U\(L\(D*y)))/rho^2
         launch_gemv_n(e->planDN, e->D, e->rhs, e->partDN, e->ctrl, e->stream);
@@ -141,7 +149,7 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
       break;
     case ADMM_PROB_QP_BOUNDED:  // planSq/partSq are shared with the objective GEMV; the x-update consumes them first
     case ADMM_PROB_MODEL:
-      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, leave_partials));
+      ADMM_TRY(factor_x_update(e, axsrc, naxpart, axld, axt, axtri, leave_partials));
       break;
     case ADMM_PROB_LINEARPROGRAM:
     case ADMM_PROB_QP_STANDARD:  // x = K*y + k0: the KKT solve of getProxOps.m:1363 / 1410, reduced once
@@ -166,7 +174,17 @@ static int x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int6
 
 // the cached-factor x-update shared by lasso (tall), bounded QP and the model problem
 static int factor_x_update(admm_engine* e, const double** axsrc, int32_t* naxpart, int64_t* axld, const double** axt,
-                           bool leave_partials) {
+                           int32_t* axtri, bool leave_partials) {
+  if (leave_partials && xsolve_tri1_partials(e)) {  // x = sum of the backward pass's rows from the diagonal tile on
+    const TrsvPlan& t = e->xfac.trsv;
+    launch_tri1_pair(t, e->rhs, nullptr, e->dfin, e->dfin && e->dfin_pending, e->ctrl, e->stream);
+    *axsrc = t.tp1;
+    *axt = t.tp1;
+    *axtri = 1;
+    *naxpart = t.ntile;
+    *axld = t.ldp;
+    return ADMM_OK;
+  }
   if (leave_partials && xsolve_has_partials(e)) {  // x = sum of these rows, taken by prox_fin_kernel
     const SliceFactor& f = e->xfac;
     if (e->dfin && f.planSy.packed)
@@ -740,7 +758,8 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   // (also with the x-solve's tiles split over the ranks: symv_apply hands the same passenger to its launch)
   const bool split_symv = sharded && e->sy_split && e->xfac.mode == ADMM_XSOLVE_INVERSE && e->xfac.Minv && !e->xcb &&
                           (e->problem == ADMM_PROB_LASSO || e->problem == ADMM_PROB_QP_BOUNDED) && !e->fat;
-  bool defer_fin = fuse_tail && e->a_identity && (xsolve_has_partials(e) || split_symv) && e->xfac.planSy.packed && !use_graph &&
+  bool defer_fin = fuse_tail && e->a_identity &&
+                         (((xsolve_has_partials(e) || split_symv) && e->xfac.planSy.packed) || xsolve_tri1_partials(e)) && !use_graph &&
                          std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
   // A = D iterations without a dual residual (fuse_tail): the finalize logic leaves the element update's launch too and
   // runs as one extra workgroup of the partial-sum launch of D'*(c + z - u) that follows it (gemv.hip)
@@ -766,9 +785,9 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
     {
       const double* axsrc;
       const double* axt;
-      int32_t naxpart;
+      int32_t naxpart, axtri;
       int64_t axld;
-      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld, &axt, fuse_tail));
+      ADMM_TRY(x_update(e, &axsrc, &naxpart, &axld, &axt, &axtri, fuse_tail));
       if (!e->a_identity && !e->D) {  // Ax = A(x) with options.A a function handle (admm.m:117-120, 535)
         TimerScope ts(e, ADMM_K_GEMV_N);
         if (e->acb(e->auser, e->x, nA, e->axbuf, len, static_cast<void*>(e->stream)) != 0)
@@ -824,6 +843,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
         TimerScope ts(e, ADMM_K_PROX);
         pa.axsrc = axsrc;
         pa.ax_t = axt;
+        pa.ax_tri = axtri;
         pa.naxpart = naxpart;
         pa.axld = axld;
         pa.x_out = e->a_identity ? e->x : nullptr;

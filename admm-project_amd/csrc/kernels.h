@@ -118,12 +118,45 @@ struct TrsvPlan {
   const void* items;         // device: TpItem[nitems]
   const int32_t* chunks;     // device: first item of every ticket, [nchunks + 1]
   int32_t nitems, nchunks, grid;
+  // one-block form (symv.hip: tri1_*): the whole factor as ONE pre-inverted block, X = inv(L) tile-packed, applied as
+  // w = X y (N-part pass) and x = X' w (T-part pass): 2 launches per pair.  When built, Fm / Um / P / the one-launch
+  // buffers above are absent (nblk = 1 and they would be the same matrix twice).
+  bool one;
+  double* X1;                // tile-packed lower triangle of inv(L)
+  double *np1, *tp1;         // [ntile][ldp] partial rows of the forward / backward pass
+  double* w1;                // [npad] forward result
+  int32_t* cnt1;             // [ntile] arrival counters of the forward pass's row tiles (zero between launches)
 };
+// arguments of the one-block form's kernels
+struct Tri1Args {
+  const double* X;
+  int64_t n;
+  const double* y;           // forward input (n elements, 8-byte aligned)
+  double* npart;
+  double* tpart;
+  double* w;
+  int32_t* cnt;
+  int64_t ldp;
+  uint32_t ncached;          // tiles with linear index < ncached are read with default loads (Infinity Cache share)
+  uint32_t ntri;             // lower-triangle tiles
+  int32_t ntile;
+};
+void launch_tri1_forward(const Tri1Args& a, const FinArgs* fin, bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
+void launch_tri1_backward(const Tri1Args& a, const Ctrl* ctrl, hipStream_t stream);
+void launch_tri1_reduce(const Tri1Args& a, double* x, const Ctrl* ctrl, hipStream_t stream);
+Tri1Args tri1_args(const TrsvPlan& p, const double* y);
+// both passes; x == nullptr leaves the backward pass's partial rows to the consumer (prox_fin_kernel)
+void launch_tri1_pair(const TrsvPlan& p, const double* y, double* x, const FinArgs* fin, bool fin_pending,
+                      const Ctrl* ctrl, hipStream_t stream);
 // doubles the plan needs in one caller-owned device buffer
-size_t trsv_plan_elems(int64_t n);
+// form 0: blocked substitution over K = ceil(n / 2048) coarse blocks; 1: the one-block form (n >= 256).
+// ADMM_TRSV_FORM=blocked|one overrides what the caller asks for (tests, A/B measurements): trsv_resolve_form.
+constexpr int kTrsvBlocked = 0, kTrsvOne = 1;
+int trsv_resolve_form(int64_t n, int form);
+size_t trsv_plan_elems(int64_t n, int form = kTrsvBlocked);
 // dinv64: the inverted 64x64 diagonal blocks of L (cholesky_lower / launch_trtri_diag)
 int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
-               hipStream_t stream);
+               hipStream_t stream, int form = kTrsvBlocked);
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream);
 // the one-launch form's error word (synchronises the stream): ADMM_OK, or ADMM_E_DEVICE after a poll gave up
 int trsv_check_error(const TrsvPlan& p, hipStream_t stream);

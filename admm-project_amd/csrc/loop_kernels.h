@@ -62,6 +62,8 @@ struct ProxArgs {
   const double* ax_t;      // one-launch tail after the lower-triangle x-solve: its T-part partial rows (axsrc = the
                            // N-part rows, naxpart = tiles, axld = row stride); null otherwise
   int32_t naxpart;
+  int32_t ax_tri;          // after the one-block triangular solves (symv.hip: tri1_*): x_i = sum of the rows p >= i / 128
+                           // of ax_t alone (naxpart = tiles; axsrc unused)
   int64_t axld;
   double* x_out;           // A = I: x_i = sum of partials is stored here (may alias axsrc when naxpart == 1)
   const double* c;         // nullable (c = 0)

@@ -313,6 +313,7 @@ constexpr int kTailRows = 24;                       // partial rows a thread loa
 
 __device__ __forceinline__ double tail_gather(const ProxArgs& a, int64_t i, int32_t p0, int32_t p1) {
   // unified partial row p of element i (diagonal tile d = i / 128): p <= d -> axsrc[p] (N-part), else ax_t[p - 1]
+  // (one-block triangular solves, ax_tri: the caller's p counts from the diagonal tile, rows d + p of ax_t)
   const int32_t d = static_cast<int32_t>(i / kTailTile);
   double s = 0.0;
   for (int32_t p = p0; p < p1; p += kTailRows) {
@@ -320,8 +321,9 @@ __device__ __forceinline__ double tail_gather(const ProxArgs& a, int64_t i, int3
 #pragma unroll
     for (int k = 0; k < kTailRows; ++k) {
       const int32_t q = (p + k < p1) ? p + k : p1 - 1;
-      const double* src = (!a.ax_t || q <= d) ? a.axsrc + static_cast<int64_t>(q) * a.axld
-                                               : a.ax_t + static_cast<int64_t>(q - 1) * a.axld;
+      const double* src = a.ax_tri ? a.ax_t + static_cast<int64_t>(d + q) * a.axld
+                          : (!a.ax_t || q <= d) ? a.axsrc + static_cast<int64_t>(q) * a.axld
+                                                : a.ax_t + static_cast<int64_t>(q - 1) * a.axld;
       v[k] = src[i];
     }
 #pragma unroll
@@ -350,7 +352,9 @@ __global__ __launch_bounds__(kTailBlock) void prox_fin_kernel(ProxArgs a, FinArg
   double ax;
   {  // partial rows of this element, split over the four slots: naxpart + 1 rows after the lower-triangle x-solve
      // (N-part rows up to the diagonal tile, T-part rows beyond), naxpart chunk rows of a column-chunked GEMV otherwise
-    const int32_t P = a.ax_t ? a.naxpart + 1 : a.naxpart, q = (P + kTailSlots - 1) / kTailSlots;
+    const int32_t dblk = static_cast<int32_t>(blockIdx.x);  // (kTailTile = the x-solve's tile: one diagonal tile per workgroup)
+    const int32_t P = a.ax_tri ? a.naxpart - dblk : (a.ax_t ? a.naxpart + 1 : a.naxpart);
+    const int32_t q = (P + kTailSlots - 1) / kTailSlots;
     const int32_t p0 = slot * q, p1 = (p0 + q < P) ? p0 + q : P;
     ax = p0 < P ? tail_gather(a, ic, p0, p1) : 0.0;
   }

@@ -93,14 +93,16 @@ __device__ __forceinline__ void sy_load(const SyLane& s, int64_t cp, double2_t (
 }
 
 // DIAG: the tile intersects the diagonal -> mask element-wise (N-part j <= row, T-part row > j)
-template <bool DIAG>
+// NP / TP: which of the two uses of an element are taken (both for the symmetric product; one each for the two
+// passes over a triangular inverse further down, whose diagonal tiles store their zeros: DIAG = false there)
+template <bool DIAG, bool NP = true, bool TP = true>
 __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const double2_t (&d)[kSyPanel], double& n0,
                                            double& n1, double* __restrict__ tout, int lane) {
   double tacc[kSyPanel];
 #pragma unroll
   for (int k = 0; k < kSyPanel; ++k) {
     const int64_t j = cp + k;
-    const double xj = s.x[j < s.n ? j : s.n - 1];  // wave-uniform -> scalar load; padding columns are 0
+    const double xj = NP ? s.x[j < s.n ? j : s.n - 1] : 0.0;  // wave-uniform -> scalar load; padding columns are 0
     double a0 = d[k].x, a1 = d[k].y;
     double t0 = a0, t1 = a1;
     if (DIAG) {
@@ -109,16 +111,20 @@ __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const do
       a0 = (j <= s.r) ? a0 : 0.0;
       a1 = (j <= s.r + 1) ? a1 : 0.0;
     }
-    tacc[k] = __builtin_fma(t0, s.xr0, t1 * s.xr1);
-    n0 = __builtin_fma(a0, xj, n0);
-    n1 = __builtin_fma(a1, xj, n1);
+    if (TP) tacc[k] = __builtin_fma(t0, s.xr0, t1 * s.xr1);
+    if (NP) {
+      n0 = __builtin_fma(a0, xj, n0);
+      n1 = __builtin_fma(a1, xj, n1);
+    }
   }
-  const double sum = reduce_scatter4(tacc);
-  if ((lane & 15) == 0) tout[cp + (lane >> 4)] = sum;
+  if (TP) {
+    const double sum = reduce_scatter4(tacc);
+    if ((lane & 15) == 0) tout[cp + (lane >> 4)] = sum;
+  }
 }
 
 // the 32 panels of one tile, next panel's loads issued before this panel's reduction
-template <bool DIAG, bool NT>
+template <bool DIAG, bool NT, bool NP = true, bool TP = true>
 __device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, double& n0, double& n1,
                                         double* __restrict__ tout, int lane) {
   double2_t bufA[kSyPanel], bufB[kSyPanel];
@@ -126,9 +132,9 @@ __device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, double& n0,
 #pragma unroll 1
   for (int64_t cp = c0; cp < c0 + kSyTile; cp += 2 * kSyPanel) {
     sy_load<NT>(s, cp + kSyPanel, bufB);
-    sy_compute<DIAG>(s, cp, bufA, n0, n1, tout, lane);
+    sy_compute<DIAG, NP, TP>(s, cp, bufA, n0, n1, tout, lane);
     if (cp + 2 * kSyPanel < c0 + kSyTile) sy_load<NT>(s, cp + 2 * kSyPanel, bufA);
-    sy_compute<DIAG>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
+    sy_compute<DIAG, NP, TP>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
   }
 }
 
@@ -250,6 +256,177 @@ __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* c
   const int64_t k = blockIdx.y;
   symv_lower_body<true>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride, tpart0 + k * pstride,
                         ldp, 0, 1, ncached);
+}
+
+// ---------------------------------------------------------------- x = X' (X y),  X = inv(L) tile-packed: the two
+// triangular solves of getProxOps.m:1200 `U \ (L \ y)` with the WHOLE factor as one pre-inverted block (trsv.hip has the
+// blocked substitution this is the one-block case of, and the reason: dependent steps, not bytes, bound a triangular
+// solve here).  Two passes over the same 8 n(n+1)/2 bytes -- the N-part alone (w = X y: rows in registers), then the
+// T-part alone (x = X' w: column sums by the reduce-scatter above) -- so both sweeps share ONE array and its
+// Infinity-Cache resident share.  Forward: tile (bi, bj) stores its partial row write-through and arrives on the counter
+// of row tile bi; the LAST of its bi + 1 tiles sums them in fixed order into w (the backward pass needs w as a vector:
+// two values per lane).  Tiles are dealt in DEscending order, long rows first, so the last folds are the short ones.
+// Backward: tile (bi, bj) writes tpart[bi][columns of bj]; x = sum over bi >= bj, taken by the consumer
+// (prox_fin_kernel's gather, or tri1_reduce_kernel).  Sums in fixed order whatever the arrival order.
+constexpr int kT1Panel = 4;  // forward pass: columns per load group (8: 144 VGPRs = 3 waves per SIMD = 12 tile slots per CU
+                             // for 12.3 tiles per CU at n = 10^4: a second generation for the last 88 tiles)
+
+__device__ __forceinline__ double t1_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <bool NT>
+__device__ __forceinline__ void t1_load(const double* __restrict__ Mr, int c, double2_t (&d)[kT1Panel]) {
+#pragma unroll
+  for (int k = 0; k < kT1Panel; ++k) d[k] = load2<NT>(Mr + (c + k) * kSyTile);
+}
+// yp: lane l holds the input pair of the tile's columns (2l, 2l + 1)
+__device__ __forceinline__ void t1_fma(double2_t yp, int co, const double2_t (&d)[kT1Panel], double& a0, double& a1) {
+#pragma unroll
+  for (int k = 0; k < kT1Panel; ++k) {
+    const double yj = t1_readlane((k & 1) ? yp.y : yp.x, (co + k) >> 1);
+    a0 = __builtin_fma(d[k].x, yj, a0);
+    a1 = __builtin_fma(d[k].y, yj, a1);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void t1_forward_tile(const double* __restrict__ Mr, double2_t yp, double& a0, double& a1) {
+  double2_t bufA[kT1Panel], bufB[kT1Panel];
+  t1_load<NT>(Mr, 0, bufA);
+#pragma unroll 1
+  for (int co = 0; co < kSyTile; co += 2 * kT1Panel) {
+    t1_load<NT>(Mr, co + kT1Panel, bufB);
+    t1_fma(yp, co, bufA, a0, a1);
+    if (co + 2 * kT1Panel < kSyTile) t1_load<NT>(Mr, co + 2 * kT1Panel, bufA);
+    t1_fma(yp, co + kT1Panel, bufB, a0, a1);
+  }
+}
+
+__device__ __forceinline__ void tri1_forward_body(unsigned lin, const Tri1Args& a, bool stopped) {
+  unsigned bi, bj;
+  tri_decode(lin, bi, bj);
+  const int lane = threadIdx.x & 63;
+  const int64_t gr = static_cast<int64_t>(bi) * kSyTile + 2 * lane;  // this lane's row pair
+  double* __restrict__ po = a.npart + static_cast<int64_t>(bj) * a.ldp + gr;
+  if (!stopped) {
+    const double* __restrict__ Mr = a.X + static_cast<int64_t>(lin) * (kSyTile * kSyTile) + 2 * lane;
+    const int64_t e = static_cast<int64_t>(bj) * kSyTile + 2 * lane;  // the tile's input columns: pair (2l, 2l + 1)
+    double2_t yp{0.0, 0.0};  // (the caller's vector is only 8-byte aligned and not padded)
+    yp.x = a.y[e < a.n ? e : a.n - 1];
+    yp.y = a.y[e + 1 < a.n ? e + 1 : a.n - 1];
+    if (e >= a.n) yp.x = 0.0;
+    if (e + 1 >= a.n) yp.y = 0.0;
+    double a0 = 0.0, a1 = 0.0;
+    if (lin < a.ncached) t1_forward_tile<false>(Mr, yp, a0, a1);
+    else t1_forward_tile<true>(Mr, yp, a0, a1);
+    __hip_atomic_store(po, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
+    __hip_atomic_store(po + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial row has left this wave before the counter says so
+  }
+  // A launch that finds the stop flag raised streams nothing, but it still arrives: the flag may be raised DURING this
+  // launch (the finalize passenger), and counters left half-way would poison the next run.  Whatever a stopped launch
+  // leaves in w is never used: every launch behind it starts with the flag raised.
+  int32_t old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(a.cnt + bi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != static_cast<int32_t>(bi)) return;  // row tile bi has bi + 1 tiles
+  if (lane == 0) __hip_atomic_store(a.cnt + bi, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (stopped) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  constexpr int G = 16;
+  double s0 = 0.0, s1 = 0.0;
+  const double* __restrict__ pr = a.npart + gr;
+  const int32_t np = static_cast<int32_t>(bi) + 1;
+  for (int32_t q = 0; q < np; q += G) {
+    double v0[G], v1[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {  // clamped: the loads of a group stay unconditional and go out together
+      const int32_t qq = (q + k < np) ? q + k : np - 1;
+      v0[k] = __hip_atomic_load(pr + static_cast<int64_t>(qq) * a.ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v1[k] = __hip_atomic_load(pr + static_cast<int64_t>(qq) * a.ldp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (q + k < np) {
+        s0 += v0[k];
+        s1 += v1[k];
+      }
+  }
+  *reinterpret_cast<double2_t*>(a.w + gr) = double2_t{s0, s1};  // w has npad entries (rows >= n: zero rows of X)
+}
+
+// workgroup 0 is the passenger of symv_lower_fin_kernel: the deferred finalize logic of the previous iteration
+__global__ __launch_bounds__(kWave) void tri1_forward_kernel(Tri1Args a, FinArgs f, int32_t fin_pending,
+                                                             const Ctrl* __restrict__ ctrl) {
+  asm volatile("" ::"s"(a.X), "s"(a.n), "s"(a.npart), "s"(a.cnt), "s"(a.ldp), "s"(a.ncached), "s"(a.ntri),
+               "s"(fin_pending), "s"(ctrl));
+  const bool stopped = ctrl && ctrl->stop;
+  if (blockIdx.x == 0) {
+    if (fin_pending && !stopped) finalize_body<false, kWave>(f);
+    return;
+  }
+  tri1_forward_body(a.ntri - blockIdx.x, a, stopped);  // blockIdx 1 .. ntri -> tiles ntri - 1 .. 0
+}
+
+__global__ __launch_bounds__(kWave) void tri1_backward_kernel(Tri1Args a, const Ctrl* __restrict__ ctrl) {
+  asm volatile("" ::"s"(a.X), "s"(a.n), "s"(a.tpart), "s"(a.ldp), "s"(a.ncached), "s"(ctrl));
+  if (ctrl && ctrl->stop) return;
+  const unsigned lin = blockIdx.x;
+  unsigned bi, bj;
+  tri_decode(lin, bi, bj);
+  const int lane = threadIdx.x & 63;
+  const int64_t gr = static_cast<int64_t>(bi) * kSyTile + 2 * lane;
+  SyLane s;
+  s.M = a.X + static_cast<int64_t>(lin) * (kSyTile * kSyTile);
+  s.x = nullptr;
+  s.ld = kSyTile;
+  s.n = 0;
+  s.r = 2 * lane;
+  const double2_t wr = *reinterpret_cast<const double2_t*>(a.w + gr);
+  s.xr0 = wr.x;
+  s.xr1 = wr.y;
+  double* __restrict__ tout = a.tpart + static_cast<int64_t>(bi) * a.ldp + static_cast<int64_t>(bj) * kSyTile;
+  double n0 = 0.0, n1 = 0.0;
+  if (lin < a.ncached) sy_tile<false, false, false, true>(s, 0, n0, n1, tout, lane);
+  else sy_tile<false, true, false, true>(s, 0, n0, n1, tout, lane);
+}
+
+// x[i] = sum_{p >= d} tpart[p][i],  d = i / 128  (the stand-alone form of what prox_fin_kernel's gather does)
+__global__ __launch_bounds__(kBlock) void tri1_reduce_kernel(const double* __restrict__ tpart, int64_t ldp, int64_t n,
+                                                             int32_t ntile, double* __restrict__ x,
+                                                             const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double sacc[16][17];
+  const int ii = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + ii;
+  double s = 0.0;
+  if (i < n) {
+    const int32_t d = static_cast<int32_t>(i / kSyTile);
+#pragma unroll 4
+    for (int32_t p = d + slot; p < ntile; p += 16) s += tpart[static_cast<int64_t>(p) * ldp + i];
+  }
+  sacc[slot][ii] = s;
+  __syncthreads();
+  if (slot == 0 && i < n) {
+    double t = sacc[0][ii];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sacc[k][ii];
+    x[i] = t;
+  }
+}
+
+void launch_tri1_forward(const Tri1Args& a, const FinArgs* fin, bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+  const FinArgs f = fin ? *fin : FinArgs{};
+  hipLaunchKernelGGL(tri1_forward_kernel, dim3(a.ntri + 1u), dim3(kWave), 0, stream, a, f,
+                     (fin && fin_pending) ? 1 : 0, ctrl);
+}
+void launch_tri1_backward(const Tri1Args& a, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(tri1_backward_kernel, dim3(a.ntri), dim3(kWave), 0, stream, a, ctrl);
+}
+void launch_tri1_reduce(const Tri1Args& a, double* x, const Ctrl* ctrl, hipStream_t stream) {
+  hipLaunchKernelGGL(tri1_reduce_kernel, dim3(static_cast<unsigned>(ceil_div(a.n, int64_t{16}))), dim3(kBlock), 0,
+                     stream, a.tpart, a.ldp, a.n, a.ntile, x, ctrl);
 }
 
 // column-major padded storage -> tile-packed storage (one workgroup per lower-triangle tile)

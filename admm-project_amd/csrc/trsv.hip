@@ -523,9 +523,105 @@ static TsGeom ts_geom(int64_t n) {
   return g;
 }
 
-size_t trsv_plan_elems(int64_t n) {
+// ---------------------------------------------------------------- the one-block form (kernels: symv.hip, tri1_*)
+// With the whole factor as ONE pre-inverted block the chain has no steps left: w = X y and x = X' w, X = inv(L), are
+// two bandwidth-bound passes over the same tile-packed triangle (8 n(n+1) bytes per pair, what the substitution reads)
+// and two launches.  The price is numerical: X is an explicit triangular inverse, forward error ~ eps * cond(L) per
+// pass where the blocked form has eps * cond(L_kk) -- still the SQUARE ROOT of what the explicit inverse of L L' costs
+// (`inverse` form).  Which of the two runs is decided by measurement at create (engine.hip: choose_trsv_form).
+int trsv_resolve_form(int64_t n, int form) {
+  if (const char* ev = std::getenv("ADMM_TRSV_FORM")) {
+    if (ev[0] == 'b') form = kTrsvBlocked;
+    else if (ev[0] == 'o') form = kTrsvOne;
+  }
+  if (n < 256) form = kTrsvBlocked;  // one or two tiles: nothing to gain
+  return form;
+}
+
+struct T1Geom {
+  int64_t npad, ntile, ntri;
+  size_t x_elems, part_elems, w_elems, cnt_elems;
+};
+static T1Geom t1_geom(int64_t n) {
+  T1Geom g{};
+  g.npad = round_up(n, kTsTile);
+  g.ntile = g.npad / kTsTile;
+  g.ntri = g.ntile * (g.ntile + 1) / 2;
+  g.x_elems = static_cast<size_t>(g.ntri) * kTsTile * kTsTile;
+  g.part_elems = static_cast<size_t>(g.ntile * g.npad);
+  g.w_elems = static_cast<size_t>(g.npad);
+  g.cnt_elems = static_cast<size_t>(g.ntile / 2 + 2);  // int32 counters in double-sized slots
+  return g;
+}
+
+size_t trsv_plan_elems(int64_t n, int form) {
+  if (trsv_resolve_form(n, form) == kTrsvOne) {
+    const T1Geom g = t1_geom(n);
+    return g.x_elems + 2 * g.part_elems + g.w_elems + g.cnt_elems;
+  }
   const TsGeom g = ts_geom(n);
   return g.base_elems + g.pp_elems + g.bb_elems + g.sync_elems + g.item_elems + g.chunk_elems;
+}
+
+static int tri1_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
+                      hipStream_t stream) {
+  TrsvPlan& p = *plan;
+  p = TrsvPlan{};
+  const T1Geom g = t1_geom(n);
+  p.n = n;
+  p.npad = g.npad;
+  p.ntile = static_cast<int32_t>(g.ntile);
+  p.nblk = 1;
+  p.bt = p.ntile;
+  p.ldm = p.npad;
+  p.ldp = p.npad;
+  p.one = true;
+  p.X1 = buf;
+  p.np1 = p.X1 + g.x_elems;
+  p.tp1 = p.np1 + g.part_elems;
+  p.w1 = p.tp1 + g.part_elems;
+  p.cnt1 = reinterpret_cast<int32_t*>(p.w1 + g.w_elems);
+  p.streaming = stream_hint(static_cast<int64_t>(g.x_elems) * 8);
+  // ONE array serves both passes: the whole Infinity-Cache budget of symv.hip goes to its first tiles
+  p.ncached = p.streaming ? static_cast<int64_t>(kSymvCacheBytes / (8 * kTsTile * kTsTile)) : INT64_MAX;
+  ADMM_HIP_TRY(hipMemsetAsync(buf, 0, trsv_plan_elems(n, kTrsvOne) * sizeof(double), stream));
+  double* dense = nullptr;  // X = inv(L) as a padded column-major square (zero above the diagonal and outside n x n)
+  const size_t msz = static_cast<size_t>(p.npad) * p.npad;
+  ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dense), msz * sizeof(double)));
+  hipError_t se = hipMemsetAsync(dense, 0, msz * sizeof(double), stream);
+  int rc = (se == hipSuccess) ? trtri_lower_from_diag(L, n, ldl, dinv64, dense, p.ldm, stream, false)
+                              : fail(ADMM_E_DEVICE, "hipMemsetAsync failed");
+  if (rc == ADMM_OK)
+    hipLaunchKernelGGL(ts_pack_kernel, dim3(static_cast<unsigned>(g.ntri)), dim3(kBlock), 0, stream, dense, p.ldm, p.X1, 0);
+  se = hipStreamSynchronize(stream);
+  (void)hipFree(dense);
+  ADMM_TRY(rc);
+  ADMM_HIP_TRY(se);
+  return ADMM_OK;
+}
+
+Tri1Args tri1_args(const TrsvPlan& p, const double* y) {
+  Tri1Args a{};
+  a.X = p.X1;
+  a.n = p.n;
+  a.y = y;
+  a.npart = p.np1;
+  a.tpart = p.tp1;
+  a.w = p.w1;
+  a.cnt = p.cnt1;
+  a.ldp = p.ldp;
+  a.ncached = static_cast<uint32_t>(p.ncached > 0xffffffffLL ? 0xffffffffLL : (p.ncached < 0 ? 0 : p.ncached));
+  a.ntile = p.ntile;
+  a.ntri = static_cast<uint32_t>(p.ntile) * static_cast<uint32_t>(p.ntile + 1) / 2u;
+  return a;
+}
+
+void launch_tri1_pair(const TrsvPlan& p, const double* y, double* x, const FinArgs* fin, bool fin_pending,
+                      const Ctrl* ctrl, hipStream_t stream) {
+  const Tri1Args a = tri1_args(p, y);
+  launch_tri1_forward(a, fin, fin_pending, ctrl, stream);
+  launch_tri1_backward(a, ctrl, stream);
+  if (x) launch_tri1_reduce(a, x, ctrl, stream);
 }
 
 // the ordered work list of the one-launch form (tri_persist_kernel has the ordering rule)
@@ -596,8 +692,10 @@ static void ts_work_list(const TsGeom& g, std::vector<TpItem>* items, std::vecto
 // L: n x n lower factor (upper part ignored); dinv64: its inverted 64x64 diagonal blocks.
 // `buf` must hold trsv_plan_elems(n) doubles and is owned by the caller.
 int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
-               hipStream_t stream) {
+               hipStream_t stream, int form) {
+  if (trsv_resolve_form(n, form) == kTrsvOne) return tri1_build(L, n, ldl, dinv64, buf, plan, stream);
   TrsvPlan& p = *plan;
+  p = TrsvPlan{};
   p.n = n;
   p.npad = round_up(n, kTsTile);
   p.ntile = static_cast<int32_t>(p.npad / kTsTile);
@@ -617,7 +715,7 @@ int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, do
   p.streaming = stream_hint(static_cast<int64_t>(psz) * 2 * 8);
   // the split cache policy of symv.hip: both triangles are read once per solve pair and share the budget
   p.ncached = p.streaming ? static_cast<int64_t>(kSymvCacheBytes / 2 / (8 * kTsTile * kTsTile)) : INT64_MAX;
-  ADMM_HIP_TRY(hipMemsetAsync(buf, 0, trsv_plan_elems(n) * sizeof(double), stream));
+  ADMM_HIP_TRY(hipMemsetAsync(buf, 0, trsv_plan_elems(n, kTrsvBlocked) * sizeof(double), stream));
   double* dense = nullptr;  // Fm | Um as padded column-major squares: GEMM outputs, packed below
   ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dense), 2 * msz * sizeof(double)));
   ADMM_HIP_TRY(hipMemsetAsync(dense, 0, 2 * msz * sizeof(double), stream));
@@ -720,6 +818,10 @@ static void ts_step(const TriStepArgs& a, bool nt, hipStream_t stream) {
 
 // y, x: n elements (not padded); x may alias y.
 void launch_trsv_pair(const TrsvPlan& p, const double* y, double* x, const Ctrl* ctrl, hipStream_t stream) {
+  if (p.one) {
+    launch_tri1_pair(p, y, x, nullptr, false, ctrl, stream);
+    return;
+  }
   // The one-launch form is correct (tests/test_gpu_ops.py::test_trsv_pair runs both) but NOT the default: at n = 10^4 it
   // measured 294 us per pair against 171 us for the 2K + 1 launches below (profiles/r3_trsv_persist.txt).  A tile costs a
   // resident workgroup ~10 dependent memory round trips (ticket, item, two counter polls, the fold of up to 16 partial

@@ -427,7 +427,7 @@ class Engine:
                     xsolve_used=names.get(i.xsolve_used, i.xsolve_used), pinv_used=bool(i.pinv_used),
                     probed=bool(i.probed), unwrapped_fused=bool(i.unwrapped_fused), trsv_blocks=i.trsv_blocks, jacobi_sweeps=i.jacobi_sweeps,
                     factor_n=i.factor_n, rank=i.rank, cond_estimate=i.cond_estimate,
-                    probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_diff=i.probe_diff,
+                    probe_err_inverse=i.probe_err_inverse, probe_err_trsv=i.probe_err_trsv, probe_err_trsv_one=i.probe_err_trsv_one, probe_diff=i.probe_diff,
                     xsolve_cacheable_bytes=i.xsolve_cacheable_bytes, xsolve_stream_bytes=i.xsolve_stream_bytes,
                     obj_bound_max=i.obj_bound_max, obj_form_literal=bool(i.obj_form_literal))
 

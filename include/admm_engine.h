@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADMM_ABI_VERSION 4
+#define ADMM_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------------ */
 enum {
@@ -318,6 +318,10 @@ typedef struct admm_engine_info_t {
   double obj_bound_max;
   int32_t obj_form_literal;
   int32_t reserved0;
+  /* ABI 5: the triangular solves' one-block form (the whole factor pre-inverted: two passes, two launches per pair;
+   * trsv_blocks = 1 when it is in use): its forward error on the probe system next to probe_err_trsv, which is the
+   * blocked substitution's (the yardstick); NaN where it was not built (n < 1536, or the explicit inverse runs) */
+  double probe_err_trsv_one;
 } admm_engine_info_t;
 int admm_engine_info(admm_engine* eng, admm_engine_info_t* info);
 /* seconds spent in create (upload + factorisation); solverruntime = setup + runtime */

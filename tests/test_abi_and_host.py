@@ -38,7 +38,7 @@ def test_struct_sizes_and_defaults(ap):
     d = ap._lib.ProblemDesc()
     lib.admm_problem_desc_default(C.byref(d))
     assert d.struct_size == C.sizeof(ap._lib.ProblemDesc)
-    assert lib.admm_abi_version() == ap._lib.ABI_VERSION == 4
+    assert lib.admm_abi_version() == ap._lib.ABI_VERSION == 5
 
 
 def test_enum_values_match_header(ap):

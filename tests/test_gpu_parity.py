@@ -353,6 +353,56 @@ def test_factor_guard_rejects_a_bad_inverse(gpu):
         assert info["probe_err_inverse"] <= max(1e-9, 2 * info["probe_err_trsv"])
 
 
+@pytest.mark.parametrize("rows,cols,seed", [(600, 300, 5), (2500, 1100, 4), (4200, 1700, 6)])
+@pytest.mark.parametrize("opts", [dict(objevals=1), dict(maxiters=9, domaxiters=1, record_history=0),
+                                  dict(fast=1, fasttype="strong", maxiters=12, domaxiters=1),
+                                  dict(fast=1, fasttype="weak", objevals=1, maxiters=12, domaxiters=1),
+                                  dict(relax=1.6, maxiters=12, domaxiters=1)])
+def test_lasso_through_the_one_block_triangular_solves(gpu, rows, cols, seed, opts, monkeypatch):
+    """xsolve = trsv with the whole factor as ONE pre-inverted block (two passes over inv(L), symv.hip: tri1_*): the
+    forward pass carries the deferred finalize, the element update sums the backward pass's partial rows -- every loop
+    variant against the oracle's LAPACK substitution; the arrival counters survive early stops and batch ends"""
+    monkeypatch.setenv("ADMM_TRSV_FORM", "one")
+    p = gpu.synth.lasso_problem(seed, rows, cols)
+    got = gpu.lasso(p["D"], p["s"], p["lam"], dict(opts, xsolve="trsv"))
+    ref_opts = {k: v for k, v in opts.items() if k != "record_history"}
+    ref = S.lasso(p["D"], p["s"], p["lam"], ref_opts)
+    keys = HIST if opts.get("record_history", 1) else ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr")
+    _compare(got, ref, keys=keys)
+    info = got["engine_info"]
+    assert info["xsolve_used"] == "trsv" and info["trsv_blocks"] == 1
+    assert info["probe_err_trsv_one"] < 1e-12 and info["probe_err_trsv"] < 1e-12
+
+
+@pytest.mark.parametrize("solver", ["lad", "huberfit"])
+def test_a_equals_d_problems_through_the_one_block_triangular_solves(gpu, solver, monkeypatch):
+    """the same form where x is needed as a vector (D*x follows): backward pass + tri1_reduce_kernel"""
+    monkeypatch.setenv("ADMM_TRSV_FORM", "one")
+    p = gpu.synth.lad_problem(2, 900, 400)
+    o = dict(objevals=1, domaxiters=1, maxiters=30)
+    got = getattr(gpu, solver)(p["D"], p["s"], dict(o, xsolve="trsv"))
+    ref = getattr(S, solver)(p["D"], p["s"], o)
+    _compare(got, ref)
+    assert got["engine_info"]["trsv_blocks"] == 1
+
+
+@pytest.mark.parametrize("kappa", [1e3, 1e4, 1e5])
+def test_one_block_form_is_chosen_by_measurement(gpu, kappa):
+    """no override: at create the one-block form replaces the blocked substitution only while the probe finds it as
+    accurate (4x / 8x) or below 1e-11; whichever runs, the iterates match the oracle"""
+    p = gpu.synth.lad_problem_conditioned(1, 2400, 1600, kappa)
+    o = dict(objevals=1, domaxiters=1, maxiters=25)
+    got = gpu.lad(p["D"], p["s"], dict(o, xsolve="trsv"))
+    ref = S.lad(p["D"], p["s"], o)
+    _compare(got, ref, tol=1e-6)
+    info = got["engine_info"]
+    assert info["xsolve_used"] == "trsv" and info["trsv_blocks"] >= 1
+    e1, eb = info["probe_err_trsv_one"], info["probe_err_trsv"]
+    assert e1 == e1 and eb == eb  # both were measured
+    if info["trsv_blocks"] == 1:
+        assert e1 <= max(1e-11, 4 * eb)
+
+
 def test_well_conditioned_auto_keeps_the_inverse(gpu):
     p = gpu.synth.lasso_problem(3, 1000, 300)
     got = gpu.lasso(p["D"], p["s"], p["lam"], dict(xsolve="auto"))
