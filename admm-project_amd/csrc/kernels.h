@@ -119,13 +119,12 @@ struct TrsvPlan {
   const int32_t* chunks;     // device: first item of every ticket, [nchunks + 1]
   int32_t nitems, nchunks, grid;
   // one-block form (symv.hip: tri1_*): the whole factor as ONE pre-inverted block, X = inv(L) tile-packed, applied as
-  // w = X y (N-part pass) and x = X' w (T-part pass): 2 launches per pair.  When built, Fm / Um / P / the one-launch
+  // w = X y (N-part pass + fold) and x = X' w (T-part pass): 3 launches per pair.  When built, Fm / Um / P / the one-launch
   // buffers above are absent (nblk = 1 and they would be the same matrix twice).
   bool one;
   double* X1;                // tile-packed lower triangle of inv(L)
   double *np1, *tp1;         // [ntile][ldp] partial rows of the forward / backward pass
   double* w1;                // [npad] forward result
-  int32_t* cnt1;             // [ntile] arrival counters of the forward pass's row tiles (zero between launches)
 };
 // arguments of the one-block form's kernels
 struct Tri1Args {
@@ -135,7 +134,6 @@ struct Tri1Args {
   double* npart;
   double* tpart;
   double* w;
-  int32_t* cnt;
   int64_t ldp;
   uint32_t ncached;          // tiles with linear index < ncached are read with default loads (Infinity Cache share)
   uint32_t ntri;             // lower-triangle tiles
@@ -149,8 +147,9 @@ Tri1Args tri1_args(const TrsvPlan& p, const double* y);
 void launch_tri1_pair(const TrsvPlan& p, const double* y, double* x, const FinArgs* fin, bool fin_pending,
                       const Ctrl* ctrl, hipStream_t stream);
 // doubles the plan needs in one caller-owned device buffer
-// form 0: blocked substitution over K = ceil(n / 2048) coarse blocks; 1: the one-block form (n >= 256).
-// ADMM_TRSV_FORM=blocked|one overrides what the caller asks for (tests, A/B measurements): trsv_resolve_form.
+// form 0: blocked substitution over K = ceil(n / 2048) coarse blocks; 1: the one-block form (n >= 256, else blocked).
+// trsv_resolve_form: `form` unless ADMM_TRSV_FORM=blocked|one says otherwise (tests, A/B measurements) -- consulted by
+// the callers that have a choice (engine.hip: choose_trsv_form; ops.hip), never by trsv_build itself.
 constexpr int kTrsvBlocked = 0, kTrsvOne = 1;
 int trsv_resolve_form(int64_t n, int form);
 size_t trsv_plan_elems(int64_t n, int form = kTrsvBlocked);

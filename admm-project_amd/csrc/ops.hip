@@ -140,8 +140,9 @@ int admm_op_trsv_pair(const double* L, int64_t n, int64_t ldL, const double* y, 
   TrsvPlan plan{};
   ADMM_TRY(sc.alloc(&dinv, static_cast<size_t>(ceil_div(n, 64)) * 64 * 64));
   launch_trtri_diag(dL, n, ld, dinv, nullptr);
-  ADMM_TRY(sc.alloc(&buf, trsv_plan_elems(n)));
-  ADMM_TRY(trsv_build(dL, n, ld, dinv, buf, &plan, nullptr));
+  const int form = trsv_resolve_form(n, kTrsvBlocked);
+  ADMM_TRY(sc.alloc(&buf, trsv_plan_elems(n, form)));
+  ADMM_TRY(trsv_build(dL, n, ld, dinv, buf, &plan, nullptr, form));
   launch_trsv_pair(plan, dy, dx, nullptr, nullptr);
   ADMM_TRY(trsv_check_error(plan, nullptr));
   ADMM_HIP_TRY(hipDeviceSynchronize());

@@ -124,17 +124,32 @@ __device__ __forceinline__ void sy_compute(const SyLane& s, int64_t cp, const do
 }
 
 // the 32 panels of one tile, next panel's loads issued before this panel's reduction
-template <bool DIAG, bool NT, bool NP = true, bool TP = true>
+// NBUF panel buffers: NBUF - 1 panels (4 KB each per wave) in flight while one is consumed.  The launch is ONE
+// generation of one-tile waves (3160 tiles on 256 CUs at n = 10^4: 12.3 waves per CU, set by the tile count, not by
+// registers), so the bytes in flight per CU are 12.3 x (NBUF - 1) x 4 KB (+ the panel being waited for).
+template <bool DIAG, bool NT, bool NP = true, bool TP = true, int NBUF = 2>
 __device__ __forceinline__ void sy_tile(const SyLane& s, int64_t c0, double& n0, double& n1,
                                         double* __restrict__ tout, int lane) {
-  double2_t bufA[kSyPanel], bufB[kSyPanel];
-  sy_load<NT>(s, c0, bufA);
+  constexpr int kPanels = kSyTile / kSyPanel, kFull = (kPanels / NBUF) * NBUF;
+  static_assert(NBUF >= 2 && NBUF <= 8, "ring of panel buffers");
+  double2_t buf[NBUF][kSyPanel];
+#pragma unroll
+  for (int b = 0; b + 1 < NBUF; ++b) sy_load<NT>(s, c0 + b * kSyPanel, buf[b]);
 #pragma unroll 1
-  for (int64_t cp = c0; cp < c0 + kSyTile; cp += 2 * kSyPanel) {
-    sy_load<NT>(s, cp + kSyPanel, bufB);
-    sy_compute<DIAG, NP, TP>(s, cp, bufA, n0, n1, tout, lane);
-    if (cp + 2 * kSyPanel < c0 + kSyTile) sy_load<NT>(s, cp + 2 * kSyPanel, bufA);
-    sy_compute<DIAG, NP, TP>(s, cp + kSyPanel, bufB, n0, n1, tout, lane);
+  for (int g = 0; g < kFull; g += NBUF) {
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b) {
+      // panel g + b is consumed from buf[b]; the panel NBUF - 1 ahead goes into the buffer freed last
+      const int nxt = g + b + NBUF - 1;
+      if (kFull - NBUF + b + NBUF - 1 < kPanels || nxt < kPanels)  // (first test: compile time, true for every g)
+        sy_load<NT>(s, c0 + nxt * kSyPanel, buf[(b + NBUF - 1) % NBUF]);
+      sy_compute<DIAG, NP, TP>(s, c0 + (g + b) * kSyPanel, buf[b], n0, n1, tout, lane);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < kPanels - kFull; ++b) {  // the panels a ring that does not divide 32 leaves over
+    if (kFull + b + NBUF - 1 < kPanels) sy_load<NT>(s, c0 + (kFull + b + NBUF - 1) * kSyPanel, buf[(b + NBUF - 1) % NBUF]);
+    sy_compute<DIAG, NP, TP>(s, c0 + (kFull + b) * kSyPanel, buf[b], n0, n1, tout, lane);
   }
 }
 
@@ -150,7 +165,7 @@ __device__ __forceinline__ void tri_decode(unsigned t, unsigned& bi, unsigned& b
 // PACKED = false: M is npad x npad (npad = round_up(n, 128)) column-major with ld >= npad, zero outside n x n; grid
 // (ntile, ntile).  PACKED = true: M holds the lower-triangle tiles back to back (symv_pack_kernel); grid = their count.
 // x: n elements.  Tiles with linear index < ncached use default loads, the others non-temporal ones.
-template <bool PACKED>
+template <bool PACKED, int NBUF = 2>
 __device__ __forceinline__ void symv_lower_body(unsigned block_x, unsigned block_y, const double* __restrict__ M,
                                                 int64_t n, int64_t ld, const double* __restrict__ x,
                                                 double* __restrict__ npart, double* __restrict__ tpart, int64_t ldp,
@@ -195,11 +210,11 @@ __device__ __forceinline__ void symv_lower_body(unsigned block_x, unsigned block
   s.xr1 = x[gr + 1 < n ? gr + 1 : n - 1];
   double n0 = 0.0, n1 = 0.0;
   if (lin < ncached) {
-    if (bi == bj) sy_tile<true, false>(s, cbase, n0, n1, tout, lane);
-    else sy_tile<false, false>(s, cbase, n0, n1, tout, lane);
+    if (bi == bj) sy_tile<true, false, true, true, NBUF>(s, cbase, n0, n1, tout, lane);
+    else sy_tile<false, false, true, true, NBUF>(s, cbase, n0, n1, tout, lane);
   } else {
-    if (bi == bj) sy_tile<true, true>(s, cbase, n0, n1, tout, lane);
-    else sy_tile<false, true>(s, cbase, n0, n1, tout, lane);
+    if (bi == bj) sy_tile<true, true, true, true, NBUF>(s, cbase, n0, n1, tout, lane);
+    else sy_tile<false, true, true, true, NBUF>(s, cbase, n0, n1, tout, lane);
   }
   *reinterpret_cast<double2_t*>(npart + static_cast<int64_t>(bj) * ldp + gr) = double2_t{n0, n1};
 }
@@ -218,6 +233,7 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
 // stop decision: ~6 us of one workgroup's serial work) while the other workgroups stream the matrix.  Nothing in this
 // launch depends on that decision, and the fused element update that follows starts after it and no-ops when it has
 // raised ctrl->stop: the tail of an iteration shrinks to the element update itself (engine_run.hip, defer_fin).
+template <int NBUF>
 __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __restrict__ M, int64_t n,
                                                                const double* __restrict__ x,
                                                                double* __restrict__ npart, double* __restrict__ tpart,
@@ -234,12 +250,13 @@ __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __r
     if (fin_pending) finalize_body<false, kWave>(f);
     return;
   }
-  symv_lower_body<true>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, part_rank, part_count, ncached);
+  symv_lower_body<true, NBUF>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, part_rank, part_count, ncached);
 }
 
 // K packed matrices of one size in ONE launch (consensus lasso: the K slice inverses of a rank; blockIdx.y = slice):
 // x, npart, tpart of slice k at x0 + k*xstride, npart0 + k*pstride, tpart0 + k*pstride
 // (workgroup (0, 0) is a passenger: the deferred finalize logic of the previous iteration, as in symv_lower_fin_kernel)
+template <int NBUF>
 __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* const* __restrict__ Ms, int64_t n,
                                                                  const double* __restrict__ x0, int64_t xstride,
                                                                  double* __restrict__ npart0,
@@ -254,8 +271,8 @@ __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* c
     return;
   }
   const int64_t k = blockIdx.y;
-  symv_lower_body<true>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride, tpart0 + k * pstride,
-                        ldp, 0, 1, ncached);
+  symv_lower_body<true, NBUF>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride,
+                              tpart0 + k * pstride, ldp, 0, 1, ncached);
 }
 
 // ---------------------------------------------------------------- x = X' (X y),  X = inv(L) tile-packed: the two
@@ -263,11 +280,15 @@ __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* c
 // blocked substitution this is the one-block case of, and the reason: dependent steps, not bytes, bound a triangular
 // solve here).  Two passes over the same 8 n(n+1)/2 bytes -- the N-part alone (w = X y: rows in registers), then the
 // T-part alone (x = X' w: column sums by the reduce-scatter above) -- so both sweeps share ONE array and its
-// Infinity-Cache resident share.  Forward: tile (bi, bj) stores its partial row write-through and arrives on the counter
-// of row tile bi; the LAST of its bi + 1 tiles sums them in fixed order into w (the backward pass needs w as a vector:
-// two values per lane).  Tiles are dealt in DEscending order, long rows first, so the last folds are the short ones.
+// Infinity-Cache resident share.  Forward: tile (bi, bj) writes the partial row npart[bj][rows of bi]; w = their sum
+// over bj <= bi, by tri1_fold_kernel (the backward pass needs w as a vector: two values per lane).  Tiles are dealt in
+// DEscending order and the backward pass in ascending order: what one pass read last the next one reads first.
 // Backward: tile (bi, bj) writes tpart[bi][columns of bj]; x = sum over bi >= bj, taken by the consumer
-// (prox_fin_kernel's gather, or tri1_reduce_kernel).  Sums in fixed order whatever the arrival order.
+// (prox_fin_kernel's gather, or tri1_reduce_kernel).  Every sum in a fixed order.
+// (Measured, n = 10^4: forward 60 us + fold + backward 62 us = 6.4 TB/s per pass, the ceiling of a read stream that
+// does not fit L2 on this part (dev/gemv_pattern: 6.8 - 7.0).  A last-arriver fold inside the forward pass -- write-through
+// partial rows, a drained counter add per tile, the row tile's last tile summing it -- was built first and is gone:
+// 74 us for the pass instead of 60 + 4; 3 or 4 panel buffers instead of 2 change nothing, here and in symv_lower_*.)
 constexpr int kT1Panel = 4;  // forward pass: columns per load group (8: 144 VGPRs = 3 waves per SIMD = 12 tile slots per CU
                              // for 12.3 tiles per CU at n = 10^4: a second generation for the last 88 tiles)
 
@@ -290,83 +311,59 @@ __device__ __forceinline__ void t1_fma(double2_t yp, int co, const double2_t (&d
     a1 = __builtin_fma(d[k].y, yj, a1);
   }
 }
-template <bool NT>
+template <bool NT, int NBUF>
 __device__ __forceinline__ void t1_forward_tile(const double* __restrict__ Mr, double2_t yp, double& a0, double& a1) {
-  double2_t bufA[kT1Panel], bufB[kT1Panel];
-  t1_load<NT>(Mr, 0, bufA);
+  constexpr int kPanels = kSyTile / kT1Panel, kFull = (kPanels / NBUF) * NBUF;
+  double2_t buf[NBUF][kT1Panel];
+#pragma unroll
+  for (int b = 0; b + 1 < NBUF; ++b) t1_load<NT>(Mr, b * kT1Panel, buf[b]);
 #pragma unroll 1
-  for (int co = 0; co < kSyTile; co += 2 * kT1Panel) {
-    t1_load<NT>(Mr, co + kT1Panel, bufB);
-    t1_fma(yp, co, bufA, a0, a1);
-    if (co + 2 * kT1Panel < kSyTile) t1_load<NT>(Mr, co + 2 * kT1Panel, bufA);
-    t1_fma(yp, co + kT1Panel, bufB, a0, a1);
+  for (int g = 0; g < kFull; g += NBUF) {
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b) {  // (the ring of sy_tile)
+      const int nxt = g + b + NBUF - 1;
+      if (kFull + b - 1 < kPanels || nxt < kPanels) t1_load<NT>(Mr, nxt * kT1Panel, buf[(b + NBUF - 1) % NBUF]);
+      t1_fma(yp, (g + b) * kT1Panel, buf[b], a0, a1);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < kPanels - kFull; ++b) {
+    if (kFull + b + NBUF - 1 < kPanels) t1_load<NT>(Mr, (kFull + b + NBUF - 1) * kT1Panel, buf[(b + NBUF - 1) % NBUF]);
+    t1_fma(yp, (kFull + b) * kT1Panel, buf[b], a0, a1);
   }
 }
 
-__device__ __forceinline__ void tri1_forward_body(unsigned lin, const Tri1Args& a, bool stopped) {
+template <int NBUF>
+__device__ __forceinline__ void tri1_forward_body(unsigned lin, const Tri1Args& a) {
   unsigned bi, bj;
   tri_decode(lin, bi, bj);
   const int lane = threadIdx.x & 63;
   const int64_t gr = static_cast<int64_t>(bi) * kSyTile + 2 * lane;  // this lane's row pair
   double* __restrict__ po = a.npart + static_cast<int64_t>(bj) * a.ldp + gr;
-  if (!stopped) {
-    const double* __restrict__ Mr = a.X + static_cast<int64_t>(lin) * (kSyTile * kSyTile) + 2 * lane;
-    const int64_t e = static_cast<int64_t>(bj) * kSyTile + 2 * lane;  // the tile's input columns: pair (2l, 2l + 1)
-    double2_t yp{0.0, 0.0};  // (the caller's vector is only 8-byte aligned and not padded)
-    yp.x = a.y[e < a.n ? e : a.n - 1];
-    yp.y = a.y[e + 1 < a.n ? e + 1 : a.n - 1];
-    if (e >= a.n) yp.x = 0.0;
-    if (e + 1 >= a.n) yp.y = 0.0;
-    double a0 = 0.0, a1 = 0.0;
-    if (lin < a.ncached) t1_forward_tile<false>(Mr, yp, a0, a1);
-    else t1_forward_tile<true>(Mr, yp, a0, a1);
-    __hip_atomic_store(po, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
-    __hip_atomic_store(po + 1, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial row has left this wave before the counter says so
-  }
-  // A launch that finds the stop flag raised streams nothing, but it still arrives: the flag may be raised DURING this
-  // launch (the finalize passenger), and counters left half-way would poison the next run.  Whatever a stopped launch
-  // leaves in w is never used: every launch behind it starts with the flag raised.
-  int32_t old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(a.cnt + bi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = __builtin_amdgcn_readfirstlane(old);
-  if (old != static_cast<int32_t>(bi)) return;  // row tile bi has bi + 1 tiles
-  if (lane == 0) __hip_atomic_store(a.cnt + bi, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (stopped) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  constexpr int G = 16;
-  double s0 = 0.0, s1 = 0.0;
-  const double* __restrict__ pr = a.npart + gr;
-  const int32_t np = static_cast<int32_t>(bi) + 1;
-  for (int32_t q = 0; q < np; q += G) {
-    double v0[G], v1[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) {  // clamped: the loads of a group stay unconditional and go out together
-      const int32_t qq = (q + k < np) ? q + k : np - 1;
-      v0[k] = __hip_atomic_load(pr + static_cast<int64_t>(qq) * a.ldp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v1[k] = __hip_atomic_load(pr + static_cast<int64_t>(qq) * a.ldp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int k = 0; k < G; ++k)
-      if (q + k < np) {
-        s0 += v0[k];
-        s1 += v1[k];
-      }
-  }
-  *reinterpret_cast<double2_t*>(a.w + gr) = double2_t{s0, s1};  // w has npad entries (rows >= n: zero rows of X)
+  const double* __restrict__ Mr = a.X + static_cast<int64_t>(lin) * (kSyTile * kSyTile) + 2 * lane;
+  const int64_t e = static_cast<int64_t>(bj) * kSyTile + 2 * lane;  // the tile's input columns: pair (2l, 2l + 1)
+  double2_t yp{0.0, 0.0};  // (the caller's vector is only 8-byte aligned and not padded)
+  yp.x = a.y[e < a.n ? e : a.n - 1];
+  yp.y = a.y[e + 1 < a.n ? e + 1 : a.n - 1];
+  if (e >= a.n) yp.x = 0.0;
+  if (e + 1 >= a.n) yp.y = 0.0;
+  double a0 = 0.0, a1 = 0.0;
+  if (lin < a.ncached) t1_forward_tile<false, NBUF>(Mr, yp, a0, a1);
+  else t1_forward_tile<true, NBUF>(Mr, yp, a0, a1);
+  *reinterpret_cast<double2_t*>(po) = double2_t{a0, a1};
 }
 
 // workgroup 0 is the passenger of symv_lower_fin_kernel: the deferred finalize logic of the previous iteration
 __global__ __launch_bounds__(kWave) void tri1_forward_kernel(Tri1Args a, FinArgs f, int32_t fin_pending,
                                                              const Ctrl* __restrict__ ctrl) {
-  asm volatile("" ::"s"(a.X), "s"(a.n), "s"(a.npart), "s"(a.cnt), "s"(a.ldp), "s"(a.ncached), "s"(a.ntri),
-               "s"(fin_pending), "s"(ctrl));
-  const bool stopped = ctrl && ctrl->stop;
+  asm volatile("" ::"s"(a.X), "s"(a.n), "s"(a.npart), "s"(a.ldp), "s"(a.ncached), "s"(a.ntri), "s"(fin_pending),
+               "s"(ctrl));
+  if (ctrl && ctrl->stop) return;
   if (blockIdx.x == 0) {
-    if (fin_pending && !stopped) finalize_body<false, kWave>(f);
+    if (fin_pending) finalize_body<false, kWave>(f);
     return;
   }
-  tri1_forward_body(a.ntri - blockIdx.x, a, stopped);  // blockIdx 1 .. ntri -> tiles ntri - 1 .. 0
+  tri1_forward_body<2>(a.ntri - blockIdx.x, a);  // blockIdx 1 .. ntri -> tiles ntri - 1 .. 0
 }
 
 __global__ __launch_bounds__(kWave) void tri1_backward_kernel(Tri1Args a, const Ctrl* __restrict__ ctrl) {
@@ -416,10 +413,36 @@ __global__ __launch_bounds__(kBlock) void tri1_reduce_kernel(const double* __res
   }
 }
 
+// w[i] = sum_{p <= d} npart[p][i], d = i / 128
+__global__ __launch_bounds__(kBlock) void tri1_fold_kernel(const double* __restrict__ npart, int64_t ldp, int64_t npad,
+                                                           double* __restrict__ w, const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stop) return;
+  __shared__ double sacc[16][17];
+  const int ii = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 16 + ii;
+  double s = 0.0;
+  if (i < npad) {
+    const int32_t d = static_cast<int32_t>(i / kSyTile);
+#pragma unroll 4
+    for (int32_t p = slot; p <= d; p += 16) s += npart[static_cast<int64_t>(p) * ldp + i];
+  }
+  sacc[slot][ii] = s;
+  __syncthreads();
+  if (slot == 0 && i < npad) {
+    double t = sacc[0][ii];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sacc[k][ii];
+    w[i] = t;
+  }
+}
+
 void launch_tri1_forward(const Tri1Args& a, const FinArgs* fin, bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
   const FinArgs f = fin ? *fin : FinArgs{};
-  hipLaunchKernelGGL(tri1_forward_kernel, dim3(a.ntri + 1u), dim3(kWave), 0, stream, a, f,
-                     (fin && fin_pending) ? 1 : 0, ctrl);
+  hipLaunchKernelGGL(tri1_forward_kernel, dim3(a.ntri + 1u), dim3(kWave), 0, stream, a, f, (fin && fin_pending) ? 1 : 0,
+                     ctrl);
+  const int64_t npad = static_cast<int64_t>(a.ntile) * kSyTile;
+  hipLaunchKernelGGL(tri1_fold_kernel, dim3(static_cast<unsigned>(ceil_div(npad, int64_t{16}))), dim3(kBlock), 0, stream,
+                     a.npart, a.ldp, npad, a.w, ctrl);
 }
 void launch_tri1_backward(const Tri1Args& a, const Ctrl* ctrl, hipStream_t stream) {
   hipLaunchKernelGGL(tri1_backward_kernel, dim3(a.ntri), dim3(kWave), 0, stream, a, ctrl);
@@ -551,17 +574,18 @@ void launch_symv_lower_batch(const SymvPlan& p, const double* const* Ms_dev, int
                              const FinArgs* fin) {
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
   const FinArgs f = fin ? *fin : FinArgs{};
-  hipLaunchKernelGGL(symv_lower_batch_kernel, dim3(static_cast<unsigned>(symv_tiles(p)) + 1u, static_cast<unsigned>(K)),
-                     dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0, pstride, p.ldp, ncached, f,
-                     fin ? 1 : 0, ctrl);
+  const dim3 grid(static_cast<unsigned>(symv_tiles(p)) + 1u, static_cast<unsigned>(K));
+  hipLaunchKernelGGL(symv_lower_batch_kernel<2>, grid, dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0,
+                     pstride, p.ldp, ncached, f, fin ? 1 : 0, ctrl);
 }
 
 void launch_symv_lower_fin(const SymvPlan& p, const double* M, const double* x, double* npart, double* tpart,
                            const FinArgs& f, bool fin_pending, const Ctrl* ctrl, hipStream_t stream, int part_rank,
                            int part_count, double* y) {
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
-  hipLaunchKernelGGL(symv_lower_fin_kernel, dim3(static_cast<unsigned>(symv_tiles(p)) + 1u), dim3(kWave), 0, stream, M,
-                     p.n, x, npart, tpart, p.ldp, part_rank, part_count, ncached, f, fin_pending ? 1 : 0, ctrl);
+  const dim3 grid(static_cast<unsigned>(symv_tiles(p)) + 1u);
+  hipLaunchKernelGGL(symv_lower_fin_kernel<2>, grid, dim3(kWave), 0, stream, M, p.n, x, npart, tpart, p.ldp, part_rank,
+                     part_count, ncached, f, fin_pending ? 1 : 0, ctrl);
   if (!y) return;  // the consumer sums the partial rows itself
   const int64_t blocks = ceil_div(p.n, 16);
   hipLaunchKernelGGL(symv_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, npart, tpart,

@@ -540,7 +540,7 @@ int trsv_resolve_form(int64_t n, int form) {
 
 struct T1Geom {
   int64_t npad, ntile, ntri;
-  size_t x_elems, part_elems, w_elems, cnt_elems;
+  size_t x_elems, part_elems, w_elems;
 };
 static T1Geom t1_geom(int64_t n) {
   T1Geom g{};
@@ -550,14 +550,13 @@ static T1Geom t1_geom(int64_t n) {
   g.x_elems = static_cast<size_t>(g.ntri) * kTsTile * kTsTile;
   g.part_elems = static_cast<size_t>(g.ntile * g.npad);
   g.w_elems = static_cast<size_t>(g.npad);
-  g.cnt_elems = static_cast<size_t>(g.ntile / 2 + 2);  // int32 counters in double-sized slots
   return g;
 }
 
 size_t trsv_plan_elems(int64_t n, int form) {
-  if (trsv_resolve_form(n, form) == kTrsvOne) {
+  if (form == kTrsvOne && n >= 256) {
     const T1Geom g = t1_geom(n);
-    return g.x_elems + 2 * g.part_elems + g.w_elems + g.cnt_elems;
+    return g.x_elems + 2 * g.part_elems + g.w_elems;
   }
   const TsGeom g = ts_geom(n);
   return g.base_elems + g.pp_elems + g.bb_elems + g.sync_elems + g.item_elems + g.chunk_elems;
@@ -580,7 +579,6 @@ static int tri1_build(const double* L, int64_t n, int64_t ldl, const double* din
   p.np1 = p.X1 + g.x_elems;
   p.tp1 = p.np1 + g.part_elems;
   p.w1 = p.tp1 + g.part_elems;
-  p.cnt1 = reinterpret_cast<int32_t*>(p.w1 + g.w_elems);
   p.streaming = stream_hint(static_cast<int64_t>(g.x_elems) * 8);
   // ONE array serves both passes: the whole Infinity-Cache budget of symv.hip goes to its first tiles
   p.ncached = p.streaming ? static_cast<int64_t>(kSymvCacheBytes / (8 * kTsTile * kTsTile)) : INT64_MAX;
@@ -608,7 +606,6 @@ Tri1Args tri1_args(const TrsvPlan& p, const double* y) {
   a.npart = p.np1;
   a.tpart = p.tp1;
   a.w = p.w1;
-  a.cnt = p.cnt1;
   a.ldp = p.ldp;
   a.ncached = static_cast<uint32_t>(p.ncached > 0xffffffffLL ? 0xffffffffLL : (p.ncached < 0 ? 0 : p.ncached));
   a.ntile = p.ntile;
@@ -693,7 +690,7 @@ static void ts_work_list(const TsGeom& g, std::vector<TpItem>* items, std::vecto
 // `buf` must hold trsv_plan_elems(n) doubles and is owned by the caller.
 int trsv_build(const double* L, int64_t n, int64_t ldl, const double* dinv64, double* buf, TrsvPlan* plan,
                hipStream_t stream, int form) {
-  if (trsv_resolve_form(n, form) == kTrsvOne) return tri1_build(L, n, ldl, dinv64, buf, plan, stream);
+  if (form == kTrsvOne && n >= 256) return tri1_build(L, n, ldl, dinv64, buf, plan, stream);
   TrsvPlan& p = *plan;
   p = TrsvPlan{};
   p.n = n;

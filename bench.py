@@ -428,20 +428,28 @@ def side_engines(ap, L, a, dist, p, xs, local, comm, lo, hi, n, rho, world, out,
                                         "includes the residual-norm kernel"}
     lg.close()
 
-    # the same loop with the factor applied as the reference writes it, two triangular solves: blocked substitution
-    # over K = ceil(n/2048) coarse blocks, 2K + 1 bandwidth-bound launches per pair (trsv.hip)
+    # the same loop with the factor applied as the reference writes it, two triangular solves (trsv.hip): blocked
+    # substitution with pre-inverted diagonal blocks -- K = ceil(n/2048) coarse blocks, 2K + 1 launches per pair, or
+    # ONE block (the whole factor pre-inverted: two passes over inv(L), two launches) where the probe at create finds
+    # that form as accurate as the K-block one; both read 8 n(n+1) bytes per pair
     if world == 1:
         _leg("xsolve_trsv")
         lt = ap.Engine(L.PROB_LASSO, D=p["D"], s=p["s"], lam=p["lam"], rho=rho, xsolve=L.XSOLVE_TRSV, device=local)
+        ti = lt.info()
         kt = max(100, a.steps // 2)
         timed_run(lt, dist, 3, rho=rho)
         dtt, _ = timed_run(lt, dist, kt, rho=rho)
         out["xsolve_trsv"] = {"iters_per_s": kt / dtt, "ms_per_step": dtt / kt * 1e3,
                               "algorithmic_GB_per_iter": 8.0 * n * (n + 1) / 1e9,
                               "frac": 8.0 * n * (n + 1) * kt / dtt / 1e9 / HBM_PEAK_GBS,
-                              "trsv_blocks": lt.info()["trsv_blocks"],
-                              "note": "x = L'\\(L\\y) as getProxOps.m:1200 writes it (blocked substitution); same "
-                                      "iterates as the headline"}
+                              "trsv_blocks": ti["trsv_blocks"],
+                              "probe_err_one_block": ti["probe_err_trsv_one"],
+                              "probe_err_blocked": ti["probe_err_trsv"],
+                              "note": "x = L'\\(L\\y) as getProxOps.m:1200 writes it: blocked substitution with "
+                                      "pre-inverted diagonal blocks; trsv_blocks = 1: the whole factor is the one "
+                                      "block (w = inv(L) y, x = inv(L)' w: two passes over one tile-packed triangle), "
+                                      "kept because its probe error matches the K-block form's; same iterates as the "
+                                      "headline"}
         lt.close()
 
     # matrix-free lasso (xsolve = cg): same iterates as the cached-factor loop (inner tolerance

@@ -139,8 +139,8 @@ def test_trsv_pair_one_launch_form(gpu, n, monkeypatch):
 @pytest.mark.parametrize("n", [256, 300, 1000, 2049, 3333, 10000])
 def test_trsv_pair_one_block_form(gpu, n, monkeypatch):
     """the triangular solves with the whole factor as ONE pre-inverted block (symv.hip: tri1_*): w = X y by the N-part
-    pass with a last-arriver fold per row tile, x = X' w by the T-part pass + reduce; against LAPACK's substitution,
-    against the blocked form, and twice in a row (the arrival counters must be back at zero; fixed-order sums)"""
+    pass + fold, x = X' w by the T-part pass + reduce; against LAPACK's substitution, against the blocked form, and
+    twice in a row (fixed-order sums: bitwise the same)"""
     rng = np.random.default_rng(n + 7)
     G = rng.standard_normal((n + 20, n)) / np.sqrt(n + 20)
     Lf = np.asfortranarray(sla.cholesky(G.T @ G + np.eye(n), lower=True))

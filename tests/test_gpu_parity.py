@@ -361,7 +361,7 @@ def test_factor_guard_rejects_a_bad_inverse(gpu):
 def test_lasso_through_the_one_block_triangular_solves(gpu, rows, cols, seed, opts, monkeypatch):
     """xsolve = trsv with the whole factor as ONE pre-inverted block (two passes over inv(L), symv.hip: tri1_*): the
     forward pass carries the deferred finalize, the element update sums the backward pass's partial rows -- every loop
-    variant against the oracle's LAPACK substitution; the arrival counters survive early stops and batch ends"""
+    variant against the oracle's LAPACK substitution, through early stops and batch ends"""
     monkeypatch.setenv("ADMM_TRSV_FORM", "one")
     p = gpu.synth.lasso_problem(seed, rows, cols)
     got = gpu.lasso(p["D"], p["s"], p["lam"], dict(opts, xsolve="trsv"))
