@@ -26,6 +26,11 @@ void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables&
 // ... with one extra workgroup that runs the finalize logic `f` of the previous iteration (when fin_pending)
 void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
                                  bool fin_pending, const Ctrl* ctrl, hipStream_t stream);
+// the fused 2-D TV pass (tv2d.h: launch_tv2d_fused) whose right-hand side goes straight into the forward column
+// transform: bhat (H x W) receives the DCT-II of every column of b = s + rho*D'(z+ - u+); a.W even, a.H = th.n
+struct Tv2Args;
+void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const DctTables& th, const Ctrl* ctrl,
+                           int* nblk_out, hipStream_t stream);
 // inverse of the above (DCT-III with the 1/H factor): src -> dst (may alias)
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream);
@@ -41,8 +46,9 @@ void launch_dct_rows_solve_strided(double* img, int64_t H, int64_t W, double rho
 // column-major, the column-transformed image), as the truncated Toeplitz kernel on the mirrored row (dct.hip);
 // src != dst.  tv2d_rows_green_taps(rho) = terms per side; usable while that is well below W.
 int tv2d_rows_green_taps(double rho);
+// fin != nullptr: one extra workgroup runs the finalize logic `*fin` of the previous iteration (when fin_pending)
 void launch_tv2d_rows_green(const double* src, double* dst, int64_t H, int64_t W, double rho, const DctTables& th,
-                            const Ctrl* ctrl, hipStream_t stream);
+                            const Ctrl* ctrl, hipStream_t stream, const FinArgs* fin = nullptr, bool fin_pending = false);
 // dst (cols x rows, column-major) = src (rows x cols, column-major) transposed
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
                       hipStream_t stream);

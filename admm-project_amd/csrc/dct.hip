@@ -12,6 +12,7 @@
 #include "dct.h"
 #include "finalize_device.h"
 #include "kernels.h"
+#include "tv2d_pixel.h"
 
 namespace admm {
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void fft_network(c64* zs, int n, int log2n, const c64
 
 // (a, b) -> LDS in Makhoul order: x[2i] -> v[i], x[2i+1] -> v[n-1-i], one 16-byte load per column and thread
 __device__ __forceinline__ void load_pair(c64* zs, const double* a, const double* b, int n) {
-#pragma unroll 4
+#pragma unroll 8
   for (int i = threadIdx.x; i < (n >> 1); i += blockDim.x) {
     const admm_double2 va = load2<false>(a + 2 * i), vb = load2<false>(b + 2 * i);
     zs[swz(i)] = c64{va.x, vb.x};
@@ -146,17 +147,32 @@ __device__ __forceinline__ void dct_to_spectrum(double xak, double xan, double x
   zn = c64{va.x + vb.y, vb.x - va.y};
 }
 
+// block partials of the S_COUNT sums of a 4-wave workgroup -> part[s][blockIdx.x]
+__device__ __forceinline__ void tv2_block_partials_lds(const double (&acc)[S_COUNT], double* __restrict__ part) {
+  __shared__ double sred[kBlock / kWave][S_COUNT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) {
+    const double w = wave_sum(acc[s]);
+    if (lane == 0) sred[wid][s] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    const int s = threadIdx.x;
+    double tot = sred[0][s];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) tot += sred[w][s];
+    part[s * kMaxPartBlocks + blockIdx.x] = tot;
+  }
+}
+
 constexpr double kSqrtHalf = 0.70710678118654752440;
 constexpr double kSqrt2 = 1.41421356237309504880;
 
-__device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, int64_t H, const DctTables& t,
-                                                      unsigned pair) {
-  extern __shared__ c64 zs[];
+// zs holds the pair (a, b) in Makhoul order (callers synchronise before): FFT, then the DCT-II coefficients to a, b
+__device__ __forceinline__ void dct_forward_from_lds(c64* zs, double* __restrict__ a, double* __restrict__ b,
+                                                     const DctTables& t) {
   const int n = t.n, p = t.log2n;
-  double* a = img + static_cast<int64_t>(2 * pair) * H;
-  double* b = a + H;
-  load_pair(zs, a, b, n);
-  __syncthreads();
   fft_network<false>(zs, n, p, t.tw);
 #pragma unroll 2
   for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
@@ -176,6 +192,71 @@ __device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, 
       b[n - k] = xbn;
     }
   }
+}
+
+__device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, int64_t H, const DctTables& t,
+                                                      unsigned pair) {
+  extern __shared__ c64 zs[];
+  double* a = img + static_cast<int64_t>(2 * pair) * H;
+  double* b = a + H;
+  load_pair(zs, a, b, t.n);
+  __syncthreads();
+  dct_forward_from_lds(zs, a, b, t);
+}
+
+// ---------------------------------------------------------------- fused 2-D TV pass -> forward column transform
+// The fused pass (tv2d.hip) ends in the next x-update's right-hand side b, and the x-update begins with the column DCT
+// of b: here b never reaches memory.  A workgroup owns column pairs; for a pair it runs the pixel update of both columns
+// (tv2d_pixel.h: the same arithmetic; x, v, s from global memory, the neighbours' reads are cache hits), drops b into
+// the FFT's LDS image at its Makhoul position, transforms, and stores the coefficients where the row stage expects
+// them.  Against the two kernels it replaces: one write and one read of the image less per iteration (11 N doubles
+// instead of 13 N), one launch less.
+template <bool VIN>
+__global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, double* __restrict__ bhat, DctTables t,
+                                                                const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int64_t it = ctrl->iter;
+  const int64_t H = a.H, W = a.W, N = H * W;
+  const int n = t.n;  // == H
+  const uint32_t tid = threadIdx.x;
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  const int64_t npairs = W >> 1;
+  for (int64_t pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int64_t j0 = 2 * pair;
+    for (int64_t row0 = 0; row0 < H; row0 += kBlock) {
+      const int64_t i = row0 + tid;
+      if (i < H) {
+        const bool hasv = i < H - 1, up = i > 0;
+        const uint32_t o_up = up ? tid : tid + 1;  // relative to the element before the chunk: own row when there is none
+        const uint32_t o_dn = hasv ? tid + 1 : tid;
+        Tv2Px px[2];
+        int64_t base[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {  // both columns' loads before either update
+          const int64_t j = j0 + c;
+          base[c] = j * H + row0;
+          const int64_t lbase = j > 0 ? base[c] - H : base[c], rbase = j < W - 1 ? base[c] + H : base[c];
+          tv2px_load<VIN>(a, N, base[c], lbase, rbase, tid, o_up, o_dn, px[c]);
+        }
+        const int k = static_cast<int>(i >> 1);
+        const int pos = swz((i & 1) ? n - 1 - k : k);  // Makhoul order: x[2k] -> v[k], x[2k+1] -> v[n-1-k]
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int64_t j = j0 + c;
+          const double bv = tv2px_apply<VIN>(a, N, it, base[c], tid, hasv, up, j < W - 1, j > 0, px[c], acc);
+          reinterpret_cast<double*>(&zs[pos])[c] = bv;
+        }
+      }
+    }
+    __syncthreads();
+    double* ca = bhat + j0 * H;
+    dct_forward_from_lds(zs, ca, ca + H, t);
+    __syncthreads();  // zs is the next pair's
+  }
+  tv2_block_partials_lds(acc, a.part);
 }
 
 __global__ __launch_bounds__(kBlock) void dct_cols_forward_kernel(double* __restrict__ img, int64_t H, DctTables t,
@@ -207,17 +288,37 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   const int n = t.n, p = t.log2n;
   const double* a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
   const double* b = a + H;
-#pragma unroll 2
-  for (int k = threadIdx.x; k <= (n >> 1); k += blockDim.x) {
-    if (k == 0) {
-      zs[0] = c64{a[0], b[0]};
-    } else if (k == (n >> 1)) {
-      zs[1] = c64{kSqrt2 * a[k], kSqrt2 * b[k]};
-    } else {
-      c64 zk, zn;
-      dct_to_spectrum(a[k], a[n - k], b[k], b[n - k], t.c4[k], zk, zn);
-      zs[swz(bitrev(k, p))] = zk;
-      zs[swz(bitrev(n - k, p))] = zn;
+  // coefficient pairs (k, n - k), 0 <= k < n/2: kInvQ of them per thread and round, every load of a round issued before
+  // any is used (clamped indices, no branches around loads: with the loads inside the three cases of the loop body the
+  // kernel fetched two pairs per round trip -- four dependent trips for a 4096-point column pair)
+  constexpr int kInvQ = 8;
+  const int half = n >> 1;
+  for (int k0 = threadIdx.x; k0 < half; k0 += kInvQ * blockDim.x) {
+    double ak[kInvQ], an[kInvQ], bk[kInvQ], bn[kInvQ];
+    c64 ck[kInvQ];
+#pragma unroll
+    for (int q = 0; q < kInvQ; ++q) {
+      const int k = k0 + q * static_cast<int>(blockDim.x);
+      const int kc = k < half ? k : half - 1, nk = kc == 0 ? half : n - kc;  // (k = 0 pairs with n/2: the two special ones)
+      ak[q] = a[kc];
+      an[q] = a[nk];
+      bk[q] = b[kc];
+      bn[q] = b[nk];
+      ck[q] = t.c4[kc];
+    }
+#pragma unroll
+    for (int q = 0; q < kInvQ; ++q) {
+      const int k = k0 + q * static_cast<int>(blockDim.x);
+      if (k >= half) continue;
+      if (k == 0) {
+        zs[0] = c64{ak[q], bk[q]};
+        zs[1] = c64{kSqrt2 * an[q], kSqrt2 * bn[q]};  // k = n/2 (bitrev(n/2) = 1)
+      } else {
+        c64 zk, zn;
+        dct_to_spectrum(ak[q], an[q], bk[q], bn[q], ck[q], zk, zn);
+        zs[swz(bitrev(k, p))] = zk;
+        zs[swz(bitrev(n - k, p))] = zn;
+      }
     }
   }
   __syncthreads();
@@ -384,6 +485,21 @@ void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables&
                      stream, img, H, th, ctrl);
 }
 
+void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const DctTables& th, const Ctrl* ctrl,
+                           int* nblk_out, hipStream_t stream) {
+  int64_t nb = a.W / 2;
+  if (nb > kMaxPartBlocks) nb = kMaxPartBlocks;  // (a workgroup then walks several pairs: one set of partials each)
+  *nblk_out = static_cast<int>(nb);
+  const size_t lds = dct_lds_bytes(th.n);
+  if (state_in) {
+    dct_allow_lds(tv2d_fused_dct_kernel<true>, lds);
+    hipLaunchKernelGGL(tv2d_fused_dct_kernel<true>, dim3(static_cast<unsigned>(nb)), dim3(kBlock), lds, stream, a, bhat, th, ctrl);
+  } else {
+    dct_allow_lds(tv2d_fused_dct_kernel<false>, lds);
+    hipLaunchKernelGGL(tv2d_fused_dct_kernel<false>, dim3(static_cast<unsigned>(nb)), dim3(kBlock), lds, stream, a, bhat, th, ctrl);
+  }
+}
+
 void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
                                  bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
   dct_allow_lds(dct_cols_forward_fin_kernel, dct_lds_bytes(th.n));
@@ -428,13 +544,23 @@ constexpr int kRowRun = 32;   // columns whose causal sums a lane keeps in regis
 constexpr int kRowRuns = 4;   // consecutive runs per wave: the causal recurrence carries over, and the K columns a run
                               // looks ahead are the next run's own columns (cache hits): ~1.7x instead of 3.6x reads
 
+// FIN: one more column of workgroups in front (blockIdx.x == 0); its first one is a passenger that runs the finalize
+// logic of the PREVIOUS iteration while the others work (as dct_cols_forward_fin_kernel does when the iteration begins
+// with the column transform).  Nothing in this launch depends on that decision, and dst is a scratch image here: the
+// launches behind it -- the inverse transform into x, the fused pass -- no-op when it has raised ctrl->stop.
+template <bool FIN>
 __global__ __launch_bounds__(kBlock, 2) void tv2d_rows_green_kernel(const double* __restrict__ src,
                                                                     double* __restrict__ dst, int64_t H, int64_t W,
                                                                     double rho, const double* __restrict__ lamH, int K,
+                                                                    FinArgs f, int32_t fin_pending,
                                                                     const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
+  if (FIN && blockIdx.x == 0) {
+    if (blockIdx.y == 0 && fin_pending) finalize_body<false>(f);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+  const int64_t i = static_cast<int64_t>(blockIdx.x - (FIN ? 1u : 0u)) * 64 + lane;
   const int64_t jseg = (static_cast<int64_t>(blockIdx.y) * 4 + wave) * (kRowRun * kRowRuns);
   if (jseg >= W) return;  // wave-uniform
   const int64_t ic = i < H ? i : H - 1;
@@ -510,6 +636,105 @@ __global__ __launch_bounds__(kBlock, 2) void tv2d_rows_green_kernel(const double
   }
 }
 
+// The same row stage with the waves of a workgroup working together (default when the truncation fits 64 columns).
+// In the kernel above a wave pays for its two carries with K-term Horner sums over its neighbours' columns: 2.1 x the
+// image in reads (PMC).  Here a workgroup is 16 waves on the SAME 64 rows, wave q holding the 32-column run q in
+// registers from its loads to its stores:
+//   local sums   S_q = sum_t r^(31-t) b_t   (what the run hands to the right),  P_q = sum_t r^t b_t   (... to the left)
+//   carries      c(j_q0 - 1) = S_(q-1) + r^32 S_(q-2),   a(j_q31) = r (P_(q+1) + r^32 P_(q+2))      (r^64 < 1e-18)
+// through 16 KB of LDS and one barrier; waves 0, 1 and 14, 15 hold the halo runs left and right of the 384 output
+// columns (mirror images at the ends of the row; columns farther than the block's own truncation K are not loaded),
+// so the halo costs 2K / 384 of the image instead of 2K / 128 + 32/32.  The second pass runs the two first-order
+// recurrences from the exact carries; c_t overwrites b_t and the anticausal pass takes b_(t+1) = c_(t+1) - r c_t
+// (one rounding of size eps |b| / (1 - r): a second 32-double array would halve the occupancy).
+constexpr int kCoopRun = 32, kCoopWaves = 16, kCoopHalo = 2, kCoopOut = kCoopWaves - 2 * kCoopHalo;
+
+template <bool FIN>
+__global__ __launch_bounds__(kCoopWaves* kWave) void tv2d_rows_coop_kernel(const double* __restrict__ src,
+                                                                          double* __restrict__ dst, int64_t H, int64_t W,
+                                                                          double rho, const double* __restrict__ lamH,
+                                                                          int K, FinArgs f, int32_t fin_pending,
+                                                                          const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  if (FIN && blockIdx.x == 0) {
+    if (blockIdx.y == 0 && fin_pending && threadIdx.x < kBlock) finalize_body<false>(f);
+    return;
+  }
+  __shared__ double Ssh[kCoopWaves][kWave], Psh[kCoopWaves][kWave];
+  const int lane = threadIdx.x & 63;
+  const int q = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));  // (scalar: the column addresses are)
+  const int64_t i = static_cast<int64_t>(blockIdx.x - (FIN ? 1u : 0u)) * 64 + lane;
+  const int64_t ic = i < H ? i : H - 1;
+  const double d = 1.0 + rho * (lamH[ic] + 2.0);
+  const double disc = sqrt(d * d - 4.0 * rho * rho);
+  const double r = 2.0 * rho / (d + disc), A = 1.0 / disc;
+  {  // the block's own truncation, from the largest ratio among its 64 rows (K: the host's bound, from r_0)
+    double rmax = r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, off, 64));
+    const int kw = static_cast<int>(-41.4465316738928 / log(rmax)) + 2;  // ln(1e-18)
+    K = __builtin_amdgcn_readfirstlane(kw < K ? kw : K);
+  }
+  const int64_t Jout = static_cast<int64_t>(blockIdx.y) * (kCoopOut * kCoopRun);  // first output column of the workgroup
+  const int64_t Jend = Jout + kCoopOut * kCoopRun;                                 // one past its last
+  const int64_t j0 = Jout + static_cast<int64_t>(q - kCoopHalo) * kCoopRun;        // this wave's first column (may be < 0)
+  const double* __restrict__ row = src + ic;
+  double bs[kCoopRun];
+#pragma unroll
+  for (int t = 0; t < kCoopRun; ++t) {
+    int64_t j = j0 + t;
+    // halo columns beyond the truncation are not needed: re-read the nearest needed one (a cache hit), count as zero
+    bool need = true;
+    if (j < Jout - K) {
+      j = Jout - K;
+      need = false;
+    }
+    if (j >= Jend + K) {
+      j = Jend + K - 1;
+      need = false;
+    }
+    if (j >= 2 * W) {  // (beyond the mirror image of the row: only in halo runs right of a short last block)
+      j = 2 * W - 1;
+      need = false;
+    }
+    const int64_t jm = j < 0 ? -1 - j : (j >= W ? 2 * W - 1 - j : j);  // mirrored column (K < W)
+    const double v = row[jm * H];
+    bs[t] = need ? v : 0.0;
+  }
+  double S = 0.0, P = 0.0;
+#pragma unroll
+  for (int t = 0; t < kCoopRun; ++t) S = __builtin_fma(r, S, bs[t]);
+#pragma unroll
+  for (int t = kCoopRun - 1; t >= 0; --t) P = __builtin_fma(r, P, bs[t]);
+  Ssh[q][lane] = S;
+  Psh[q][lane] = P;
+  __syncthreads();
+  if (q < kCoopHalo || q >= kCoopWaves - kCoopHalo || j0 >= W) return;  // halo runs; runs right of the image
+  double r32 = r * r;  // r^2
+  r32 *= r32;          // r^4
+  r32 *= r32;          // r^8
+  r32 *= r32;          // r^16
+  r32 *= r32;          // r^32
+  double c = __builtin_fma(r32, Ssh[q - 2][lane], Ssh[q - 1][lane]);
+  double a = r * __builtin_fma(r32, Psh[q + 2][lane], Psh[q + 1][lane]);
+#pragma unroll
+  for (int t = 0; t < kCoopRun; ++t) {
+    c = __builtin_fma(r, c, bs[t]);
+    bs[t] = c;
+  }
+  const bool rowok = i < H;
+#pragma unroll
+  for (int t = kCoopRun - 1; t >= 0; --t) {
+    if (rowok && j0 + t < W) dst[i + (j0 + t) * H] = A * (bs[t] + a);
+    if (t > 0) a = r * (a + (bs[t] - r * bs[t - 1]));
+  }
+}
+
+// the cooperative form covers truncations up to its two halo runs
+static bool tv2d_rows_coop_ok(int taps, int64_t W) {
+  return taps <= kCoopHalo * kCoopRun && W >= kCoopOut * kCoopRun && std::getenv("ADMM_HIP_TV2D_ROWS_WAVE") == nullptr;
+}
+
 int tv2d_rows_green_taps(double rho) {
   const double d0 = 1.0 + 2.0 * rho;
   const double r0 = 2.0 * rho / (d0 + std::sqrt(d0 * d0 - 4.0 * rho * rho));
@@ -517,10 +742,25 @@ int tv2d_rows_green_taps(double rho) {
 }
 
 void launch_tv2d_rows_green(const double* src, double* dst, int64_t H, int64_t W, double rho, const DctTables& th,
-                            const Ctrl* ctrl, hipStream_t stream) {
-  const dim3 grid(static_cast<unsigned>(ceil_div(H, int64_t{64})), static_cast<unsigned>(ceil_div(W, int64_t{4 * kRowRun * kRowRuns})));
-  hipLaunchKernelGGL(tv2d_rows_green_kernel, grid, dim3(kBlock), 0, stream, src, dst, H, W, rho, th.lam,
-                     tv2d_rows_green_taps(rho), ctrl);
+                            const Ctrl* ctrl, hipStream_t stream, const FinArgs* fin, bool fin_pending) {
+  const int taps = tv2d_rows_green_taps(rho);
+  if (tv2d_rows_coop_ok(taps, W)) {
+    const unsigned cx = static_cast<unsigned>(ceil_div(H, int64_t{64})), cy = static_cast<unsigned>(ceil_div(W, int64_t{kCoopOut * kCoopRun}));
+    if (fin)
+      hipLaunchKernelGGL(tv2d_rows_coop_kernel<true>, dim3(cx + 1u, cy), dim3(kCoopWaves * kWave), 0, stream, src, dst, H, W,
+                         rho, th.lam, taps, *fin, fin_pending ? 1 : 0, ctrl);
+    else
+      hipLaunchKernelGGL(tv2d_rows_coop_kernel<false>, dim3(cx, cy), dim3(kCoopWaves * kWave), 0, stream, src, dst, H, W, rho,
+                         th.lam, taps, FinArgs{}, 0, ctrl);
+    return;
+  }
+  const unsigned gx = static_cast<unsigned>(ceil_div(H, int64_t{64})), gy = static_cast<unsigned>(ceil_div(W, int64_t{4 * kRowRun * kRowRuns}));
+  if (fin)
+    hipLaunchKernelGGL(tv2d_rows_green_kernel<true>, dim3(gx + 1u, gy), dim3(kBlock), 0, stream, src, dst, H, W, rho, th.lam,
+                       tv2d_rows_green_taps(rho), *fin, fin_pending ? 1 : 0, ctrl);
+  else
+    hipLaunchKernelGGL(tv2d_rows_green_kernel<false>, dim3(gx, gy), dim3(kBlock), 0, stream, src, dst, H, W, rho, th.lam,
+                       tv2d_rows_green_taps(rho), FinArgs{}, 0, ctrl);
 }
 
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,

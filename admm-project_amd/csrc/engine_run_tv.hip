@@ -64,15 +64,19 @@ static bool tv2d_rows_green_ok(const admm_engine* e, double rho) {
   return taps <= 96 && e->tv2_W >= 4 * taps;
 }
 
+// ... and it is the form dct_solve_tv2d takes by default (no environment override asks for a row transform)
+static bool tv2d_rows_green_default(const admm_engine* e, double rho) {
+  return tv2d_rows_green_ok(e, rho) && (!e->tv2_rows_dct || (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
+                                                            std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr));
+}
+
 // fin != nullptr: the forward transform's launch carries the finalize logic of the previous iteration (when pending)
 static int dct_solve_tv2d(admm_engine* e, double* y, const FinArgs* fin = nullptr, bool fin_pending = false) {
   TimerScope ts(e, ADMM_K_XSOLVE);
   const int64_t H = e->tv2_H, W = e->tv2_W;
   if (fin) launch_dct_cols_forward_fin(y, H, W, e->dctH, *fin, fin_pending, e->ctrl, e->stream);
   else launch_dct_cols_forward(y, H, W, e->dctH, e->ctrl, e->stream);            // along i, in place
-  if (tv2d_rows_green_ok(e, e->last_opts.rho) &&
-      (!e->tv2_rows_dct || (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
-                            std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr))) {
+  if (tv2d_rows_green_default(e, e->last_opts.rho)) {
     // default: no row transform at all -- the exact Toeplitz kernel of the row operator on the mirrored row (dct.hip)
     launch_tv2d_rows_green(y, e->x, H, W, e->last_opts.rho, e->dctH, e->ctrl, e->stream);
     launch_dct_cols_inverse(e->x, e->x, H, W, e->dctH, e->ctrl, e->stream);
@@ -210,6 +214,12 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   // (dct_cols_forward_fin_kernel); a batch's last iteration gets the stand-alone launch.  A stop it raises turns the
   // rest of iteration i + 1 into no-ops -- only the in-place transform of the right-hand side has run by then.
   const bool tv2_defer = spectral && std::getenv("ADMM_HIP_NO_DEFERRED_FINALIZE") == nullptr;
+  // Default spectral form ("glued"): the fused pass hands its right-hand side to the forward column transform inside
+  // one kernel (dct.hip: tv2d_fused_dct_kernel), so e->rhs holds the TRANSFORMED right-hand side from one iteration to
+  // the next and an iteration is three launches: row stage (+ the previous iteration's finalize as a passenger) into the
+  // scratch image e->cg_r, inverse column transform into x, fused pass + forward transform.  (The row stage writes a
+  // scratch image, not x: it is the launch that carries the passenger, so it still runs when the passenger raises stop.)
+  const bool tv2_glued = spectral && tv2d_rows_green_default(e, o.rho) && std::getenv("ADMM_HIP_TV2D_NO_GLUE") == nullptr;
   bool tv2_pending = false;
   while (alg == 0 && done < N && !stop_seen) {
     double* const vbuf[2] = {e->tv_zB, e->tv_uB};
@@ -219,13 +229,24 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
     if (done == 0) {  // later right-hand sides come out of the fused z/u pass of the previous iteration
       TimerScope ts(e, ADMM_K_XSOLVE);
       launch_tv2d_rhs(ta, e->rhs, e->ctrl, e->stream);
+      if (tv2_glued) launch_dct_cols_forward(e->rhs, ta.H, ta.W, e->dctH, e->ctrl, e->stream);
     }
-    // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
-    if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs, tv2_defer ? &fa : nullptr, tv2_pending));
-    else ADMM_TRY(cg_solve(e, e->rhs));
-    tv2_pending = false;
     int nblk = 1;
-    {
+    if (tv2_glued) {
+      {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        launch_tv2d_rows_green(e->rhs, e->cg_r, ta.H, ta.W, o.rho, e->dctH, e->ctrl, e->stream, tv2_defer ? &fa : nullptr,
+                               tv2_pending);
+        launch_dct_cols_inverse(e->cg_r, e->x, ta.H, ta.W, e->dctH, e->ctrl, e->stream);
+      }
+      tv2_pending = false;
+      TimerScope ts(e, ADMM_K_PROX);
+      launch_tv2d_fused_dct(ta, done > 0, e->rhs, e->dctH, e->ctrl, &nblk, e->stream);
+    } else {
+      // (I + rho*D'D) x = s + rho*D'(z - u): spectral, or warm-started CG (polls the device)
+      if (spectral) ADMM_TRY(dct_solve_tv2d(e, e->rhs, tv2_defer ? &fa : nullptr, tv2_pending));
+      else ADMM_TRY(cg_solve(e, e->rhs));
+      tv2_pending = false;
       TimerScope ts(e, ADMM_K_PROX);
       launch_tv2d_fused(ta, done > 0, e->rhs, e->ctrl, &nblk, e->stream);
     }

@@ -122,6 +122,38 @@ def test_tv2d_compact_state_with_arbitrary_start(gpu, H, W, iters):
             _close(k, got[k], ref[k], 1e-7)
 
 
+@pytest.mark.parametrize("H,W,opts", [(64, 200, dict(objevals=1, maxiters=30, domaxiters=1)),
+                                      (1024, 640, dict(objevals=1, maxiters=19, domaxiters=1)),
+                                      (256, 256, dict(objevals=1, stopcond="both", maxiters=200)),       # stops early
+                                      (128, 512, dict(maxiters=21, domaxiters=1, record_history=0)),
+                                      (512, 384, dict(objevals=1, rho=2.0, maxiters=12, domaxiters=1)),
+                                      (8192, 192, dict(objevals=1, maxiters=5, domaxiters=1))])          # 128 KB of LDS
+def test_tv2d_fused_pass_into_the_forward_transform(gpu, H, W, opts, monkeypatch):
+    """default spectral form: the fused pass hands its right-hand side to the forward column DCT inside one kernel
+    (dct.hip: tv2d_fused_dct_kernel; three launches per iteration, the row stage carries the deferred finalize) --
+    the same arithmetic per pixel as the four-launch form (ADMM_HIP_TV2D_NO_GLUE=1): the same iterates bit for bit"""
+    img = _image(3 * H + W, H, W)
+    got = gpu.totalvariation2d(img, 0.45, dict(opts))
+    monkeypatch.setenv("ADMM_HIP_TV2D_NO_GLUE", "1")
+    old = gpu.totalvariation2d(img, 0.45, dict(opts))
+    assert got["steps"] == old["steps"] and got["cg_iters_total"] == 0
+    keys = ["xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr"]
+    if opts.get("record_history", 1):
+        keys += ["xvals", "zvals", "uvals"]
+    if opts.get("objevals"):
+        keys += ["objevals"]
+    for k in keys:
+        if k in ("xopt", "zopt", "uopt", "xvals", "zvals", "uvals"):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(old[k])), k
+        else:  # sums over the image: the two kernels cut it into different blocks
+            np.testing.assert_allclose(np.asarray(got[k]), np.asarray(old[k]), rtol=1e-12, atol=0, err_msg=k)
+    if H * W <= 1 << 18:
+        ref = S.totalvariation2d(img, 0.45, {k: v for k, v in opts.items() if k != "record_history"})
+        assert got["steps"] == ref["steps"]
+        for k in ("xopt", "zopt", "uopt", "pnorm", "dnorm"):
+            _close(k, got[k], ref[k], 1e-8)
+
+
 def test_tv2d_relaxation_is_a_dimension_error(gpu):
     with pytest.raises(Exception, match="dimension error"):
         gpu.totalvariation2d(_image(3, 16, 16), 0.5, dict(relax=1.5))
