@@ -328,79 +328,10 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   store_pair(zs, oa, oa + H, n, 1.0 / static_cast<double>(n));
 }
 
-// ---------------------------------------------------------------- ONE real column per workgroup, half-size transform
-// A real sequence of length n needs only an n/2-point complex FFT: with v the Makhoul permutation of the column,
-// z[m] = v[2m] + i v[2m+1] and Z = FFT_(n/2)(z),
-//   V[k] = (Z[k] + conj Z[n/2-k])/2 - i e^(-2 pi i k/n) (Z[k] - conj Z[n/2-k])/2,   k = 0 .. n/2   (Z[n/2] = Z[0]),
-// is the n-point spectrum of v the DCT rotation wants -- and backwards.  In x itself: the four consecutive samples
-// x[4m .. 4m+3] are z[m] = (x[4m], x[4m+2]) and z[n/2-1-m] = (x[4m+3], x[4m+1]).  Half the LDS of the two-column form
-// (32 KB at n = 4096): four workgroups per CU instead of two take turns in the load / transform / store phases.
-constexpr int kHalfThreads = 128;
-
-__global__ __launch_bounds__(kHalfThreads) void dct_col_inverse_half_kernel(const double* __restrict__ src,
-                                                                            double* __restrict__ dst, int64_t H,
-                                                                            DctTables t, const Ctrl* __restrict__ ctrl) {
-  if (ctrl->stop) return;
-  extern __shared__ c64 zs[];
-  const int n = t.n, h = n >> 1, q4 = n >> 2, ph = t.log2n - 1;
-  const double* __restrict__ X = src + static_cast<int64_t>(blockIdx.x) * H;
-  // coefficient quadruples (k, n-k, h-k, h+k), 0 <= k <= n/4 -> Z[k], Z[h-k] at their bit-reversed places; every load of
-  // a round before any use, clamped indices instead of branches around loads
-  constexpr int kQ = 8;
-  for (int k0 = threadIdx.x; k0 <= q4; k0 += kQ * kHalfThreads) {
-    double xk[kQ], xnk[kQ], xhk[kQ], xhpk[kQ];
-    c64 ck[kQ], chk[kQ], wk[kQ];
-#pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-      const int k = k0 + q * kHalfThreads;
-      const int kc = k <= q4 ? k : q4;
-      xk[q] = X[kc];
-      xnk[q] = X[kc == 0 ? 0 : n - kc];
-      xhk[q] = X[h - kc];
-      xhpk[q] = X[kc == 0 ? h : h + kc];
-      ck[q] = t.c4[kc];
-      chk[q] = t.c4[h - kc];
-      wk[q] = t.tw[kc];  // e^{-2 pi i k / n}, k <= n/4 < n/2
-    }
-#pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-      const int k = k0 + q * kHalfThreads;
-      if (k > q4) continue;
-      // V[k] = e^{+i pi k/(2n)} (X[k] - i X[n-k]) (0 < k < n/2), V[0] = X[0], V[n/2] = sqrt(2) X[n/2]
-      c64 Vk, Vh;
-      if (k == 0) {
-        Vk = c64{xk[q], 0.0};
-        Vh = c64{kSqrt2 * xhk[q], 0.0};
-      } else {
-        Vk = cmulc(c64{xk[q], -xnk[q]}, ck[q]);
-        Vh = cmulc(c64{xhk[q], -xhpk[q]}, chk[q]);
-      }
-      // Z[k] = (V[k] + conj V[h-k]) + i e^{+2 pi i k/n} (V[k] - conj V[h-k])   (twice the textbook value: folded into the
-      // final scale), and Z[h-k] = conj of the same with the roles exchanged
-      const c64 sum = c64{Vk.x + Vh.x, Vk.y - Vh.y}, dif = c64{Vk.x - Vh.x, Vk.y + Vh.y};
-      const c64 rot = cmulc(dif, wk[q]);  // e^{+2 pi i k/n} (V[k] - conj V[h-k])
-      const c64 Zk = c64{sum.x - rot.y, sum.y + rot.x};
-      if (k == 0) {
-        zs[0] = Zk;
-      } else {
-        // Z[h-k] = (V[h-k] + conj V[k]) + i e^{2 pi i (h-k)/n} (V[h-k] - conj V[k]),  e^{2 pi i (h-k)/n} = -conj(e^{2 pi i k/n})
-        const c64 Zh = c64{sum.x + rot.y, -sum.y + rot.x};
-        zs[swz(bitrev(k, ph))] = Zk;
-        if (k != q4) zs[swz(bitrev(h - k, ph))] = Zh;
-      }
-    }
-  }
-  __syncthreads();
-  fft_network<true>(zs, h, ph, t.tw, 1);
-  double* __restrict__ o = dst + static_cast<int64_t>(blockIdx.x) * H;
-  const double scale = 1.0 / static_cast<double>(n);
-#pragma unroll 4
-  for (int m = threadIdx.x; m < q4; m += kHalfThreads) {
-    const c64 z0 = zs[swz(m)], z1 = zs[swz(h - 1 - m)];
-    store2<false>(o + 4 * m, admm_double2{z0.x * scale, z1.y * scale});
-    store2<false>(o + 4 * m + 2, admm_double2{z0.y * scale, z1.x * scale});
-  }
-}
+// (Round 3 also built the inverse transform with ONE real column per workgroup -- an n/2-point complex FFT of
+// z[m] = v[2m] + i v[2m+1], half the LDS, four workgroups per CU instead of two: correct, and 9 us SLOWER per launch at
+// 4096^2 (74 against 65 us): the transform is bound by its own instruction stream, not by the overlap of its phases.
+// Removed; the commit that carried it: "2-D TV row stage: 16 waves of a workgroup ...".)
 
 // columns of t have length W (= tw.n) and belong to the row frequencies i = 2*blockIdx.x, +1 of the image
 __global__ __launch_bounds__(kBlock) void dct_rows_solve_kernel(double* __restrict__ tm, int64_t W, double rho,
@@ -584,12 +515,6 @@ void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTab
 
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream) {
-  if (th.n >= 64 && std::getenv("ADMM_HIP_DCT_PAIRS") == nullptr) {  // one column per workgroup, n/2-point transform
-    dct_allow_lds(dct_col_inverse_half_kernel, dct_lds_bytes(th.n) / 2);
-    hipLaunchKernelGGL(dct_col_inverse_half_kernel, dim3(static_cast<unsigned>(W)), dim3(kHalfThreads),
-                       dct_lds_bytes(th.n) / 2, stream, src, dst, H, th, ctrl);
-    return;
-  }
   dct_allow_lds(dct_cols_inverse_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, src, dst, H, th, ctrl);

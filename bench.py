@@ -290,11 +290,13 @@ def other_configs(ap, L, device, steps):
             gb = (19.0 + 10.0 * inner) * 8.0 * npix / 1e9
             extra = {"x_update": "cg", "cg_inner_iters_per_step": inner, "cg_tol": 1e-11}
         else:
-            # fused z/u/dual/rhs pass on the compact state v = z + u: 4N read (x, v, s) + 3N written (v, next rhs);
-            # spectral solve: three passes (column DCT, row stage, column inverse) = 6N.  (Up to r2i the pass
-            # carried z and u apart: 11N + 6N = 17N; round 1: 21N.)
-            gb = 13.0 * 8.0 * npix / 1e9
-            extra = {"x_update": "dct"}
+            # three launches: row stage 2N (transformed right-hand side -> scratch image), inverse column DCT 2N, and the
+            # fused z/u/dual pass on the compact state v = z + u whose right-hand side goes through the forward column
+            # DCT inside the kernel: 4N read (x, v, s) + 3N written (v, transformed next rhs) = 11N.  (Round 2 and the
+            # start of round 3: b written and read back, 13N in four launches; up to r2i 17N; round 1: 21N.)
+            gb = 11.0 * 8.0 * npix / 1e9
+            extra = {"x_update": "dct",
+                     "frac_in_the_13N_unit_of_round_2": 13.0 * 8.0 * npix / 1e9 * s2.steps / dt2 / HBM_PEAK_GBS}
         res["totalvariation2d_4096x4096" + tag] = dict(
             {"iters_per_s": s2.steps / dt2, "ms_per_step": dt2 / s2.steps * 1e3, "algorithmic_GB_per_iter": gb,
              "achieved_GBs": gb * s2.steps / dt2, "frac": gb * s2.steps / dt2 / HBM_PEAK_GBS}, **extra)
@@ -303,9 +305,11 @@ def other_configs(ap, L, device, steps):
             res["totalvariation2d_4096x4096" + tag]["kernel_classes"] = cls
             if "xsolve" in cls and "prox" in cls:
                 res["totalvariation2d_4096x4096" + tag]["roofline"] = {
-                    "spectral_solve": leg_roofline("dct_cols_forward + tv2d_rows_green + dct_cols_inverse (3 launches)",
-                                                   6.0 * 8.0 * npix, cls["xsolve"]["avg_ms"], bound="hbm+infinity_cache"),
-                    "fused_pass": leg_roofline("tv2d_fused_kernel", 7.0 * 8.0 * npix, cls["prox"]["avg_ms"])}
+                    "spectral_solve": leg_roofline("tv2d_rows_coop + dct_cols_inverse (2 launches)",
+                                                   4.0 * 8.0 * npix, cls["xsolve"]["avg_ms"], bound="hbm+infinity_cache"),
+                    "fused_pass": leg_roofline("tv2d_fused_dct_kernel (z/u update, dual stencils, next right-hand "
+                                               "side -> forward column DCT in LDS)", 7.0 * 8.0 * npix,
+                                               cls["prox"]["avg_ms"])}
         tv2.close()
     return res
 
