@@ -233,7 +233,6 @@ __global__ __launch_bounds__(kWave) void symv_lower_kernel(const double* __restr
 // stop decision: ~6 us of one workgroup's serial work) while the other workgroups stream the matrix.  Nothing in this
 // launch depends on that decision, and the fused element update that follows starts after it and no-ops when it has
 // raised ctrl->stop: the tail of an iteration shrinks to the element update itself (engine_run.hip, defer_fin).
-template <int NBUF>
 __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __restrict__ M, int64_t n,
                                                                const double* __restrict__ x,
                                                                double* __restrict__ npart, double* __restrict__ tpart,
@@ -250,13 +249,12 @@ __global__ __launch_bounds__(kWave) void symv_lower_fin_kernel(const double* __r
     if (fin_pending) finalize_body<false, kWave>(f);
     return;
   }
-  symv_lower_body<true, NBUF>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, part_rank, part_count, ncached);
+  symv_lower_body<true>(blockIdx.x - 1u, 0u, M, n, 0, x, npart, tpart, ldp, part_rank, part_count, ncached);
 }
 
 // K packed matrices of one size in ONE launch (consensus lasso: the K slice inverses of a rank; blockIdx.y = slice):
 // x, npart, tpart of slice k at x0 + k*xstride, npart0 + k*pstride, tpart0 + k*pstride
 // (workgroup (0, 0) is a passenger: the deferred finalize logic of the previous iteration, as in symv_lower_fin_kernel)
-template <int NBUF>
 __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* const* __restrict__ Ms, int64_t n,
                                                                  const double* __restrict__ x0, int64_t xstride,
                                                                  double* __restrict__ npart0,
@@ -271,8 +269,8 @@ __global__ __launch_bounds__(kWave) void symv_lower_batch_kernel(const double* c
     return;
   }
   const int64_t k = blockIdx.y;
-  symv_lower_body<true, NBUF>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride,
-                              tpart0 + k * pstride, ldp, 0, 1, ncached);
+  symv_lower_body<true>(blockIdx.x - 1u, 0u, Ms[k], n, 0, x0 + k * xstride, npart0 + k * pstride, tpart0 + k * pstride,
+                        ldp, 0, 1, ncached);
 }
 
 // ---------------------------------------------------------------- x = X' (X y),  X = inv(L) tile-packed: the two
@@ -575,7 +573,7 @@ void launch_symv_lower_batch(const SymvPlan& p, const double* const* Ms_dev, int
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
   const FinArgs f = fin ? *fin : FinArgs{};
   const dim3 grid(static_cast<unsigned>(symv_tiles(p)) + 1u, static_cast<unsigned>(K));
-  hipLaunchKernelGGL(symv_lower_batch_kernel<2>, grid, dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0,
+  hipLaunchKernelGGL(symv_lower_batch_kernel, grid, dim3(kWave), 0, stream, Ms_dev, p.n, x0, xstride, npart0, tpart0,
                      pstride, p.ldp, ncached, f, fin ? 1 : 0, ctrl);
 }
 
@@ -584,7 +582,7 @@ void launch_symv_lower_fin(const SymvPlan& p, const double* M, const double* x, 
                            int part_count, double* y) {
   const uint32_t ncached = static_cast<uint32_t>(p.ncached < 0 ? 0 : p.ncached);
   const dim3 grid(static_cast<unsigned>(symv_tiles(p)) + 1u);
-  hipLaunchKernelGGL(symv_lower_fin_kernel<2>, grid, dim3(kWave), 0, stream, M, p.n, x, npart, tpart, p.ldp, part_rank,
+  hipLaunchKernelGGL(symv_lower_fin_kernel, grid, dim3(kWave), 0, stream, M, p.n, x, npart, tpart, p.ldp, part_rank,
                      part_count, ncached, f, fin_pending ? 1 : 0, ctrl);
   if (!y) return;  // the consumer sums the partial rows itself
   const int64_t blocks = ceil_div(p.n, 16);
