@@ -252,6 +252,14 @@ def read_idx3_images(path, count=None, border=4):
     return np.asfortranarray(img.reshape(k, -1))
 
 
+def reference_mnist_labels(which="train"):
+    """The label files the reference tree holds (examples/MNIST/{train,t10k}-labels.idx1-ubyte), committed byte for
+    byte under tests/golden/mnist/; None where the repository's tests are not installed next to the package."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mnist",
+                        f"{which}-labels.idx1-ubyte")
+    return read_idx1_labels(path) if os.path.exists(path) else None
+
+
 def mnist_like_problem(seed=1, m=6000, n=400, digit=0, labels=None):
     """Config-3 stand-in (the MNIST image files are absent from the reference tree):
     entries 0 w.p. 0.5 else U(0,1) as cropped /255 pixels; labels digit-vs-rest -> +-1

@@ -360,7 +360,9 @@ def consensus_leg(ap, L, a, dist, p, rho, device, comm, rank, world, m_global, x
 def _svm_configs(ap, L, device, res):
     # config 3: linear SVM, hinge, MNIST-shaped synthetic pixels (image files are absent from the reference)
     for m in (6000, 60000):
-        q = ap.synth.mnist_like_problem(seed=1, m=m, n=400, digit=0)
+        # images: synthetic (the reference tree holds no MNIST image file); labels: the reference's own
+        # examples/MNIST/train-labels.idx1-ubyte (tests/golden/mnist/), digit 0 against the rest (mnistsvm.m:133-142)
+        q = ap.synth.mnist_like_problem(seed=1, m=m, n=400, digit=0, labels=ap.synth.reference_mnist_labels("train"))
         svm = ap.Engine(L.PROB_LINEARSVM, D=q["D"], ell=q["ell"], Cval=q["C"], xsolve=L.XSOLVE_INVERSE, device=device)
         kw = dict(maxiters=1000, domaxiters=1, record_history=0, nodualerror=1, stopcond="both",
                   x0=q["x0"], z0=q["z0"], u0=q["u0"])  # unwrappedadmm.m:87-92

@@ -186,6 +186,27 @@ def test_mnist_label_reader(ap, tmp_path):
         ap.synth.read_idx1_labels(str(bad))
 
 
+def test_mnist_label_files_the_reference_holds(ap):
+    """examples/MNIST/{train,t10k}-labels.idx1-ubyte are the only DATA files in the reference tree (the image files its
+    example reads, mnistsvm.m:51-54, are absent there): committed byte for byte under tests/golden/mnist/ and read with
+    the loader that mirrors readMNIST (mnistsvm.m:215-233).  Pinned against what is publicly known about MNIST: the
+    counts, the class histograms, the first ten labels of either file -- and the +1 / -1 relabelling of trainForDigit
+    (mnistsvm.m:133-142)."""
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mnist")
+    train = ap.synth.read_idx1_labels(os.path.join(here, "train-labels.idx1-ubyte"))
+    test = ap.synth.read_idx1_labels(os.path.join(here, "t10k-labels.idx1-ubyte"), 10000)
+    assert train.shape == (60000,) and test.shape == (10000,)
+    assert np.bincount(train.astype(int)).tolist() == [5923, 6742, 5958, 6131, 5842, 5421, 5918, 6265, 5851, 5949]
+    assert np.bincount(test.astype(int)).tolist() == [980, 1135, 1032, 1010, 982, 892, 958, 1028, 974, 1009]
+    assert train[:10].tolist() == [5, 0, 4, 1, 9, 2, 1, 3, 1, 4] and test[:10].tolist() == [7, 2, 1, 0, 4, 1, 4, 9, 5, 9]
+    with pytest.raises(ValueError):  # "Trying to read too many digits" (mnistsvm.m:226-228)
+        ap.synth.read_idx1_labels(os.path.join(here, "t10k-labels.idx1-ubyte"), 10001)
+    ell = np.where(train == 3, 1.0, -1.0)  # trainForDigit(., ., ., ell, 3)
+    assert int((ell > 0).sum()) == 6131 and set(np.unique(ell)) == {-1.0, 1.0}
+
+
 def test_solver_argument_errors_mirror_the_reference(ap):
     """Validation happens on the host before any device work: the reference's error() texts (model.m:204-211,
     linearprogram.m:241-244, quadraticprogram.m:348-363, lasso.m / lad.m size checks)."""

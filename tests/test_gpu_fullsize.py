@@ -76,7 +76,8 @@ def test_lad_100k_x_10k_identities(gpu, big):
 
 def test_svm_60000_x_400_identities(gpu):
     """Config 3 at the full MNIST-shaped size (synthetic pixels; the image files are absent from the reference)."""
-    q = gpu.synth.mnist_like_problem(seed=1, m=60000, n=400, digit=0)
+    q = gpu.synth.mnist_like_problem(seed=1, m=60000, n=400, digit=0,
+                                     labels=gpu.synth.reference_mnist_labels("train"))  # the reference's label file
     D, ell, C, rho = q["D"], q["ell"], q["C"], 1.0
     run = lambda o: gpu.linearsvm(D, ell, C, o)
     st = run(dict(x0=q["x0"], z0=q["z0"], u0=q["u0"], record_history=0, maxiters=50, domaxiters=1))

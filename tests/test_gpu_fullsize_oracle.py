@@ -154,7 +154,8 @@ def test_svm_60000_x_400_50_iterations(gpu, blas):
     """Config 3 at the full MNIST shape (synthetic pixels): unwrappedadmm.m:76-92 with linearsvm.m:185 and
     getProxOps.m:1062-1100; fixed x0, z0, u0; 50 iterations (unwrappedadmm.m:90 would force 1000: the loop is entered
     through admm() with the same operators on both sides)."""
-    q = gpu.synth.mnist_like_problem(seed=1, m=60000, n=400, digit=0)
+    q = gpu.synth.mnist_like_problem(seed=1, m=60000, n=400, digit=0,
+                                     labels=gpu.synth.reference_mnist_labels("train"))  # the reference's label file
     D, ell, C = q["D"], q["ell"], q["C"]
     m, n = D.shape
     o = dict(maxiters=50, domaxiters=1, nodualerror=1, stopcond="both", objevals=1, x0=q["x0"], z0=q["z0"],
