@@ -98,6 +98,28 @@ class EngineInfo(C.Structure):
     ]
 
 
+class Field(C.Structure):  # admm_field: one field of a host struct as the binding layer reads it
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int32), ("reserved", C.c_int32), ("data", C.POINTER(C.c_double)),
+                ("rows", C.c_int64), ("cols", C.c_int64), ("text", C.c_char_p), ("ir", C.POINTER(C.c_uint64)),
+                ("jc", C.POINTER(C.c_uint64))]
+
+
+class BindingInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("problem", C.c_int32), ("nA", C.c_int64), ("nB", C.c_int64),
+                ("nU", C.c_int64), ("a_handle", C.c_int32), ("b_kind", C.c_int32), ("b_scalar", C.c_double),
+                ("b_matrix", C.POINTER(C.c_double)), ("b_ld", C.c_int64)]
+
+
+class ResultField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int32), ("source", C.c_int32), ("rows", C.c_int64),
+                ("cols", C.c_int64), ("scalar", C.c_double)]
+
+
+FIELD_NUMERIC, FIELD_TEXT, FIELD_HANDLE, FIELD_SPARSE, FIELD_OTHER = 0, 1, 2, 3, 4
+RES_FETCH, RES_SCALAR, RES_START = 0, 1, 2
+F_WVALS = 23
+
+
 class AdmmError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"[admm_hip {code}] {message}")
@@ -127,6 +149,16 @@ _SIGNATURES = {
     "admm_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "admm_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "admm_engine_destroy": (None, [C.c_void_p]),
+    "admm_binding_create": (C.c_int, [C.c_char_p, C.POINTER(Field), C.c_int32, C.POINTER(Field), C.c_int32,
+                                      C.POINTER(C.c_void_p)]),
+    "admm_binding_destroy": (None, [C.c_void_p]),
+    "admm_binding_desc": (C.POINTER(ProblemDesc), [C.c_void_p]),
+    "admm_binding_get_info": (C.c_int, [C.c_void_p, C.POINTER(BindingInfo)]),
+    "admm_binding_apply": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "admm_binding_options": (C.c_int, [C.c_void_p, C.POINTER(Field), C.c_int32, C.POINTER(Field), C.c_int32,
+                                       C.POINTER(Options)]),
+    "admm_binding_results": (C.c_int, [C.c_void_p, C.POINTER(Options), C.POINTER(RunSummary), C.POINTER(ResultField),
+                                       C.c_int32, C.POINTER(C.c_int32)]),
     "admm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "admm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "admm_op_gemv_n": (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int64, _dp, _dp]),

@@ -1515,6 +1515,26 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
     case ADMM_F_AVALS: src = e->avals; count = steps; need_fast = true; break;
     case ADMM_F_DVALS: src = e->dvals; count = steps; need_fast = true; break;
     case ADMM_F_RESTARTED: src = e->restarted; count = steps; need_fast = true; break;
+    case ADMM_F_WVALS: {  // w = [x; z; rho*u] per iteration (admm.m:678-681)
+      if (!e->hist_vectors) return fail(ADMM_E_INVALID, "vector histories were not recorded (options.record_history = 0)");
+      const size_t nx = static_cast<size_t>(e->nA), nz = static_cast<size_t>(e->bgen ? e->nBz : e->len),
+                   nu = static_cast<size_t>(e->len), nw = nx + nz + nu;
+      count = nw * steps;
+      if (cap < count) return fail(ADMM_E_CAPACITY, "destination too small");
+      if (steps > 0) {
+        const size_t pitch = nw * sizeof(double);
+        ADMM_HIP_TRY(hipMemcpy2D(dst, pitch, e->xhist, nx * sizeof(double), nx * sizeof(double), steps, hipMemcpyDeviceToHost));
+        ADMM_HIP_TRY(hipMemcpy2D(dst + nx, pitch, e->bgen ? e->zthist : e->zhist, nz * sizeof(double), nz * sizeof(double),
+                                 steps, hipMemcpyDeviceToHost));
+        ADMM_HIP_TRY(hipMemcpy2D(dst + nx + nz, pitch, e->uhist, nu * sizeof(double), nu * sizeof(double), steps,
+                                 hipMemcpyDeviceToHost));
+        const double rho = e->last_opts.rho;
+        for (size_t i = 0; i < steps; ++i)
+          for (size_t j = 0; j < nu; ++j) dst[i * nw + nx + nz + j] *= rho;
+      }
+      if (written) *written = count;
+      return ADMM_OK;
+    }
     case ADMM_F_CG_ITERS: {
       if (e->xsolve != ADMM_XSOLVE_CG) return fail(ADMM_E_INVALID, "field exists only for xsolve = cg");
       if (cap < 1) return fail(ADMM_E_CAPACITY, "destination too small");

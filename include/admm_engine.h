@@ -242,7 +242,9 @@ enum {
   ADMM_F_FACTOR = 19,     /* n x n (or m x m, fat lasso) lower Cholesky factor */
   ADMM_F_CG_ITERS = 20,   /* ADMM_XSOLVE_CG: inner iterations used per x-update */
   ADMM_F_CONS_X = 21,     /* consensus lasso: the local slices' x_k, n x K column-major (closure state xi{k}, getProxOps.m:1247) */
-  ADMM_F_CONS_U = 22      /* consensus lasso: the local slices' u_k (closure state ui{k}, getProxOps.m:1296) */
+  ADMM_F_CONS_U = 22,     /* consensus lasso: the local slices' u_k (closure state ui{k}, getProxOps.m:1296) */
+  ADMM_F_WVALS = 23       /* (nA + nB + nU) x steps: w = [x; z; rho*u] per iteration, results.wvals of the H-norm runs
+                           * (admm.m:678-681); needs the vector histories */
 };
 
 /* ---- library ---------------------------------------------------------------- */
@@ -337,6 +339,67 @@ int admm_engine_set_profiling(admm_engine* eng, int mask);
  * loop 2/stride event records per iteration instead of 2 */
 int admm_engine_set_profiling_stride(admm_engine* eng, int stride);
 void admm_engine_destroy(admm_engine* eng);
+
+/* ---- binding layer (ABI 5): the getproxops / admm argument structs seen through the C ABI -------------------------
+ * A host language (the MATLAB MEX gateway, ctypes, ...) flattens its structs into admm_field entries; everything that
+ * INTERPRETS them lives behind the ABI (csrc/binding.hip; host code, no GPU needed): which field means what for which
+ * problem (getProxOps.m:52-917: the args struct of getproxops), the defaults of admm's options (admm.m:780-971), what
+ * admm refuses before its loop, and the layout of the results struct (admm.m:257-767).  A gateway converts containers
+ * and stages function handles; it decides nothing. */
+enum { ADMM_FIELD_NUMERIC = 0,  /* full real double array: data, rows, cols (column-major) */
+       ADMM_FIELD_TEXT = 1,     /* character vector: text */
+       ADMM_FIELD_HANDLE = 2,   /* a function handle (its presence is what counts; the gateway keeps the callable) */
+       ADMM_FIELD_SPARSE = 3,   /* real double CSC matrix: data = nonzeros, ir = their rows, jc = column starts (cols + 1) */
+       ADMM_FIELD_OTHER = 4 };
+typedef struct admm_field {
+  const char* name;
+  int32_t kind;
+  int32_t reserved;
+  const double* data;
+  int64_t rows, cols;
+  const char* text;
+  const uint64_t* ir;
+  const uint64_t* jc;
+} admm_field;
+typedef struct admm_binding admm_binding;
+/* problem: the getproxops problem string ('lasso', 'lad', 'huberfit', 'linearsvm', 'totalvariation', 'quadraticprogram',
+ * 'linearprogram', 'basispursuit', 'model'; extensions 'totalvariation2d', 'generic' = both prox operators the caller's);
+ * args: the struct getproxops receives; handles: the caller's function handles by name (xminf, zming, obj, A, At, B, altu,
+ * specialnorms) plus the scalars a solver keeps next to them (s, r, objnative).  The description borrows the numeric
+ * arrays of `args`: they must stay valid until admm_engine_create has returned. */
+int admm_binding_create(const char* problem, const admm_field* args, int32_t nargs, const admm_field* handles,
+                        int32_t nhandles, admm_binding** out);
+void admm_binding_destroy(admm_binding* b);
+const admm_problem_desc* admm_binding_desc(const admm_binding* b);
+typedef struct admm_binding_info {
+  int32_t struct_size;  /* sizeof(admm_binding_info), set by the caller */
+  int32_t problem;      /* ADMM_PROB_* */
+  int64_t nA, nB, nU;   /* lengths of x, of z, and of u / c / A*x (admm.m:252-254) */
+  int32_t a_handle;     /* generic: A and At are function handles (admm_engine_set_operators before a run) */
+  int32_t b_kind;       /* generic: 0 = B is the shorthand -1, 1 = another scalar, 2 = a matrix, 3 = a function handle */
+  double b_scalar;
+  const double* b_matrix;
+  int64_t b_ld;
+} admm_binding_info;
+int admm_binding_get_info(const admm_binding* b, admm_binding_info* info);
+/* after admm_engine_create: a scalar or matrix B goes to the engine (admm_engine_set_constraint_b) */
+int admm_binding_apply(const admm_binding* b, admm_engine* eng);
+/* options struct -> admm_options (defaults of admm.m:780-971; x0 / z0 / u0 point into the fields) and the checks admm
+ * makes before its loop -- callable BEFORE an engine exists, so that a refused call never holds device memory */
+int admm_binding_options(const admm_binding* b, const admm_field* options, int32_t nopt, const admm_field* handles,
+                         int32_t nhandles, admm_options* out);
+/* the fields of results after a run, in the reference's order (admm.m:257-767) */
+enum { ADMM_RES_FETCH = 0,   /* admm_engine_fetch(source = ADMM_F_*), rows x cols */
+       ADMM_RES_SCALAR = 1,  /* `scalar` */
+       ADMM_RES_START = 2 }; /* the start vector the run used: options.x0 / z0 / u0 (source 0 / 1 / 2) or zeros */
+typedef struct admm_result_field {
+  const char* name;  /* static storage */
+  int32_t kind, source;
+  int64_t rows, cols;
+  double scalar;
+} admm_result_field;
+int admm_binding_results(admm_binding* b, const admm_options* opts, const admm_run_summary* summary,
+                         admm_result_field* out, int32_t cap, int32_t* count);
 
 /* Host <-> device copies on the engine's stream (hip_stream as handed to a callback, NULL = default stream), complete on
  * return.  For bindings whose callbacks live on the host (a MATLAB function handle staged by the MEX gateway): the
