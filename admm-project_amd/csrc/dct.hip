@@ -225,15 +225,16 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
 #pragma unroll
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
   const int64_t npairs = W >> 1;
-  // Neighbouring pairs share two columns of x and one of v (the stencil's halo): they go to workgroups of ONE XCD at
-  // the same time, so that the halo is an L2 hit -- workgroup b runs on XCD b mod 8 (round-robin placement; speed
-  // only), XCD c takes the pairs [c*npairs/8, (c+1)*npairs/8) in order.  (Dealt round-robin instead, every XCD fetched
-  // its own copy of the halo: 743 MB read per launch at 4096^2 where x, v and s are 537 MB.)
-  const bool xcd_ranges = (npairs & 7) == 0 && (gridDim.x & 7u) == 0;
-  const int64_t per_xcd = npairs >> 3, wg_per_xcd = gridDim.x >> 3;
+  // Neighbouring pairs share two columns of x and one of v (the stencil's halo).  Workgroup b runs on XCD b mod 8
+  // (round-robin placement; speed only): within every 64 consecutive pairs, XCD c takes the 8 adjacent pairs
+  // [8c, 8c + 8), so that seven of eight halos are hits in its own L2 while all XCDs still work inside one 128-column
+  // window.  (Dealt round-robin, every XCD fetched its own copy of the halo: 743 MB read per launch at 4096^2 where x,
+  // v and s are 537 MB.  Whole eighths of the image per XCD were 30 us SLOWER than that: the eight streams sit
+  // 16 MB apart and meet in the same HBM channels.)
+  const bool xcd_groups = (npairs & 63) == 0 && (gridDim.x & 63u) == 0;
   for (int64_t w = blockIdx.x; w < npairs; w += gridDim.x) {
-    const int64_t round = w / gridDim.x, b = w - round * gridDim.x;
-    const int64_t pair = xcd_ranges ? (b & 7) * per_xcd + round * wg_per_xcd + (b >> 3) : w;
+    const int64_t b = w & 63;
+    const int64_t pair = xcd_groups ? (w - b) + (b & 7) * 8 + (b >> 3) : w;
     const int64_t j0 = 2 * pair;
     for (int64_t row0 = 0; row0 < H; row0 += kBlock) {
       const int64_t i = row0 + tid;

@@ -1,7 +1,8 @@
 """Pin the CPU oracle with the only result pins the reference offers: the pass criteria of
 its own testers and modeltest's closed form.  The reference holds
 no stored golden vectors, so per-iteration parity is "parity unpinned" by the reference;
-these property pins and the committed fixtures (test_golden.py) are what anchors it."""
+these property pins, the closed forms at the end of this file (problems whose minimiser mathematics gives: the oracle
+must converge to it) and the committed fixtures (test_golden.py) are what anchors it."""
 import numpy as np
 import pytest
 
@@ -161,3 +162,88 @@ def test_linearprogram_criterion(ap):  # linearprogramtest.m:122-134
     Dx = p["D"] @ x
     assert np.mean(np.abs((Dx - p["s"]) / Dx)) <= 1e-3
     assert abs(r["objopt"] - float(p["b"] @ x)) <= 1e-9 * abs(r["objopt"])
+
+
+# ---------------------------------------------------------------------------- closed forms (round 3)
+# Where the reference offers no number to pin against, mathematics does: problems whose minimiser is known in closed
+# form.  The oracle's solver must converge to it -- which pins the restated closures (getProxOps.m) and the loop
+# (admm.m) to the optimisation problem each solver file states, independently of any stored output.
+TIGHT = dict(abstol=1e-12, reltol=1e-10, maxiters=20000)
+
+
+def test_lasso_with_orthonormal_columns_is_a_soft_threshold():  # lasso.m:5-9: 1/2||Dx - s||^2 + lambda||x||_1
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((60, 12)))
+    s = rng.standard_normal(60)
+    lam = 0.3
+    r = S.lasso(Q, s, lam, dict(TIGHT))
+    np.testing.assert_allclose(r["zopt"], soft_threshold(Q.T @ s, lam), atol=1e-8)
+    np.testing.assert_allclose(r["xopt"], r["zopt"], atol=1e-7)
+
+
+def test_lad_on_a_constant_column_is_the_median():  # lad.m:5-8: minimise ||Dx - s||_1
+    s = np.array([3.0, -1.0, 7.0, 2.0, 10.0, 2.5, 0.0])
+    r = S.lad(np.ones((7, 1)), s, dict(TIGHT))
+    assert r["xopt"][0] == pytest.approx(np.median(s), abs=1e-6)
+
+
+def test_huber_without_outliers_is_least_squares():  # huberfit.m:5-9: inside the threshold Huber's loss is quadratic
+    rng = np.random.default_rng(1)
+    D = rng.standard_normal((40, 5))
+    x0 = rng.standard_normal(5)
+    s = D @ x0 + 0.01 * rng.standard_normal(40)  # residuals << 1
+    r = S.huberfit(D, s, dict(TIGHT))
+    np.testing.assert_allclose(r["xopt"], np.linalg.lstsq(D, s, rcond=None)[0], atol=1e-7)
+
+
+def test_total_variation_limits():  # totalvariation.m:5-9: 1/2||x - s||^2 + lambda||Dx||_1
+    rng = np.random.default_rng(2)
+    s = rng.standard_normal(50)
+    # the reference's D = spdiags([1 -1], 0:1, n, n) (totalvariation.m:127) is SQUARE: its last row is e_n', so the
+    # penalty is sum |x_i - x_(i+1)| + |x_n| and D x = 0 means x = 0, not x = const
+    r = S.totalvariation(s, 1e4, dict(TIGHT, rho=10.0))
+    np.testing.assert_allclose(r["xopt"], np.zeros(50), atol=1e-6)  # lambda -> inf
+    r = S.totalvariation(s, 0.0, dict(TIGHT))
+    np.testing.assert_allclose(r["xopt"], s, atol=1e-8)  # lambda = 0: the signal
+    # two samples, s = (1, 4), lambda = 1/2: stationarity of 1/2||x - s||^2 + lambda (|x1 - x2| + |x2|) with x1 < x2, x2 > 0
+    # gives x1 = s1 + lambda, x2 = s2 - 2 lambda
+    r = S.totalvariation(np.array([1.0, 4.0]), 0.5, dict(TIGHT))
+    np.testing.assert_allclose(r["xopt"], [1.5, 3.0], atol=1e-7)
+
+
+def test_basis_pursuit_on_an_identity_block():  # basispursuit.m:5-8: min ||x||_1  s.t.  D x = s
+    s = np.array([0.7, -1.2, 2.0])
+    D = np.hstack([np.eye(3), np.zeros((3, 4))])
+    r = S.basispursuit(D, s, dict(TIGHT))
+    np.testing.assert_allclose(r["zopt"], np.concatenate([s, np.zeros(4)]), atol=1e-7)
+    # a redundant dictionary: D = [I, 2I] -- the l1-cheapest representation uses the longer atoms, x = [0; s/2]
+    r = S.basispursuit(np.hstack([np.eye(3), 2 * np.eye(3)]), s, dict(TIGHT))
+    np.testing.assert_allclose(r["zopt"], np.concatenate([np.zeros(3), s / 2]), atol=1e-6)
+
+
+def test_bounded_qp_with_identity_hessian_is_a_projection():  # quadraticprogram.m:5-9, lb <= x <= ub
+    q = np.array([2.0, -3.0, 0.25, -0.1])
+    lb, ub = -np.ones(4), np.ones(4)
+    r = S.quadraticprogram_bounded(np.eye(4), q, 1.5, lb, ub, dict(TIGHT, objevals=1))
+    np.testing.assert_allclose(r["zopt"], np.clip(-q, lb, ub), atol=1e-8)
+    x = r["zopt"]
+    assert r["objopt"] == pytest.approx(0.5 * x @ x + q @ x + 1.5, abs=1e-7)
+
+
+def test_linear_program_on_the_simplex_picks_the_cheapest_vertex():  # linearprogram.m:5-8: min b'x, Dx = s, x >= 0
+    b = np.array([3.0, 1.0, 2.0, 5.0])
+    r = S.linearprogram(b, np.ones((1, 4)), np.array([1.0]), dict(TIGHT, rho=1.0))
+    np.testing.assert_allclose(r["zopt"], [0.0, 1.0, 0.0, 0.0], atol=1e-6)
+
+
+def test_standard_form_qp_against_its_kkt_system():  # quadraticprogram.m 'standard': Dx = s, x >= 0, inactive bounds
+    rng = np.random.default_rng(3)
+    P = np.diag([1.0, 2.0, 3.0, 4.0])
+    q = -np.array([4.0, 8.0, 12.0, 16.0])  # unconstrained minimiser (4, 4, 4, 4) > 0
+    D = np.ones((1, 4))
+    s = np.array([12.0])
+    r = S.quadraticprogram_standard(P, q, 0.0, D, s, dict(TIGHT))
+    kkt = np.block([[P, D.T], [D, np.zeros((1, 1))]])
+    sol = np.linalg.solve(kkt, np.concatenate([-q, s]))[:4]
+    assert np.all(sol > 0)
+    np.testing.assert_allclose(r["zopt"], sol, atol=1e-6)
