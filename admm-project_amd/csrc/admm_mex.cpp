@@ -251,13 +251,15 @@ void put(mxArray* res, const char* name, mxArray* v) {
   mxSetField(res, 0, name, v);
 }
 
-// options -> admm_options and every refusal that needs no engine (admm_binding_options); a MATLAB error on failure
-void read_options(const Desc& ds, const mxArray* op, const mxArray* handles, admm_options& o) {
+// options -> admm_options and every refusal that needs no engine (admm_binding_options); a MATLAB error on failure.
+// `keep` owns what the options may point into besides MATLAB's own arrays (a start vector given as an integer scalar)
+// and must live as long as `o` is used.
+void read_options(const Desc& ds, const mxArray* op, const mxArray* handles, Fields& keep, admm_options& o) {
   if (!mxIsStruct(op)) mexErrMsgIdAndTxt("admm:arg", "Given options is not a struct! At least pass empty struct!");
-  Fields fo, fh;
-  fo.add(op);
+  Fields fh;
+  keep.add(op);
   fh.add(handles);
-  const int rc = admm_binding_options(ds.b, fo.data(), fo.size(), fh.data(), fh.size(), &o);
+  const int rc = admm_binding_options(ds.b, keep.data(), keep.size(), fh.data(), fh.size(), &o);
   if (rc != ADMM_OK) mexErrMsgIdAndTxt(rc == ADMM_E_UNSUPPORTED ? "admm:unsupported" : "admm:arg", "%s", admm_last_error());
 }
 
@@ -418,7 +420,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     Desc& ds = *g_solve;
     describe(to_string(prhs[1]), prhs[2], handles, ds);
     admm_options o;
-    read_options(ds, prhs[3], handles, o);  // (every refusal that needs no engine: nothing is on the device yet)
+    static Fields opt_fields;  // (static: a MATLAB error below long-jumps past destructors; cleared on every call)
+    opt_fields = Fields();
+    read_options(ds, prhs[3], handles, opt_fields, o);  // (every refusal that needs no engine: nothing is on the device yet)
     static bool registered = false;
     if (!registered) {
       mexAtExit(at_exit_all);
@@ -466,7 +470,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     Live* l = find_live(prhs[1]);
     const mxArray* hd = nrhs > 3 ? prhs[3] : nullptr;
     admm_options o;
-    read_options(*l->ds, prhs[2], hd, o);
+    static Fields opt_fields;
+    opt_fields = Fields();
+    read_options(*l->ds, prhs[2], hd, opt_fields, o);
     RunError err;
     mxArray* res = run_engine(l->e, *l->ds, o, hd, err);  // (the engine persists by design: 'destroy' frees it)
     if (!res) mexErrMsgIdAndTxt(err.id.c_str(), "%s", err.msg.c_str());

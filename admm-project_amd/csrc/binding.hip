@@ -26,7 +26,6 @@ struct admm_binding {
   double b_scalar = -1.0;
   const double* b_matrix = nullptr;
   int64_t b_ld = 0;
-  std::vector<std::string> names;  // storage of the result-field names handed out
 };
 
 namespace {

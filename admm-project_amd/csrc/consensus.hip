@@ -1,6 +1,8 @@
 // consensus.hip -- vector kernels of consensus lasso (getProxOps.m:1217-1343).  Each slice k keeps
 // its own x_k, u_k and cached factor; the consensus variable z couples them through the means
 // of x_k and u_k (one all-reduce of 2n doubles when the slices live on several GPUs, X1 in SURVEY).
+#include <cstdlib>
+
 #include "consensus.h"
 #include "loop_kernels.h"
 
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const C
 // are dealt to (slice, row range) pairs: 313 workgroups at n = 10^4, 20 loads in flight per thread -- 21.4 us for
 // gather + update (rocprof; 16 elements x 32 slots, one round of loads per thread on 625 workgroups: 25.7 us -- the
 // rows' 128-byte segments are too short for the memory system), and 579 -> 570 us per iteration with the launch gone.
-constexpr int kCuTile = 32, kCuSlots = 16;
+constexpr int kCuSlots = 16;
+template <int kCuTile>
 __global__ __launch_bounds__(kCuTile* kCuSlots) void cons_gather_update_kernel(
     ConsArgs a, const double* __restrict__ npart, const double* __restrict__ tpart, int64_t pstride, int64_t ldp,
     int32_t ntile, const Ctrl* __restrict__ ctrl) {
@@ -308,11 +311,19 @@ bool cons_gather_update_ok(const ConsArgs& a) { return a.K >= 1 && a.K <= kCuSlo
 
 void launch_cons_gather_update(const ConsArgs& a, const double* npart, const double* tpart, int64_t pstride, int64_t ldp,
                                int32_t ntile, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
-  int64_t blocks = ceil_div(a.n, kCuTile);
+  static const int tile = [] {
+    const char* ev = std::getenv("ADMM_CONS_TILE");
+    return (ev && std::atoi(ev) == 64) ? 64 : 32;
+  }();
+  int64_t blocks = ceil_div(a.n, int64_t{tile});
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
   *nblk_out = static_cast<int>(blocks);
-  hipLaunchKernelGGL(cons_gather_update_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kCuTile * kCuSlots), 0, stream,
-                     a, npart, tpart, pstride, ldp, ntile, ctrl);
+  if (tile == 64)
+    hipLaunchKernelGGL(cons_gather_update_kernel<64>, dim3(static_cast<unsigned>(blocks)), dim3(64 * kCuSlots), 0, stream, a,
+                       npart, tpart, pstride, ldp, ntile, ctrl);
+  else
+    hipLaunchKernelGGL(cons_gather_update_kernel<32>, dim3(static_cast<unsigned>(blocks)), dim3(32 * kCuSlots), 0, stream, a,
+                       npart, tpart, pstride, ldp, ntile, ctrl);
 }
 
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
