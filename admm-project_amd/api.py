@@ -650,9 +650,9 @@ def admm(xminf, zming, options):
         results["objevals"] = eng.fetch(L.F_OBJEVALS, steps)
     if use_h:
         results["Hnormsq"] = eng.fetch(L.F_HNORMSQ, steps)
-        if record_history:  # admm.m:678-681  w = [x; z; rho*u]
-            results["wvals"] = np.asfortranarray(
-                np.concatenate([results["xvals"], results["zvals"], rho * results["uvals"]], axis=0))
+        if record_history:  # admm.m:678-681  w = [x; z; rho*u], assembled behind the ABI (ADMM_F_WVALS)
+            nw = nA + nB + mC
+            results["wvals"] = eng.fetch(L.F_WVALS, nw * steps, (nw, steps))
 
     if not quiet and alg != L.FAST_WEAK:  # admm.m:318-330, 661-673
         hdr = ["Iteration", "Primal Residual Norm", "Primal Error", "Dual Residual Norm", "Dual Error"]

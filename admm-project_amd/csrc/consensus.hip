@@ -191,8 +191,7 @@ __global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const C
 // are dealt to (slice, row range) pairs: 313 workgroups at n = 10^4, 20 loads in flight per thread -- 21.4 us for
 // gather + update (rocprof; 16 elements x 32 slots, one round of loads per thread on 625 workgroups: 25.7 us -- the
 // rows' 128-byte segments are too short for the memory system), and 579 -> 570 us per iteration with the launch gone.
-constexpr int kCuSlots = 16;
-template <int kCuTile>
+template <int kCuTile, int kCuSlots>
 __global__ __launch_bounds__(kCuTile* kCuSlots) void cons_gather_update_kernel(
     ConsArgs a, const double* __restrict__ npart, const double* __restrict__ tpart, int64_t pstride, int64_t ldp,
     int32_t ntile, const Ctrl* __restrict__ ctrl) {
@@ -307,23 +306,31 @@ __global__ __launch_bounds__(kCuTile* kCuSlots) void cons_gather_update_kernel(
   }
 }
 
-bool cons_gather_update_ok(const ConsArgs& a) { return a.K >= 1 && a.K <= kCuSlots; }
+bool cons_gather_update_ok(const ConsArgs& a) { return a.K >= 1 && a.K <= 16; }
 
 void launch_cons_gather_update(const ConsArgs& a, const double* npart, const double* tpart, int64_t pstride, int64_t ldp,
                                int32_t ntile, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
-  static const int tile = [] {
+  // elements x (slice, row-range) slots per workgroup: the longer the row segments the better the memory system likes
+  // them (32 x 16: 25.1 us, 64 x 16: 21.0 us for the 52 MB of partial rows of 8 slices at n = 10^4)
+  static const int shape = [] {
     const char* ev = std::getenv("ADMM_CONS_TILE");
-    return (ev && std::atoi(ev) == 64) ? 64 : 32;
+    const int v = ev ? std::atoi(ev) : 64;
+    return (v == 32 || v == 128) ? v : 64;
   }();
+  const int tile = (shape == 128 && a.K > 8) ? 64 : shape;
   int64_t blocks = ceil_div(a.n, int64_t{tile});
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
   *nblk_out = static_cast<int>(blocks);
-  if (tile == 64)
-    hipLaunchKernelGGL(cons_gather_update_kernel<64>, dim3(static_cast<unsigned>(blocks)), dim3(64 * kCuSlots), 0, stream, a,
-                       npart, tpart, pstride, ldp, ntile, ctrl);
+  const dim3 grid(static_cast<unsigned>(blocks));
+  if (tile == 128)
+    hipLaunchKernelGGL((cons_gather_update_kernel<128, 8>), grid, dim3(1024), 0, stream, a, npart, tpart, pstride, ldp, ntile,
+                       ctrl);
+  else if (tile == 64)
+    hipLaunchKernelGGL((cons_gather_update_kernel<64, 16>), grid, dim3(1024), 0, stream, a, npart, tpart, pstride, ldp, ntile,
+                       ctrl);
   else
-    hipLaunchKernelGGL(cons_gather_update_kernel<32>, dim3(static_cast<unsigned>(blocks)), dim3(32 * kCuSlots), 0, stream, a,
-                       npart, tpart, pstride, ldp, ntile, ctrl);
+    hipLaunchKernelGGL((cons_gather_update_kernel<32, 16>), grid, dim3(512), 0, stream, a, npart, tpart, pstride, ldp, ntile,
+                       ctrl);
 }
 
 void launch_cons_update(const ConsArgs& a, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {

@@ -155,6 +155,26 @@ def test_lasso_options(gpu, opts):
     _compare(gpu.lasso(p["D"], p["s"], p["lam"], o), S.lasso(p["D"], p["s"], p["lam"], o))
 
 
+@pytest.mark.parametrize("solver", ["lasso", "lad"])
+def test_wvals_of_the_h_norm_runs(gpu, solver):
+    """results.wvals = [x; z; rho*u] per iteration (admm.m:678-681), assembled behind the ABI (ADMM_F_WVALS) -- A = 1
+    (all three parts of length n) and A = D (x of length n, z and u of length m), rho != 1"""
+    if solver == "lasso":
+        p = gpu.synth.lasso_problem(6, 150, 40)
+        o = dict(stopcond="both", rho=2.5, maxiters=40)
+        got, ref = gpu.lasso(p["D"], p["s"], p["lam"], o), S.lasso(p["D"], p["s"], p["lam"], o)
+        rows = 3 * 40
+    else:
+        p = gpu.synth.lad_problem(3, 120, 30)
+        o = dict(convtest=1, convtol=1e3, rho=0.5, maxiters=25, domaxiters=1)
+        got, ref = gpu.lad(p["D"], p["s"], o), S.lad(p["D"], p["s"], o)
+        rows = 30 + 120 + 120
+    _compare(got, ref)
+    assert got["wvals"].shape == (rows, got["steps"])
+    _close("wvals", got["wvals"], ref["wvals"])
+    np.testing.assert_array_equal(got["wvals"][:got["xvals"].shape[0]], got["xvals"])
+
+
 def test_lasso_warm_start(gpu):
     p = gpu.synth.lasso_problem(5, 128, 32)
     rng = np.random.default_rng(0)
