@@ -187,9 +187,9 @@ __global__ __launch_bounds__(kBlock) void cons_update_kernel(ConsArgs a, const C
 // lower-triangle x-solve left behind (as cons_gather_sum_kernel does), and the means, z, the u_k, the next right-hand
 // sides y_k and every partial sum follow in the same workgroup (as cons_update_kernel does) -- the K x n sums never
 // travel through memory and one launch boundary disappears.  Round 2 ran the gather as 79 workgroups (128 elements x 4
-// row slots at n = 10^4: a third of the CUs, 22.9 us for 52 MB); here a workgroup takes 32 elements and its 16 slots
-// are dealt to (slice, row range) pairs: 313 workgroups at n = 10^4, 20 loads in flight per thread -- 21.4 us for
-// gather + update (rocprof; 16 elements x 32 slots, one round of loads per thread on 625 workgroups: 25.7 us -- the
+// row slots at n = 10^4: a third of the CUs, 22.9 us for 52 MB); here a workgroup takes 64 elements (round 3, first
+// form: 32) and its 16 slots are dealt to (slice, row range) pairs: 157 workgroups of 1024 threads at n = 10^4, 20 loads
+// in flight per thread -- 21 us for gather + update (rocprof; 16 elements x 32 slots, one round of loads per thread on 625 workgroups: 25.7 us -- the
 // rows' 128-byte segments are too short for the memory system), and 579 -> 570 us per iteration with the launch gone.
 template <int kCuTile, int kCuSlots>
 __global__ __launch_bounds__(kCuTile* kCuSlots) void cons_gather_update_kernel(
@@ -310,22 +310,17 @@ bool cons_gather_update_ok(const ConsArgs& a) { return a.K >= 1 && a.K <= 16; }
 
 void launch_cons_gather_update(const ConsArgs& a, const double* npart, const double* tpart, int64_t pstride, int64_t ldp,
                                int32_t ntile, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
-  // elements x (slice, row-range) slots per workgroup: the longer the row segments the better the memory system likes
-  // them (32 x 16: 25.1 us, 64 x 16: 21.0 us for the 52 MB of partial rows of 8 slices at n = 10^4)
-  static const int shape = [] {
+  // elements x (slice, row-range) slots per workgroup, for the 52 MB of partial rows of 8 slices at n = 10^4:
+  // 32 x 16: 25.1 us, 64 x 16: 20.9 us (default), 128 x 8 (one slot per slice, 80 rows per thread): 25.4 us
+  static const int tile = [] {
     const char* ev = std::getenv("ADMM_CONS_TILE");
-    const int v = ev ? std::atoi(ev) : 64;
-    return (v == 32 || v == 128) ? v : 64;
+    return (ev && std::atoi(ev) == 32) ? 32 : 64;
   }();
-  const int tile = (shape == 128 && a.K > 8) ? 64 : shape;
   int64_t blocks = ceil_div(a.n, int64_t{tile});
   if (blocks > kMaxPartBlocks) blocks = kMaxPartBlocks;
   *nblk_out = static_cast<int>(blocks);
   const dim3 grid(static_cast<unsigned>(blocks));
-  if (tile == 128)
-    hipLaunchKernelGGL((cons_gather_update_kernel<128, 8>), grid, dim3(1024), 0, stream, a, npart, tpart, pstride, ldp, ntile,
-                       ctrl);
-  else if (tile == 64)
+  if (tile == 64)
     hipLaunchKernelGGL((cons_gather_update_kernel<64, 16>), grid, dim3(1024), 0, stream, a, npart, tpart, pstride, ldp, ntile,
                        ctrl);
   else
