@@ -8,17 +8,27 @@ namespace admm {
 
 struct FinArgs;
 
-struct DctTables {        // device tables of one transform length n = 2^log2n
+struct DctTables {        // device tables of one transform length n (= 2^log2n, or any n with the chirp tables below)
   int32_t n, log2n;
-  const admm_double2* tw;   // e^{-2 pi i k / n},     k < n/2        (FFT twiddles)
-  const admm_double2* c4;   // e^{-i pi k / (2n)},    k <= n/2       (FFT -> DCT-II rotation)
+  const admm_double2* tw;   // e^{-2 pi i k / n},     k < n/2        (FFT twiddles; chirp form: of length bm)
+  const admm_double2* c4;   // e^{-i pi k / (2n)},    k <= n/2       (FFT -> DCT-II rotation; chirp form: every k < n)
   const double* lam;        // 4 sin^2(pi k / (2n)),  k < n          (eigenvalues of the 1-D Neumann Laplacian)
+  // n not a power of two: the n-point DFT as a circular convolution of length bm = 2^log2bm >= 2n - 1 (Bluestein)
+  int32_t bm, log2bm;          // 0: plain power-of-two network
+  const admm_double2* chirp;   // c_j = e^{-pi i j^2 / n}, j < n
+  const admm_double2* hbr;     // FFT_bm of h_m = conj(c_|m|) (wrapped), at the network's output positions, times 1/bm
 };
 
 // host side of the tables (long double trigonometry); buffers have n/2, n/2 + 1 and n entries
 void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam);
 // n is a power of two the LDS-resident transform supports
 bool dct_length_ok(int64_t n);
+// any other length the column transform supports through the chirp form (2n - 1 <= 8192), and its FFT length
+bool dct_chirp_length_ok(int64_t n);
+int32_t dct_chirp_fft_length(int64_t n);
+// host side of the chirp tables: tw (bm/2), c4 (n: every k), lam (n), chirp (n), hbr (bm)
+void dct_fill_chirp_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam, admm_double2* chirp,
+                           admm_double2* hbr);
 
 // img (H x W, column-major, ld = H), in place: every column -> its DCT-II (unnormalised), two columns per workgroup
 void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,

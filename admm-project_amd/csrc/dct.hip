@@ -8,6 +8,8 @@
 // (decimation in time, conjugate twiddles), bit-reversed in -> natural out, so nothing is ever reordered: the
 // spectral step addresses position bitrev(k) directly.
 #include <cmath>
+#include <utility>
+#include <vector>
 
 #include "dct.h"
 #include "finalize_device.h"
@@ -337,6 +339,99 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   store_pair(zs, oa, oa + H, n, 1.0 / static_cast<double>(n));
 }
 
+// ---------------------------------------------------------------- column transforms of ANY length (chirp form)
+// For a height that is not a power of two the n-point DFT behind the DCT is taken as a circular convolution (Bluestein):
+// with c_j = e^{-pi i j^2/n},  V_k = c_k * sum_j (v_j c_j) conj(c_(k-j)):  one forward FFT of length bm >= 2n - 1 of the
+// chirped, zero-padded sequence, a pointwise product with the filter's spectrum (precomputed, 1/bm folded in, stored at
+// the network's bit-reversed output positions), one inverse FFT, and the chirp again.  The inverse DFT is the same with
+// conjugated chirps and the conjugated filter spectrum (the filter is even).  Two real columns per workgroup as one
+// complex sequence, as in the power-of-two kernels; ~4.5 x their work per column, and still an order of magnitude ahead
+// of the ~33 CG iterations the x-update costs otherwise.  Scalar loads and stores: any n, any column alignment.
+__device__ __forceinline__ int makhoul_pos(int j, int n) { return (j & 1) ? n - 1 - (j >> 1) : (j >> 1); }  // x index -> v index
+
+__device__ __forceinline__ void chirp_convolve(c64* zs, const DctTables& t, bool conj_filter) {
+  const int M = t.bm;
+  __syncthreads();
+  fft_network<false>(zs, M, t.log2bm, t.tw);
+  for (int p = threadIdx.x; p < M; p += blockDim.x) {
+    const c64 h = t.hbr[p];
+    zs[swz(p)] = conj_filter ? cmulc(zs[swz(p)], h) : cmul(zs[swz(p)], h);
+  }
+  __syncthreads();
+  fft_network<true>(zs, M, t.log2bm, t.tw);
+}
+
+template <bool FIN>
+__global__ __launch_bounds__(kBlock) void dct_cols_forward_chirp_kernel(double* __restrict__ img, int64_t H, DctTables t,
+                                                                        FinArgs f, int32_t fin_pending,
+                                                                        const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  if (FIN && blockIdx.x == 0) {
+    if (fin_pending) finalize_body<false>(f);
+    return;
+  }
+  extern __shared__ c64 zs[];
+  const int n = t.n, M = t.bm;
+  const unsigned pair = blockIdx.x - (FIN ? 1u : 0u);
+  double* __restrict__ a = img + static_cast<int64_t>(2 * pair) * H;
+  double* __restrict__ b = a + H;
+  for (int j = threadIdx.x; j < M; j += blockDim.x) {  // v_j c_j in Makhoul order, zeros behind
+    c64 y{0.0, 0.0};
+    if (j < n) {
+      const int v = makhoul_pos(j, n);
+      y = cmul(c64{a[j], b[j]}, t.chirp[v]);
+      zs[swz(v)] = y;
+    } else {
+      zs[swz(j)] = y;
+    }
+  }
+  chirp_convolve(zs, t, false);
+  for (int k = threadIdx.x; k < n; k += blockDim.x) zs[swz(k)] = cmul(zs[swz(k)], t.chirp[k]);  // V_k (of a + i b)
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {  // X_k = Re(e^{-i pi k/(2n)} V_k) for either column
+    const c64 zk = zs[swz(k)], zn = zs[swz(k == 0 ? 0 : n - k)];
+    const c64 va = c64{0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y)};
+    const c64 vb = c64{0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x)};
+    const c64 ck = t.c4[k];
+    a[k] = cmul(ck, va).x;
+    b[k] = cmul(ck, vb).x;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void dct_cols_inverse_chirp_kernel(const double* __restrict__ src,
+                                                                        double* __restrict__ dst, int64_t H, DctTables t,
+                                                                        const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  extern __shared__ c64 zs[];
+  const int n = t.n, M = t.bm;
+  const double* __restrict__ a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
+  const double* __restrict__ b = a + H;
+  for (int k = threadIdx.x; k < M; k += blockDim.x) {  // Z_k conj(c_k), zeros behind
+    c64 y{0.0, 0.0};
+    if (k < n) {
+      const int nk = k == 0 ? 0 : n - k;
+      const c64 ck = t.c4[k];
+      c64 va = cmulc(c64{a[k], -a[nk]}, ck), vb = cmulc(c64{b[k], -b[nk]}, ck);  // V = e^{+i pi k/(2n)} (X_k - i X_(n-k))
+      if (k == 0) {
+        va = c64{a[0], 0.0};
+        vb = c64{b[0], 0.0};
+      }
+      y = cmulc(c64{va.x - vb.y, va.y + vb.x}, t.chirp[k]);
+    }
+    zs[swz(k)] = y;
+  }
+  chirp_convolve(zs, t, true);
+  double* __restrict__ oa = dst + static_cast<int64_t>(2 * blockIdx.x) * H;
+  double* __restrict__ ob = oa + H;
+  const double scale = 1.0 / static_cast<double>(n);
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {  // x_j = v_(pos(j)),  v = conj(c) * convolution / n
+    const int v = makhoul_pos(j, n);
+    const c64 z = cmulc(zs[swz(v)], t.chirp[v]);
+    oa[j] = z.x * scale;
+    ob[j] = z.y * scale;
+  }
+}
+
 // (Round 3 also built the inverse transform with ONE real column per workgroup -- an n/2-point complex FFT of
 // z[m] = v[2m] + i v[2m+1], half the LDS, four workgroups per CU instead of two: correct, and 9 us SLOWER per launch at
 // 4096^2 (74 against 65 us): the transform is bound by its own instruction stream, not by the overlap of its phases.
@@ -400,9 +495,9 @@ __global__ __launch_bounds__(kBlock) void dct_rows_solve_strided_kernel(double* 
   extern __shared__ c64 zs[];
   const int n = t.n, p = t.log2n;
   const unsigned npairs = gridDim.x;
-  // contiguous ranges of row pairs per XCD (npairs is a power of two >= 8 here; smaller images fall back below)
+  // contiguous ranges of row pairs per XCD (where the pairs divide by 8; otherwise in order)
   const unsigned b = blockIdx.x;
-  const unsigned pair = (npairs >= 8) ? (b & 7u) * (npairs >> 3) + (b >> 3) : b;
+  const unsigned pair = (npairs >= 8 && (npairs & 7u) == 0) ? (b & 7u) * (npairs >> 3) + (b >> 3) : b;
   double* __restrict__ base = img + 2 * static_cast<int64_t>(pair);
   // Makhoul order: x[2k] -> v[k], x[2k+1] -> v[n-1-k]; all loads of a thread are independent
 #pragma unroll 8
@@ -485,6 +580,76 @@ void dct_fill_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam)
   }
 }
 
+bool dct_chirp_length_ok(int64_t n) { return n >= 8 && n <= 4096 && !dct_length_ok(n); }
+
+int32_t dct_chirp_fft_length(int64_t n) {
+  int32_t m = 16;
+  while (m < 2 * n - 1) m <<= 1;
+  return m;
+}
+
+void dct_fill_chirp_tables(int32_t n, admm_double2* tw, admm_double2* c4, double* lam, admm_double2* chirp,
+                           admm_double2* hbr) {
+  const long double pi = 3.141592653589793238462643383279502884L;
+  const int32_t M = dct_chirp_fft_length(n);
+  int log2m = 0;
+  while ((1 << log2m) < M) ++log2m;
+  for (int32_t k = 0; k < M / 2; ++k) {
+    const long double ang = -2.0L * pi * k / M;
+    tw[k] = admm_double2{static_cast<double>(cosl(ang)), static_cast<double>(sinl(ang))};
+  }
+  for (int32_t k = 0; k < n; ++k) {
+    const long double ang = -pi * k / (2.0L * n);
+    c4[k] = admm_double2{static_cast<double>(cosl(ang)), static_cast<double>(sinl(ang))};
+    const long double sv = sinl(pi * k / (2.0L * n));
+    lam[k] = static_cast<double>(4.0L * sv * sv);
+  }
+  // c_j = e^{-pi i j^2/n}: j^2 reduced modulo 2n exactly before the angle is formed
+  std::vector<long double> hr(static_cast<size_t>(M), 0.0L), hi(static_cast<size_t>(M), 0.0L);
+  for (int32_t j = 0; j < n; ++j) {
+    const int64_t q = (static_cast<int64_t>(j) * j) % (2 * static_cast<int64_t>(n));
+    const long double ang = -pi * static_cast<long double>(q) / n;
+    const long double cr = cosl(ang), ci = sinl(ang);
+    chirp[j] = admm_double2{static_cast<double>(cr), static_cast<double>(ci)};
+    hr[j] = cr;  // h_m = conj(c_|m|) at m and at M - m
+    hi[j] = -ci;
+    if (j > 0) {
+      hr[M - j] = cr;
+      hi[M - j] = -ci;
+    }
+  }
+  // H = FFT_M(h): iterative radix-2 in long double (bit-reversal permutation first), then H[bitrev(p)] / M at position p
+  auto brev = [&](int32_t k) {
+    int32_t r = 0;
+    for (int b = 0; b < log2m; ++b) r |= ((k >> b) & 1) << (log2m - 1 - b);
+    return r;
+  };
+  for (int32_t k = 0; k < M; ++k) {
+    const int32_t r = brev(k);
+    if (r > k) {
+      std::swap(hr[k], hr[r]);
+      std::swap(hi[k], hi[r]);
+    }
+  }
+  for (int32_t len = 2; len <= M; len <<= 1) {
+    const long double ang = -2.0L * pi / len;
+    for (int32_t i0 = 0; i0 < M; i0 += len)
+      for (int32_t j = 0; j < len / 2; ++j) {
+        const long double wr = cosl(ang * j), wi = sinl(ang * j);
+        const int32_t p = i0 + j, q = p + len / 2;
+        const long double tr = hr[q] * wr - hi[q] * wi, ti = hr[q] * wi + hi[q] * wr;
+        hr[q] = hr[p] - tr;
+        hi[q] = hi[p] - ti;
+        hr[p] += tr;
+        hi[p] += ti;
+      }
+  }
+  for (int32_t p = 0; p < M; ++p) {
+    const int32_t k = brev(p);
+    hbr[p] = admm_double2{static_cast<double>(hr[k] / M), static_cast<double>(hi[k] / M)};
+  }
+}
+
 static size_t dct_lds_bytes(int n) { return sizeof(c64) * static_cast<size_t>(n); }
 
 // n = 8192 needs 128 KB of the CU's 160 KB LDS (one workgroup per CU): beyond the 64 KB a launch gets by default
@@ -495,6 +660,12 @@ static void dct_allow_lds(K kernel, size_t bytes) {
 
 void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
                              hipStream_t stream) {
+  if (th.bm) {
+    dct_allow_lds(dct_cols_forward_chirp_kernel<false>, dct_lds_bytes(th.bm));
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<false>, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock),
+                       dct_lds_bytes(th.bm), stream, img, H, th, FinArgs{}, 0, ctrl);
+    return;
+  }
   dct_allow_lds(dct_cols_forward_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, img, H, th, ctrl);
@@ -517,6 +688,12 @@ void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const 
 
 void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
                                  bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+  if (th.bm) {
+    dct_allow_lds(dct_cols_forward_chirp_kernel<true>, dct_lds_bytes(th.bm));
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<true>, dim3(static_cast<unsigned>(W / 2) + 1u), dim3(kBlock),
+                       dct_lds_bytes(th.bm), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
+    return;
+  }
   dct_allow_lds(dct_cols_forward_fin_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_forward_fin_kernel, dim3(static_cast<unsigned>(W / 2) + 1u), dim3(kBlock),
                      dct_lds_bytes(th.n), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
@@ -524,6 +701,12 @@ void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTab
 
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream) {
+  if (th.bm) {
+    dct_allow_lds(dct_cols_inverse_chirp_kernel, dct_lds_bytes(th.bm));
+    hipLaunchKernelGGL(dct_cols_inverse_chirp_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock),
+                       dct_lds_bytes(th.bm), stream, src, dst, H, th, ctrl);
+    return;
+  }
   dct_allow_lds(dct_cols_inverse_kernel, dct_lds_bytes(th.n));
   hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
                      stream, src, dst, H, th, ctrl);

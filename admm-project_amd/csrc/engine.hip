@@ -800,8 +800,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // CG; the CG vectors are allocated either way (one of them is the transposition scratch of the spectral solve)
   // (the row stage needs no transform -- dct.hip: tv2d_rows_green_kernel -- so only the HEIGHT has to be a power of two
   // as long as the row kernel's truncation fits the width; run() falls back to CG for a rho where it does not)
+  // (a height that is not a power of two takes the chirp form of the column transform, dct.hip: any height up to 4096)
   const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
-                            dct_length_ok(desc->m) && (dct_length_ok(desc->n) || (desc->n >= 64 && desc->n % 2 == 0));  // (the column DCT takes column pairs)
+                            (dct_length_ok(desc->m) || dct_chirp_length_ok(desc->m)) &&
+                            (dct_length_ok(desc->n) || (desc->n >= 64 && desc->n % 2 == 0));  // (the column DCT takes column pairs)
   if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
@@ -1236,6 +1238,30 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       if (tv2_want_dct) {
         auto tables = [&](int64_t len, DctTables* t) -> int {
           const int32_t L = static_cast<int32_t>(len);
+          *t = DctTables{};
+          if (!dct_length_ok(L)) {  // chirp form: an FFT of length M >= 2L - 1 behind every column pair
+            const int32_t M = dct_chirp_fft_length(L);
+            std::vector<admm_double2> tw(static_cast<size_t>(M / 2)), c4(static_cast<size_t>(L)), ch(static_cast<size_t>(L)),
+                hb(static_cast<size_t>(M));
+            std::vector<double> lam(static_cast<size_t>(L));
+            dct_fill_chirp_tables(L, tw.data(), c4.data(), lam.data(), ch.data(), hb.data());
+            double *dtw = nullptr, *dc4 = nullptr, *dlam = nullptr, *dch = nullptr, *dhb = nullptr;
+            ADMM_TRY(upload(e->mem, &dtw, reinterpret_cast<const double*>(tw.data()), M, ADMM_MEM_HOST, e->stream));
+            ADMM_TRY(upload(e->mem, &dc4, reinterpret_cast<const double*>(c4.data()), 2 * L, ADMM_MEM_HOST, e->stream));
+            ADMM_TRY(upload(e->mem, &dlam, lam.data(), L, ADMM_MEM_HOST, e->stream));
+            ADMM_TRY(upload(e->mem, &dch, reinterpret_cast<const double*>(ch.data()), 2 * L, ADMM_MEM_HOST, e->stream));
+            ADMM_TRY(upload(e->mem, &dhb, reinterpret_cast<const double*>(hb.data()), 2 * M, ADMM_MEM_HOST, e->stream));
+            ADMM_HIP_TRY(hipStreamSynchronize(e->stream));  // the host vectors go out of scope
+            t->n = L;
+            t->bm = M;
+            while ((1 << t->log2bm) < M) ++t->log2bm;
+            t->tw = reinterpret_cast<const admm_double2*>(dtw);
+            t->c4 = reinterpret_cast<const admm_double2*>(dc4);
+            t->lam = dlam;
+            t->chirp = reinterpret_cast<const admm_double2*>(dch);
+            t->hbr = reinterpret_cast<const admm_double2*>(dhb);
+            return ADMM_OK;
+          }
           std::vector<admm_double2> tw(static_cast<size_t>(L / 2)), c4(static_cast<size_t>(L / 2 + 1));
           std::vector<double> lam(static_cast<size_t>(L));
           dct_fill_tables(L, tw.data(), c4.data(), lam.data());

@@ -66,7 +66,8 @@ static bool tv2d_rows_green_ok(const admm_engine* e, double rho) {
 
 // ... and it is the form dct_solve_tv2d takes by default (no environment override asks for a row transform)
 static bool tv2d_rows_green_default(const admm_engine* e, double rho) {
-  return tv2d_rows_green_ok(e, rho) && (!e->tv2_rows_dct || (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
+  return tv2d_rows_green_ok(e, rho) && (!e->tv2_rows_dct || e->tv2_H % 2 != 0 ||
+                                        (std::getenv("ADMM_HIP_TV2D_ROWS_DCT") == nullptr &&
                                                             std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr));
 }
 
@@ -110,7 +111,8 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
     return fail(ADMM_E_INVALID, "relaxation with the 2-D total-variation prox is a dimension error (D is 2N x N)");
   const int64_t Npix = e->tv2_H * e->tv2_W;
   // spectral x-update: needs the row DCT (width a power of two) or a rho the Toeplitz row stage covers; else CG
-  const bool spectral = e->tv2_dct && (e->tv2_rows_dct || tv2d_rows_green_ok(e, o.rho));
+  // (the row transform works on row PAIRS: an odd height needs the Toeplitz row stage)
+  const bool spectral = e->tv2_dct && ((e->tv2_rows_dct && e->tv2_H % 2 == 0) || tv2d_rows_green_ok(e, o.rho));
   if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
@@ -219,7 +221,8 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   // the next and an iteration is three launches: row stage (+ the previous iteration's finalize as a passenger) into the
   // scratch image e->cg_r, inverse column transform into x, fused pass + forward transform.  (The row stage writes a
   // scratch image, not x: it is the launch that carries the passenger, so it still runs when the passenger raises stop.)
-  const bool tv2_glued = spectral && tv2d_rows_green_default(e, o.rho) && std::getenv("ADMM_HIP_TV2D_NO_GLUE") == nullptr;
+  const bool tv2_glued = spectral && tv2d_rows_green_default(e, o.rho) && e->dctH.bm == 0 &&  // (power-of-two heights)
+                         std::getenv("ADMM_HIP_TV2D_NO_GLUE") == nullptr;
   bool tv2_pending = false;
   while (alg == 0 && done < N && !stop_seen) {
     double* const vbuf[2] = {e->tv_zB, e->tv_uB};

@@ -105,6 +105,26 @@ def test_tv2d_any_width_when_the_height_is_a_power_of_two(gpu, H, W, rho, spectr
     assert (got["cg_iters_total"] == 0) == spectral
 
 
+@pytest.mark.parametrize("H,W,rho", [(24, 64, 1.0), (100, 128, 0.6), (17, 256, 1.0), (1000, 240, 1.5), (3000, 64, 1.0),
+                                     (4095, 250, 2.0), (2049, 256, 1.0), (640, 480, 1.0), (9, 256, 1.0)])
+def test_tv2d_any_height_through_the_chirp_transform(gpu, H, W, rho):
+    """a height that is not a power of two: the column DCT as a circular convolution of length 2^p >= 2H - 1 (Bluestein,
+    dct.hip: dct_cols_*_chirp_kernel) -- the spectral x-update for any image up to 4096 rows, against the oracle's
+    sparse-direct solve; odd heights (columns at 8-byte alignment) included.  (The row stage keeps its own conditions:
+    the Toeplitz kernel needs 4 x its truncation <= W, the row transform a power-of-two width and an even height.)"""
+    img = _image(7 * H + W, H, W)
+    o = dict(objevals=1, rho=rho, maxiters=12, domaxiters=1)
+    got = gpu.totalvariation2d(img, 0.4, dict(o))
+    ref = S.totalvariation2d(img, 0.4, dict(o))
+    assert got["steps"] == ref["steps"] and got["cg_iters_total"] == 0
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt"):
+        _close(k, got[k], ref[k], 1e-9)
+    stop = gpu.totalvariation2d(img, 0.4, dict(objevals=1, rho=rho, stopcond="both", maxiters=80))
+    rstop = S.totalvariation2d(img, 0.4, dict(objevals=1, rho=rho, stopcond="both", maxiters=80))
+    assert stop["steps"] == rstop["steps"]
+    _close("xopt", stop["xopt"], rstop["xopt"], 1e-9)
+
+
 @pytest.mark.parametrize("H,W,iters", [(64, 64, 1), (64, 64, 2), (64, 64, 7), (40, 33, 2), (128, 96, 12)])
 def test_tv2d_compact_state_with_arbitrary_start(gpu, H, W, iters):
     """The fused pass carries v = z + u; z0, u0 that do not satisfy z0 = soft(z0 + u0) are read as given by the first
