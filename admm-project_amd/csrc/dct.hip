@@ -361,13 +361,18 @@ __device__ __forceinline__ void chirp_convolve(c64* zs, const DctTables& t, bool
   fft_network<true>(zs, M, t.log2bm, t.tw);
 }
 
+// (512 threads where the FFT has 8192 points -- 128 KB of LDS, one workgroup per CU: every radix-16 pass then has one
+// butterfly group per thread instead of two rounds of 256)
+constexpr int kChirpMaxThreads = 512;
+static int chirp_threads(int M) { return M >= 8192 ? kChirpMaxThreads : kBlock; }
+
 template <bool FIN>
-__global__ __launch_bounds__(kBlock) void dct_cols_forward_chirp_kernel(double* __restrict__ img, int64_t H, DctTables t,
+__global__ __launch_bounds__(kChirpMaxThreads) void dct_cols_forward_chirp_kernel(double* __restrict__ img, int64_t H, DctTables t,
                                                                         FinArgs f, int32_t fin_pending,
                                                                         const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
   if (FIN && blockIdx.x == 0) {
-    if (fin_pending) finalize_body<false>(f);
+    if (fin_pending && threadIdx.x < kBlock) finalize_body<false>(f);  // (written for one 256-thread workgroup)
     return;
   }
   extern __shared__ c64 zs[];
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void dct_cols_forward_chirp_kernel(double* 
   }
 }
 
-__global__ __launch_bounds__(kBlock) void dct_cols_inverse_chirp_kernel(const double* __restrict__ src,
+__global__ __launch_bounds__(kChirpMaxThreads) void dct_cols_inverse_chirp_kernel(const double* __restrict__ src,
                                                                         double* __restrict__ dst, int64_t H, DctTables t,
                                                                         const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
@@ -662,7 +667,7 @@ void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables&
                              hipStream_t stream) {
   if (th.bm) {
     dct_allow_lds(dct_cols_forward_chirp_kernel<false>, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<false>, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock),
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<false>, dim3(static_cast<unsigned>(W / 2)), dim3(chirp_threads(th.bm)),
                        dct_lds_bytes(th.bm), stream, img, H, th, FinArgs{}, 0, ctrl);
     return;
   }
@@ -690,8 +695,8 @@ void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTab
                                  bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
   if (th.bm) {
     dct_allow_lds(dct_cols_forward_chirp_kernel<true>, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<true>, dim3(static_cast<unsigned>(W / 2) + 1u), dim3(kBlock),
-                       dct_lds_bytes(th.bm), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<true>, dim3(static_cast<unsigned>(W / 2) + 1u),
+                       dim3(chirp_threads(th.bm)), dct_lds_bytes(th.bm), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
     return;
   }
   dct_allow_lds(dct_cols_forward_fin_kernel, dct_lds_bytes(th.n));
@@ -703,7 +708,7 @@ void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t 
                              const Ctrl* ctrl, hipStream_t stream) {
   if (th.bm) {
     dct_allow_lds(dct_cols_inverse_chirp_kernel, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_inverse_chirp_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock),
+    hipLaunchKernelGGL(dct_cols_inverse_chirp_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(chirp_threads(th.bm)),
                        dct_lds_bytes(th.bm), stream, src, dst, H, th, ctrl);
     return;
   }
