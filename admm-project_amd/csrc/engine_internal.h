@@ -111,6 +111,7 @@ struct admm_engine {
   // iterates
   double *x = nullptr, *z = nullptr, *u = nullptr, *rhs = nullptr, *dz = nullptr, *g = nullptr;
   int64_t ldg = 0;
+  double* opG = nullptr;         // one-pass A = D iteration: [workgroups][ldg] partial rows of D'*(c + z - u)
   double *v = nullptr, *uhat = nullptr, *zprev = nullptr, *uprev = nullptr;
   double *tmpA = nullptr, *tmpB = nullptr;  // fat lasso scratch (m and n long)
   // total variation: forward-sweep intermediate, ping-pong partners of z/u, LDL' pivot prefix

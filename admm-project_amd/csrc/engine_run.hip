@@ -768,7 +768,48 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   FinArgs dff{};
   e->dfin = nullptr;
   e->dfin_pending = false;
+  // A = D iterations without a dual residual on a tall, narrow D (config 3 at MNIST's full size): ONE pass over D per
+  // iteration instead of two (unwrapped.hip: ad_onepass_kernel) -- x-solve, the pass (D*x, element update, the partial
+  // rows of D'*(c + z - u)), their sum with the iteration's finalize as passenger.
+  const bool onepass = fuse_tail && defer_fin_ad && !uw_fused && alg == 0 && o.relax == 1.0 && o.nodualerror && e->D &&
+                       !e->DplusT && !sharded && !hooks && !e->xcb && !e->zcb && !e->ocb && !e->acb && !e->atcb && !e->bgen &&
+                       !split_z && !use_graph && e->xsolve != ADMM_XSOLVE_CG && onepass_supported(e->m, e->n);
+  OnePassArgs opa{};
+  GemvTPlan op_plan = e->planDT;
+  if (onepass) {
+    const int nwg = onepass_workgroups(e->m);
+    if (!e->opG) ADMM_TRY(e->mem.alloc(&e->opG, static_cast<size_t>(nwg) * static_cast<size_t>(e->ldg)));
+    opa.D = e->D;
+    opa.ldD = e->ldD;
+    opa.m = e->m;
+    opa.n = e->n;
+    opa.x = e->x;
+    opa.gpart = e->opG;
+    opa.ldg = e->ldg;
+    op_plan.nchunk = nwg;
+    op_plan.ldg = e->ldg;
+  }
   auto enqueue_iteration = [&]() -> int {
+    if (onepass) {
+      {
+        TimerScope ts(e, ADMM_K_XSOLVE);
+        ADMM_TRY(solve_factor(e, e->g, e->x));  // (row 0 of g: D'*(c + z - u) of the previous pass)
+      }
+      int nblk = 1;
+      {
+        TimerScope ts(e, ADMM_K_PROX);
+        pa.axsrc = nullptr;
+        pa.ax_t = nullptr;
+        pa.ax_tri = 0;
+        pa.x_out = nullptr;
+        launch_ad_onepass(opa, pa, e->ctrl, &nblk, e->stream);
+      }
+      dff = prox_fin_args(pa, fa);
+      dff.nblk = nblk;
+      TimerScope ts(e, ADMM_K_GEMV_T);
+      launch_sum_partials_t_fin(op_plan, e->opG, 1, e->g, e->ldg, dff, e->ctrl, e->stream);
+      return ADMM_OK;
+    }
     if (uw_fused) {
       TimerScope ts(e, ADMM_K_PROX);
       pa.axsrc = nullptr;

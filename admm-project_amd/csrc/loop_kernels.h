@@ -254,6 +254,18 @@ FinArgs uw_fin_args(const UwArgs& a, const FinArgs& f);
 void launch_uw_ax(const UwArgs& a, const FinArgs& f, Ctrl* ctrl, hipStream_t stream);
 void launch_uw_prox(const UwArgs& a, const ProxArgs& pa, const Ctrl* ctrl, hipStream_t stream);
 
+// One pass over a tall, NARROW D per A = D iteration without a dual residual (unwrapped.hip: ad_onepass_kernel)
+struct OnePassArgs {
+  const double* D;   // m x n, column-major
+  int64_t ldD, m, n;
+  const double* x;   // the iteration's x (n)
+  double* gpart;     // [workgroups][ldg] partial rows of D'*(c + z - u): the next x-update's right-hand side
+  int64_t ldg;
+};
+bool onepass_supported(int64_t m, int64_t n);
+int onepass_workgroups(int64_t m);
+void launch_ad_onepass(const OnePassArgs& a, const ProxArgs& pa, const Ctrl* ctrl, int* nblk_out, hipStream_t stream);
+
 // State of the caller's z when options.B is general (the loop's z buffers hold w = -B*z): after zming returned znew,
 // zprev <- z, z <- znew, zvals(:, i) = znew and -- fast ADMM -- v = z + coef*(z - zprev) (admm.m:568, 579) or the
 // restart value zprev (admm.m:586).  phase 0: state + history (+ v for alg 1, coefficient from ctrl->acurr as the fused

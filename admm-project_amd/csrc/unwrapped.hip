@@ -22,6 +22,9 @@
 // kernel runs at the bandwidth of 47 CUs.  The tiles have to be small enough for all 256 CUs to share the bytes.)
 // Partial rows are double-buffered on the parity of ctrl->iter; every sum runs in a fixed order (bitwise reproducible).
 // All loads are unconditional (clamped addresses, zero weights): a branch per load would serialise the round trips.
+#include <algorithm>
+#include <cstdlib>
+
 #include "finalize_device.h"
 #include "kernels.h"
 #include "loop_kernels.h"
@@ -232,6 +235,113 @@ void launch_uw_prox(const UwArgs& args, const ProxArgs& pargs, const Ctrl* ctrl,
   pa.rhs_add = nullptr;
   hipLaunchKernelGGL(uw_prox_kernel, dim3(static_cast<unsigned>(args.nblk)), dim3(kUwProxThreads), 0, stream, args, pa,
                      ctrl);
+}
+
+// ---------------------------------------------------------------- ONE pass over D per iteration (tall, narrow D)
+// An A = D iteration reads D twice -- D*x for the element update, D'*(c + z - u) for the next x-update -- although both
+// uses of a ROW of D belong to the same iteration: with x known, rows r0 .. r0+63 give (D x)_r, the new z_r, u_r, and
+// their contribution D_r'*(c + z - u)_r to the next right-hand side.  Where a 64-row block of D fits the registers of a
+// workgroup (n <= 448: 8 waves x 56 columns x 64 lanes), D is read ONCE: BASELINE config 3 at MNIST's full size
+// (60000 x 400: 192 MB per pass) is two such passes in the generic path.  Lane = row, wave w holds the columns
+// j = w (mod 8) of the block (every load of a lane issued before any is used: 205 KB in flight per workgroup);
+//   1. (D x)_r: per-wave partial over its columns, the eight partials summed in wave order through LDS;
+//   2. wave 0: the fused element update (prox_apply, the code every loop shares) -> t_r = (c + z - u)_r to LDS;
+//   3. every wave: column sums of D_rj t_r over the 64 rows (wave_sum), accumulated per workgroup in LDS.
+// Persistent workgroups walk the row blocks; a workgroup's partial row of the right-hand side is written once, at the
+// end, and summed (with the iteration's deferred finalize as passenger) by sum_partials_t_fin_kernel.  Requires a loop
+// that records no dual residual (unwrappedadmm.m:92 / nodualerror: no D'*(z - zprev), no D'*u) and plain ADMM.
+constexpr int kOpRows = 64, kOpWaves = 8, kOpCols = 56, kOpMaxN = kOpWaves * kOpCols;  // 448
+
+__global__ __launch_bounds__(kOpWaves* kWave) void ad_onepass_kernel(OnePassArgs a, ProxArgs pa,
+                                                                    const Ctrl* __restrict__ ctrl) {
+  if (ctrl->stop) return;
+  const int64_t it = ctrl->iter;
+  __shared__ double xs[kOpMaxN], gacc[kOpMaxN];
+  __shared__ double axr[kOpWaves][kOpRows];
+  __shared__ double tsh[kOpRows];
+  __shared__ double sred[S_COUNT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t n = a.n, m = a.m;
+  for (int j = tid; j < kOpMaxN; j += kOpWaves * kWave) {
+    xs[j] = j < n ? a.x[j] : 0.0;
+    gacc[j] = 0.0;
+  }
+  __syncthreads();
+  double acc[S_COUNT];
+#pragma unroll
+  for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
+  const int64_t nblocks = (m + kOpRows - 1) / kOpRows;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t r = blk * kOpRows + lane;
+    const int64_t rc = r < m ? r : m - 1;
+    const double* __restrict__ drow = a.D + rc;
+    double d[kOpCols];
+#pragma unroll
+    for (int k = 0; k < kOpCols; ++k) {  // clamped columns: the loads stay unconditional, x is zero beyond n
+      const int64_t j = w + kOpWaves * k;
+      d[k] = drow[(j < n ? j : n - 1) * a.ldD];
+    }
+    ProxIn in{};
+    if (w == 0) in = prox_load(pa, rc);  // in flight with the block
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < kOpCols; ++k) p = __builtin_fma(d[k], xs[w + kOpWaves * k], p);
+    axr[w][lane] = p;
+    __syncthreads();
+    if (w == 0) {
+      double ax = axr[0][lane];
+#pragma unroll
+      for (int q = 1; q < kOpWaves; ++q) ax += axr[q][lane];
+      double t = 0.0;
+      if (r < m) prox_apply(pa, r, ax, it, 0.0, in, acc, &t);
+      tsh[lane] = t;  // rows beyond m contribute nothing
+    }
+    __syncthreads();
+    const double t = tsh[lane];
+#pragma unroll
+    for (int k = 0; k < kOpCols; ++k) {
+      const double sum = wave_sum(d[k] * t);
+      const int j = w + kOpWaves * k;
+      if (lane == 0 && j < n) gacc[j] += sum;  // (each wave owns its columns)
+    }
+  }
+  __syncthreads();
+  double* __restrict__ gout = a.gpart + static_cast<int64_t>(blockIdx.x) * a.ldg;
+  for (int j = tid; j < n; j += kOpWaves * kWave) gout[j] = gacc[j];
+  if (w == 0) {  // the block partials of the residual sums: wave 0 made all of them
+#pragma unroll
+    for (int s = 0; s < S_COUNT; ++s) {
+      const double v = wave_sum(acc[s]);
+      if (lane == 0) sred[s] = v;
+    }
+    if (lane < S_COUNT) pa.part[lane * kMaxPartBlocks + blockIdx.x] = sred[lane];
+  }
+}
+
+bool onepass_supported(int64_t m, int64_t n) {
+  // (worth it where the passes over D are what an iteration costs: below ~48 MB the launches are)
+  return n >= 1 && n <= kOpMaxN && m * n * 8 >= (int64_t{48} << 20) && std::getenv("ADMM_HIP_NO_ONEPASS") == nullptr;
+}
+
+int onepass_workgroups(int64_t m) {
+  const int64_t nblocks = ceil_div(m, int64_t{kOpRows});
+  return static_cast<int>(std::min<int64_t>(nblocks, 256));  // one per CU: a block is 205 KB of registers' worth of loads
+}
+
+void launch_ad_onepass(const OnePassArgs& a, const ProxArgs& pargs, const Ctrl* ctrl, int* nblk_out, hipStream_t stream) {
+  ProxArgs pa = pargs;
+  const bool need_ell = pa.prox == PROX_HINGE || pa.prox == PROX_01 || pa.objx == OBJX_HINGE || pa.objx == OBJX_ZEROONE ||
+                        pa.objx == OBJX_DOT;
+  if (!need_ell) pa.ell = nullptr;
+  if (pa.prox != PROX_GIVEN) pa.zgiven = nullptr;
+  if (pa.prox != PROX_BOX) pa.lb = pa.ub = nullptr;
+  pa.rhs_add = nullptr;
+  pa.rhs = nullptr;  // t = c + z - u never leaves the kernel
+  pa.dz = nullptr;
+  const int nwg = onepass_workgroups(a.m);
+  *nblk_out = nwg;
+  hipLaunchKernelGGL(ad_onepass_kernel, dim3(static_cast<unsigned>(nwg)), dim3(kOpWaves * kWave), 0, stream, a, pa, ctrl);
 }
 
 }  // namespace admm

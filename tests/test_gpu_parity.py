@@ -798,6 +798,54 @@ def test_unwrapped_two_launch_iteration_matches_the_generic_path(gpu, monkeypatc
         _compare(got, ref, tol=1e-7)
 
 
+@pytest.mark.parametrize("solver,m,n,opts", [
+    ("linearsvm", 24000, 400, dict(objevals=1, maxiters=60)),                        # stops early
+    ("linearsvm", 24000, 400, dict(objevals=1, maxiters=21, domaxiters=1, record_history=0)),
+    ("linearsvm", 17011, 448, dict(lossfunction="01", maxiters=9, domaxiters=1)),    # ragged last block, widest D
+    ("linearsvm", 70000, 97, dict(objevals=1, maxiters=30, domaxiters=1)),
+    ("lad", 20000, 333, dict(objevals=1, nodualerror=1, maxiters=25, domaxiters=1)),
+    ("huberfit", 20000, 333, dict(objevals=1, nodualerror=1, maxiters=25, domaxiters=1)),
+])
+def test_one_pass_iteration_on_a_tall_narrow_matrix(gpu, monkeypatch, solver, m, n, opts):
+    """unwrapped.hip: ad_onepass_kernel -- an A = D iteration without a dual residual reads a tall, narrow D ONCE (D*x,
+    the element update and the partial rows of D'*(c + z - u) per 64-row block held in registers) instead of twice:
+    against the generic path of the same engine (ADMM_HIP_NO_ONEPASS), against the oracle, and that it is the path
+    that ran (no D*x launch of its own)."""
+    if solver == "linearsvm":
+        p = gpu.synth.mnist_like_problem(seed=2, m=m, n=n, digit=1, labels=gpu.synth.reference_mnist_labels("train"))
+        o = dict(opts, x0=p["x0"], z0=p["z0"], u0=p["u0"])
+        run = lambda: gpu.linearsvm(p["D"], p["ell"], p["C"], dict(o))
+        ref = S.linearsvm(p["D"], p["ell"], p["C"], {k: v for k, v in o.items() if k != "record_history"})
+    else:
+        p = gpu.synth.lad_problem(4, m, n)
+        o = dict(opts)
+        run = lambda: getattr(gpu, solver)(p["D"], p["s"], dict(o))
+        ref = getattr(S, solver)(p["D"], p["s"], dict(o))
+    got = run()
+    monkeypatch.setenv("ADMM_HIP_NO_ONEPASS", "1")
+    gen = run()
+    monkeypatch.delenv("ADMM_HIP_NO_ONEPASS")
+    assert got["steps"] == gen["steps"] == ref["steps"]
+    keys = ["pnorm", "perr", "xopt", "zopt", "uopt"] + (["objevals"] if opts.get("objevals") else [])
+    if opts.get("record_history", 1):
+        keys += ["xvals", "zvals", "uvals"]
+    for k in keys:
+        _close(k, got[k], gen[k], 1e-9)
+        if opts.get("lossfunction") != "01":  # (the 0-1 prox is discontinuous, q24: the two device paths agree)
+            _close(k, got[k], ref[k], 1e-7)
+    assert np.isnan(got["dnorm"]).all()
+    # the path: an engine of the same shape, event-timed -- the one-pass iteration launches no D*x kernel
+    L = gpu._lib
+    if solver == "linearsvm":
+        eng = gpu.Engine(L.PROB_LINEARSVM, D=p["D"], ell=p["ell"], Cval=p["C"])
+    else:
+        eng = gpu.Engine(L.PROB_LAD if solver == "lad" else L.PROB_HUBERFIT, D=p["D"], s=p["s"])
+    eng.set_profiling([L.K_GEMV_N, L.K_PROX])
+    eng.run(maxiters=5, domaxiters=1, record_history=0, nodualerror=1)
+    assert eng.kernel_time(L.K_GEMV_N)[1] == 0 and eng.kernel_time(L.K_PROX)[1] == 5
+    eng.close()
+
+
 @pytest.mark.parametrize("opts", [dict(), dict(objevals=1, maxiters=40), dict(fast=1, fasttype="strong", maxiters=60),
                                   dict(relax=1.6, stopcond="both", maxiters=50), dict(convtest=1, stopcond="hnorm"),
                                   dict(maxiters=13, domaxiters=1), dict(record_history=0, maxiters=70)])
