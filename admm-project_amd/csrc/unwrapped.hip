@@ -29,6 +29,7 @@
 #include "kernels.h"
 #include "loop_kernels.h"
 #include "prox_device.h"
+#include "wave_reduce.h"
 
 namespace admm {
 
@@ -246,7 +247,9 @@ void launch_uw_prox(const UwArgs& args, const ProxArgs& pargs, const Ctrl* ctrl,
 // j = w (mod 8) of the block (every load of a lane issued before any is used: 205 KB in flight per workgroup);
 //   1. (D x)_r: per-wave partial over its columns, the eight partials summed in wave order through LDS;
 //   2. wave 0: the fused element update (prox_apply, the code every loop shares) -> t_r = (c + z - u)_r to LDS;
-//   3. every wave: column sums of D_rj t_r over the 64 rows (wave_sum), accumulated per workgroup in LDS.
+//   3. every wave: column sums of D_rj t_r over the 64 rows -- four at a time by the permlane / DPP reduce-scatter of
+//      the symmetric x-solve (56 __shfl_down sums per wave and block made the kernel slower than the two passes it
+//      replaces: 113 against 79 us per iteration at 60000 x 400) --, accumulated per workgroup in LDS.
 // Persistent workgroups walk the row blocks; a workgroup's partial row of the right-hand side is written once, at the
 // end, and summed (with the iteration's deferred finalize as passenger) by sum_partials_t_fin_kernel.  Requires a loop
 // that records no dual residual (unwrappedadmm.m:92 / nodualerror: no D'*(z - zprev), no D'*u) and plain ADMM.
@@ -299,11 +302,15 @@ __global__ __launch_bounds__(kOpWaves* kWave) void ad_onepass_kernel(OnePassArgs
     }
     __syncthreads();
     const double t = tsh[lane];
+    static_assert(kOpCols % kSyPanel == 0, "column sums are taken four at a time");
 #pragma unroll
-    for (int k = 0; k < kOpCols; ++k) {
-      const double sum = wave_sum(d[k] * t);
-      const int j = w + kOpWaves * k;
-      if (lane == 0 && j < n) gacc[j] += sum;  // (each wave owns its columns)
+    for (int k = 0; k < kOpCols; k += kSyPanel) {  // four column sums per permlane / DPP reduce-scatter (wave_reduce.h)
+      double q[kSyPanel];
+#pragma unroll
+      for (int c = 0; c < kSyPanel; ++c) q[c] = d[k + c] * t;
+      const double sum = reduce_scatter4(q);  // lanes 16c .. 16c+15 hold the sum of column k + c
+      const int j = w + kOpWaves * (k + (lane >> 4));
+      if ((lane & 15) == 0 && j < n) gacc[j] += sum;  // (each wave owns its columns)
     }
   }
   __syncthreads();

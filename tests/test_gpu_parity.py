@@ -802,7 +802,7 @@ def test_unwrapped_two_launch_iteration_matches_the_generic_path(gpu, monkeypatc
     ("linearsvm", 24000, 400, dict(objevals=1, maxiters=60)),                        # stops early
     ("linearsvm", 24000, 400, dict(objevals=1, maxiters=21, domaxiters=1, record_history=0)),
     ("linearsvm", 17011, 448, dict(lossfunction="01", maxiters=9, domaxiters=1)),    # ragged last block, widest D
-    ("linearsvm", 70000, 97, dict(objevals=1, maxiters=30, domaxiters=1)),
+    ("linearsvm", 60000, 120, dict(objevals=1, maxiters=30, domaxiters=1)),
     ("lad", 20000, 333, dict(objevals=1, nodualerror=1, maxiters=25, domaxiters=1)),
     ("huberfit", 20000, 333, dict(objevals=1, nodualerror=1, maxiters=25, domaxiters=1)),
 ])
