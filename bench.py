@@ -371,16 +371,25 @@ def _svm_configs(ap, L, device, res):
         s = svm.run(**kw)
         dt = time.perf_counter() - t0
         mb = 16.0 * m * 400 / 1e6
+        cls = profile_classes(svm, L, lambda: svm.run(**dict(kw, maxiters=64)))
+        two_launch = bool(svm.info()["unwrapped_fused"])
+        one_pass = not two_launch and "gemv_n" not in cls  # (unwrapped.hip: ad_onepass_kernel launches no D*x of its own)
         res[f"linearsvm_{m}x400"] = {"iters_per_s": s.steps / dt, "ms_per_step": dt / s.steps * 1e3,
                                      "algorithmic_MB_per_iter": mb,
                                      "achieved_GBs": mb * 1e6 * s.steps / dt / 1e9,
                                      "frac": mb * 1e6 * s.steps / dt / 1e9 / HBM_PEAK_GBS,
-                                     "two_launch_iteration": bool(svm.info()["unwrapped_fused"]),
+                                     "two_launch_iteration": two_launch, "one_pass_iteration": one_pass,
                                      "note": ("D and pinv(D) (2 x %.0f MB) sit in the 256 MB Infinity Cache: latency-bound, "
                                               "the fraction is an effective rate" % (mb / 2)) if mb < 200 else
+                                             ("the unit is the iteration's two products D*x and D'*(c + z - u) "
+                                              "(2 x %.0f MB); the one-pass kernel READS D once per iteration (64-row "
+                                              "blocks held in registers serve both products): in bytes actually moved "
+                                              "the rate is half the figure" % (mb / 2)) if one_pass else
                                              ("D (%.0f MB) is read twice per iteration (D*x, D'*[..]) and only partly "
                                               "cache-resident: effective rate of both passes" % (mb / 2))}
-        res[f"linearsvm_{m}x400"]["kernel_classes"] = profile_classes(svm, L, lambda: svm.run(**dict(kw, maxiters=64)))
+        if one_pass:
+            res[f"linearsvm_{m}x400"]["frac_of_bytes_read"] = 0.5 * res[f"linearsvm_{m}x400"]["frac"]
+        res[f"linearsvm_{m}x400"]["kernel_classes"] = cls
         svm.close()
 
 
