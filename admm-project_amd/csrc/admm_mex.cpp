@@ -147,93 +147,75 @@ mxArray* staged_vector(const double* dev, size_t n, void* stream) {
   return a;
 }
 
-int prox_thunk(void* user, const double* x, const double* z, const double* u, double rho, double* out, int64_t nout,
-               void* stream) {
-  Thunk* t = static_cast<Thunk*>(user);
-  mxArray* rhs[5] = {t->fh, staged_vector(x, t->nfirst, stream), staged_vector(z, t->nB, stream),
-                     staged_vector(u, t->nU, stream), mxCreateDoubleScalar(rho)};
-  mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2] && rhs[3]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
-  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
-    t->failure = "a proximal-operator handle returned something that is not a full real vector of the expected length";
-    rc = 1;
+// out[0 .. nout) = feval(handle, in_0, ..., in_(nin-1) [, scalar]): device vectors staged down, the result staged up.
+// exact: the result must be a full real vector of exactly nout values (else: of at least nout; nout = 1: any numeric
+// scalar).  `what` names the handle in the failure text.
+struct StagedIn {
+  const double* dev;
+  size_t n;
+};
+int staged_call(Thunk* t, const StagedIn* in, int nin, const double* scalar, double* out, size_t nout, bool exact,
+                const char* what, void* stream) {
+  mxArray* rhs[6] = {t->fh, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int nrhs = 1, rc = 0;
+  for (int k = 0; k < nin; ++k, ++nrhs) {
+    rhs[nrhs] = staged_vector(in[k].dev, in[k].n, stream);
+    if (!rhs[nrhs]) rc = 1;
   }
-  if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), static_cast<size_t>(nout) * sizeof(double), stream);
-  for (int k = 1; k < 5; ++k)
+  if (scalar) rhs[nrhs++] = mxCreateDoubleScalar(*scalar);
+  mxArray* lhs[1] = {nullptr};
+  if (rc == 0) rc = call_handle(t, 1, lhs, nrhs, rhs);
+  if (rc == 0) {
+    const size_t got = lhs[0] ? mxGetNumberOfElements(lhs[0]) : 0;
+    const bool scalar_ok = nout == 1 && got == 1 && (mxIsNumeric(lhs[0]) || mxIsLogical(lhs[0]));
+    if (!scalar_ok && (!is_dense_double(lhs[0]) || (exact ? got != nout : got < nout))) {
+      t->failure = std::string(what) + " returned something that is not a full real vector of the expected length";
+      rc = 1;
+    } else if (scalar_ok) {
+      const double v = mxGetScalar(lhs[0]);
+      rc = admm_memcpy_h2d(out, &v, sizeof(double), stream);
+    } else {
+      rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), nout * sizeof(double), stream);
+    }
+  }
+  for (int k = 1; k < nrhs; ++k)
     if (rhs[k]) mxDestroyArray(rhs[k]);
   if (lhs[0]) mxDestroyArray(lhs[0]);
   return rc;
 }
 
-// options.A / At / B as MATLAB function handles of a single vector (admm.m:117-158, 206-216)
-int op_thunk(void* user, const double* in, int64_t nin, double* out, int64_t nout, void* stream) {
+int prox_thunk(void* user, const double* x, const double* z, const double* u, double rho, double* out, int64_t nout,
+               void* stream) {
   Thunk* t = static_cast<Thunk*>(user);
-  mxArray* rhs[2] = {t->fh, staged_vector(in, static_cast<size_t>(nin), stream)};
-  mxArray* lhs[1] = {nullptr};
-  int rc = rhs[1] ? call_handle(t, 1, lhs, 2, rhs) : 1;
-  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != static_cast<size_t>(nout))) {
-    t->failure = "a constraint-operator handle (A, At or B) returned something that is not a full real vector of the "
-                 "expected length";
-    rc = 1;
-  }
-  if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), static_cast<size_t>(nout) * sizeof(double), stream);
-  if (rhs[1]) mxDestroyArray(rhs[1]);
-  if (lhs[0]) mxDestroyArray(lhs[0]);
-  return rc;
+  const StagedIn in[3] = {{x, t->nfirst}, {z, t->nB}, {u, t->nU}};
+  return staged_call(t, in, 3, &rho, out, static_cast<size_t>(nout), true, "a proximal-operator handle", stream);
+}
+
+// options.A / At / B as MATLAB function handles of a single vector (admm.m:117-158, 206-216)
+int op_thunk(void* user, const double* v, int64_t nin, double* out, int64_t nout, void* stream) {
+  const StagedIn in[1] = {{v, static_cast<size_t>(nin)}};
+  return staged_call(static_cast<Thunk*>(user), in, 1, nullptr, out, static_cast<size_t>(nout), true,
+                     "a constraint-operator handle (A, At or B)", stream);
 }
 
 // options.altu(u, Ax, Bz, c) and options.specialnorms(x, z, u, rho) as MATLAB handles (admm.m:553-559, 612-616)
 int altu_thunk(void* user, const double* u, const double* ax, const double* bz, const double* c, int64_t m, double* out,
                void* stream) {
-  Thunk* t = static_cast<Thunk*>(user);
   const size_t n = static_cast<size_t>(m);
-  mxArray* rhs[5] = {t->fh, staged_vector(u, n, stream), staged_vector(ax, n, stream), staged_vector(bz, n, stream),
-                     staged_vector(c, n, stream)};
-  mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2] && rhs[3] && rhs[4]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
-  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) != n)) {
-    t->failure = "options.altu returned something that is not a full real vector of the length of u";
-    rc = 1;
-  }
-  if (rc == 0) rc = admm_memcpy_h2d(out, mxGetPr(lhs[0]), n * sizeof(double), stream);
-  for (int k = 1; k < 5; ++k)
-    if (rhs[k]) mxDestroyArray(rhs[k]);
-  if (lhs[0]) mxDestroyArray(lhs[0]);
-  return rc;
+  const StagedIn in[4] = {{u, n}, {ax, n}, {bz, n}, {c, n}};
+  return staged_call(static_cast<Thunk*>(user), in, 4, nullptr, out, n, true, "options.altu", stream);
 }
 
 int norms_thunk(void* user, const double* x, int64_t nA, const double* z, int64_t nB, const double* u, int64_t m,
                 double rho, double* out2, void* stream) {
-  Thunk* t = static_cast<Thunk*>(user);
-  mxArray* rhs[5] = {t->fh, staged_vector(x, static_cast<size_t>(nA), stream), staged_vector(z, static_cast<size_t>(nB), stream),
-                     staged_vector(u, static_cast<size_t>(m), stream), mxCreateDoubleScalar(rho)};
-  mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2] && rhs[3]) ? call_handle(t, 1, lhs, 5, rhs) : 1;
-  if (rc == 0 && (!is_dense_double(lhs[0]) || mxGetNumberOfElements(lhs[0]) < 2)) {
-    t->failure = "options.specialnorms must return a vector of two values (admm.m:613-616)";
-    rc = 1;
-  }
-  if (rc == 0) rc = admm_memcpy_h2d(out2, mxGetPr(lhs[0]), 2 * sizeof(double), stream);
-  for (int k = 1; k < 5; ++k)
-    if (rhs[k]) mxDestroyArray(rhs[k]);
-  if (lhs[0]) mxDestroyArray(lhs[0]);
-  return rc;
+  const StagedIn in[3] = {{x, static_cast<size_t>(nA)}, {z, static_cast<size_t>(nB)}, {u, static_cast<size_t>(m)}};
+  return staged_call(static_cast<Thunk*>(user), in, 3, &rho, out2, 2, false, "options.specialnorms (two values, admm.m:613-616)",
+                     stream);
 }
 
 int obj_thunk(void* user, const double* x, int64_t nA, const double* z, int64_t nB, double* out, void* stream) {
-  Thunk* t = static_cast<Thunk*>(user);
-  mxArray* rhs[3] = {t->fh, staged_vector(x, static_cast<size_t>(nA), stream), staged_vector(z, static_cast<size_t>(nB), stream)};
-  mxArray* lhs[1] = {nullptr};
-  int rc = (rhs[1] && rhs[2]) ? call_handle(t, 1, lhs, 3, rhs) : 1;
-  if (rc == 0 && (!lhs[0] || mxGetNumberOfElements(lhs[0]) != 1)) rc = 1;
-  if (rc == 0) {
-    const double v = mxGetScalar(lhs[0]);
-    rc = admm_memcpy_h2d(out, &v, sizeof(double), stream);
-  }
-  for (int k = 1; k < 3; ++k)
-    if (rhs[k]) mxDestroyArray(rhs[k]);
-  if (lhs[0]) mxDestroyArray(lhs[0]);
-  return rc;
+  const StagedIn in[2] = {{x, static_cast<size_t>(nA)}, {z, static_cast<size_t>(nB)}};
+  return staged_call(static_cast<Thunk*>(user), in, 2, nullptr, out, 1, true, "options.obj", stream);
 }
 
 // ---- results ----------------------------------------------------------------------------------------------------
