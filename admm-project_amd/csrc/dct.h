@@ -17,6 +17,9 @@ struct DctTables {        // device tables of one transform length n (= 2^log2n,
   int32_t bm, log2bm;          // 0: plain power-of-two network
   const admm_double2* chirp;   // c_j = e^{-pi i j^2 / n}, j < n
   const admm_double2* hbr;     // FFT_bm of h_m = conj(c_|m|) (wrapped), at the network's output positions, times 1/bm
+  // the column kernels transform two real columns as one complex sequence; an odd width leaves one column without a
+  // partner: pair `odd_pair` (set by the launchers, -1 otherwise) takes its single column twice
+  int32_t odd_pair;
 };
 
 // host side of the tables (long double trigonometry); buffers have n/2, n/2 + 1 and n entries

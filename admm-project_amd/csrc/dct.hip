@@ -201,7 +201,7 @@ __device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, 
                                                       unsigned pair) {
   extern __shared__ c64 zs[];
   double* a = img + static_cast<int64_t>(2 * pair) * H;
-  double* b = a + H;
+  double* b = (static_cast<int32_t>(pair) == t.odd_pair) ? a : a + H;  // (an odd width's last column: both halves of the pair)
   load_pair(zs, a, b, t.n);
   __syncthreads();
   dct_forward_from_lds(zs, a, b, t);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
   double acc[S_COUNT];
 #pragma unroll
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-  const int64_t npairs = W >> 1;
+  const int64_t npairs = (W + 1) >> 1;  // (an odd width: the last pair is its single column twice)
   // Neighbouring pairs share two columns of x and one of v (the stencil's halo).  Workgroup b runs on XCD b mod 8
   // (round-robin placement; speed only): within every 64 consecutive pairs, XCD c takes the 8 adjacent pairs
   // [8c, 8c + 8), so that seven of eight halos are hits in its own L2 while all XCDs still work inside one 128-column
@@ -248,24 +248,30 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
         int64_t base[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {  // both columns' loads before either update
-          const int64_t j = j0 + c;
+          const int64_t j = (j0 + c < W) ? j0 + c : j0;
           base[c] = j * H + row0;
           const int64_t lbase = j > 0 ? base[c] - H : base[c], rbase = j < W - 1 ? base[c] + H : base[c];
           tv2px_load<VIN>(a, N, base[c], lbase, rbase, tid, o_up, o_dn, px[c]);
         }
         const int k = static_cast<int>(i >> 1);
         const int pos = swz((i & 1) ? n - 1 - k : k);  // Makhoul order: x[2k] -> v[k], x[2k+1] -> v[n-1-k]
+        double bv0 = 0.0;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int64_t j = j0 + c;
-          const double bv = tv2px_apply<VIN>(a, N, it, base[c], tid, hasv, up, j < W - 1, j > 0, px[c], acc);
-          reinterpret_cast<double*>(&zs[pos])[c] = bv;
+          if (j < W) {  // (uniform)
+            const double bv = tv2px_apply<VIN>(a, N, it, base[c], tid, hasv, up, j < W - 1, j > 0, px[c], acc);
+            if (c == 0) bv0 = bv;
+            reinterpret_cast<double*>(&zs[pos])[c] = bv;
+          } else {
+            reinterpret_cast<double*>(&zs[pos])[c] = bv0;
+          }
         }
       }
     }
     __syncthreads();
     double* ca = bhat + j0 * H;
-    dct_forward_from_lds(zs, ca, ca + H, t);
+    dct_forward_from_lds(zs, ca, (j0 + 1 < W) ? ca + H : ca, t);
     __syncthreads();  // zs is the next pair's
   }
   tv2_block_partials_lds(acc, a.part);
@@ -298,8 +304,9 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   if (ctrl->stop) return;
   extern __shared__ c64 zs[];
   const int n = t.n, p = t.log2n;
+  const bool odd = static_cast<int32_t>(blockIdx.x) == t.odd_pair;
   const double* a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
-  const double* b = a + H;
+  const double* b = odd ? a : a + H;
   // coefficient pairs (k, n - k), 0 <= k < n/2: kInvQ of them per thread and round, every load of a round issued before
   // any is used (clamped indices, no branches around loads: with the loads inside the three cases of the loop body the
   // kernel fetched two pairs per round trip -- four dependent trips for a 4096-point column pair)
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void dct_cols_inverse_kernel(const double* 
   __syncthreads();
   fft_network<true>(zs, n, p, t.tw);
   double* oa = dst + static_cast<int64_t>(2 * blockIdx.x) * H;
-  store_pair(zs, oa, oa + H, n, 1.0 / static_cast<double>(n));
+  store_pair(zs, oa, odd ? oa : oa + H, n, 1.0 / static_cast<double>(n));
 }
 
 // ---------------------------------------------------------------- column transforms of ANY length (chirp form)
@@ -378,8 +385,8 @@ __global__ __launch_bounds__(kChirpMaxThreads) void dct_cols_forward_chirp_kerne
   extern __shared__ c64 zs[];
   const int n = t.n, M = t.bm;
   const unsigned pair = blockIdx.x - (FIN ? 1u : 0u);
-  double* __restrict__ a = img + static_cast<int64_t>(2 * pair) * H;
-  double* __restrict__ b = a + H;
+  double* a = img + static_cast<int64_t>(2 * pair) * H;
+  double* b = (static_cast<int32_t>(pair) == t.odd_pair) ? a : a + H;
   for (int j = threadIdx.x; j < M; j += blockDim.x) {  // v_j c_j in Makhoul order, zeros behind
     c64 y{0.0, 0.0};
     if (j < n) {
@@ -409,8 +416,9 @@ __global__ __launch_bounds__(kChirpMaxThreads) void dct_cols_inverse_chirp_kerne
   if (ctrl->stop) return;
   extern __shared__ c64 zs[];
   const int n = t.n, M = t.bm;
-  const double* __restrict__ a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
-  const double* __restrict__ b = a + H;
+  const bool odd = static_cast<int32_t>(blockIdx.x) == t.odd_pair;
+  const double* a = src + static_cast<int64_t>(2 * blockIdx.x) * H;
+  const double* b = odd ? a : a + H;
   for (int k = threadIdx.x; k < M; k += blockDim.x) {  // Z_k conj(c_k), zeros behind
     c64 y{0.0, 0.0};
     if (k < n) {
@@ -426,8 +434,8 @@ __global__ __launch_bounds__(kChirpMaxThreads) void dct_cols_inverse_chirp_kerne
     zs[swz(k)] = y;
   }
   chirp_convolve(zs, t, true);
-  double* __restrict__ oa = dst + static_cast<int64_t>(2 * blockIdx.x) * H;
-  double* __restrict__ ob = oa + H;
+  double* oa = dst + static_cast<int64_t>(2 * blockIdx.x) * H;
+  double* ob = odd ? oa : oa + H;
   const double scale = 1.0 / static_cast<double>(n);
   for (int j = threadIdx.x; j < n; j += blockDim.x) {  // x_j = v_(pos(j)),  v = conj(c) * convolution / n
     const int v = makhoul_pos(j, n);
@@ -656,6 +664,12 @@ void dct_fill_chirp_tables(int32_t n, admm_double2* tw, admm_double2* c4, double
 }
 
 static size_t dct_lds_bytes(int n) { return sizeof(c64) * static_cast<size_t>(n); }
+static unsigned col_pairs(int64_t W) { return static_cast<unsigned>((W + 1) / 2); }
+static DctTables with_pairs(const DctTables& th, int64_t W) {  // the tables as a launch over the columns of a W-wide image sees them
+  DctTables t = th;
+  t.odd_pair = (W & 1) ? static_cast<int32_t>(W / 2) : -1;
+  return t;
+}
 
 // n = 8192 needs 128 KB of the CU's 160 KB LDS (one workgroup per CU): beyond the 64 KB a launch gets by default
 template <typename K>
@@ -665,20 +679,21 @@ static void dct_allow_lds(K kernel, size_t bytes) {
 
 void launch_dct_cols_forward(double* img, int64_t H, int64_t W, const DctTables& th, const Ctrl* ctrl,
                              hipStream_t stream) {
+  const DctTables t2 = with_pairs(th, W);
   if (th.bm) {
     dct_allow_lds(dct_cols_forward_chirp_kernel<false>, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<false>, dim3(static_cast<unsigned>(W / 2)), dim3(chirp_threads(th.bm)),
-                       dct_lds_bytes(th.bm), stream, img, H, th, FinArgs{}, 0, ctrl);
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<false>, dim3(col_pairs(W)), dim3(chirp_threads(th.bm)),
+                       dct_lds_bytes(th.bm), stream, img, H, t2, FinArgs{}, 0, ctrl);
     return;
   }
   dct_allow_lds(dct_cols_forward_kernel, dct_lds_bytes(th.n));
-  hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
-                     stream, img, H, th, ctrl);
+  hipLaunchKernelGGL(dct_cols_forward_kernel, dim3(col_pairs(W)), dim3(kBlock), dct_lds_bytes(th.n), stream, img, H, t2,
+                     ctrl);
 }
 
 void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const DctTables& th, const Ctrl* ctrl,
                            int* nblk_out, hipStream_t stream) {
-  int64_t nb = a.W / 2;
+  int64_t nb = (a.W + 1) / 2;
   if (nb > kMaxPartBlocks) nb = kMaxPartBlocks;  // (a workgroup then walks several pairs: one set of partials each)
   *nblk_out = static_cast<int>(nb);
   const size_t lds = dct_lds_bytes(th.n);
@@ -693,28 +708,30 @@ void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const 
 
 void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
                                  bool fin_pending, const Ctrl* ctrl, hipStream_t stream) {
+  const DctTables t2 = with_pairs(th, W);
   if (th.bm) {
     dct_allow_lds(dct_cols_forward_chirp_kernel<true>, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<true>, dim3(static_cast<unsigned>(W / 2) + 1u),
-                       dim3(chirp_threads(th.bm)), dct_lds_bytes(th.bm), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
+    hipLaunchKernelGGL(dct_cols_forward_chirp_kernel<true>, dim3(col_pairs(W) + 1u), dim3(chirp_threads(th.bm)),
+                       dct_lds_bytes(th.bm), stream, img, H, t2, f, fin_pending ? 1 : 0, ctrl);
     return;
   }
   dct_allow_lds(dct_cols_forward_fin_kernel, dct_lds_bytes(th.n));
-  hipLaunchKernelGGL(dct_cols_forward_fin_kernel, dim3(static_cast<unsigned>(W / 2) + 1u), dim3(kBlock),
-                     dct_lds_bytes(th.n), stream, img, H, th, f, fin_pending ? 1 : 0, ctrl);
+  hipLaunchKernelGGL(dct_cols_forward_fin_kernel, dim3(col_pairs(W) + 1u), dim3(kBlock), dct_lds_bytes(th.n), stream, img, H,
+                     t2, f, fin_pending ? 1 : 0, ctrl);
 }
 
 void launch_dct_cols_inverse(const double* src, double* dst, int64_t H, int64_t W, const DctTables& th,
                              const Ctrl* ctrl, hipStream_t stream) {
+  const DctTables t2 = with_pairs(th, W);
   if (th.bm) {
     dct_allow_lds(dct_cols_inverse_chirp_kernel, dct_lds_bytes(th.bm));
-    hipLaunchKernelGGL(dct_cols_inverse_chirp_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(chirp_threads(th.bm)),
-                       dct_lds_bytes(th.bm), stream, src, dst, H, th, ctrl);
+    hipLaunchKernelGGL(dct_cols_inverse_chirp_kernel, dim3(col_pairs(W)), dim3(chirp_threads(th.bm)), dct_lds_bytes(th.bm),
+                       stream, src, dst, H, t2, ctrl);
     return;
   }
   dct_allow_lds(dct_cols_inverse_kernel, dct_lds_bytes(th.n));
-  hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(static_cast<unsigned>(W / 2)), dim3(kBlock), dct_lds_bytes(th.n),
-                     stream, src, dst, H, th, ctrl);
+  hipLaunchKernelGGL(dct_cols_inverse_kernel, dim3(col_pairs(W)), dim3(kBlock), dct_lds_bytes(th.n), stream, src, dst, H, t2,
+                     ctrl);
 }
 
 void launch_dct_rows_solve(double* t, int64_t H, int64_t W, double rho, const DctTables& th, const DctTables& tw,

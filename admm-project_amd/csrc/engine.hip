@@ -803,7 +803,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // (a height that is not a power of two takes the chirp form of the column transform, dct.hip: any height up to 4096)
   const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
                             (dct_length_ok(desc->m) || dct_chirp_length_ok(desc->m)) &&
-                            (dct_length_ok(desc->n) || (desc->n >= 64 && desc->n % 2 == 0));  // (the column DCT takes column pairs)
+                            (dct_length_ok(desc->n) || desc->n >= 64);  // (any width the row stage's truncation fits: run())
   if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)
@@ -1239,6 +1239,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
         auto tables = [&](int64_t len, DctTables* t) -> int {
           const int32_t L = static_cast<int32_t>(len);
           *t = DctTables{};
+          t->odd_pair = -1;
           if (!dct_length_ok(L)) {  // chirp form: an FFT of length M >= 2L - 1 behind every column pair
             const int32_t M = dct_chirp_fft_length(L);
             std::vector<admm_double2> tw(static_cast<size_t>(M / 2)), c4(static_cast<size_t>(L)), ch(static_cast<size_t>(L)),

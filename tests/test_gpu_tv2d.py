@@ -90,11 +90,11 @@ def test_tv2d_fast_admm(gpu, H, W, opts):
 
 
 @pytest.mark.parametrize("H,W,rho,spectral", [(32, 200, 1.0, True), (64, 334, 0.5, True), (16, 1000, 2.0, True),
-                                              (32, 100, 1.0, False), (32, 300, 10.0, False), (64, 333, 0.5, False)])
+                                              (32, 100, 1.0, False), (32, 300, 10.0, False), (64, 333, 0.5, True)])
 def test_tv2d_any_width_when_the_height_is_a_power_of_two(gpu, H, W, rho, spectral):
     """the row stage of the spectral solve is the Toeplitz kernel of the row operator (no row transform), so only the
     height has to be a power of two -- while the kernel's truncation (42 terms per side at rho = 1) is well inside the
-    width and the width is even (the column DCT takes column pairs); otherwise the solve falls back to CG"""
+    width (an odd width's last column is both halves of its column pair); otherwise the solve falls back to CG"""
     img = _image(H + W, H, W)
     o = dict(objevals=1, rho=rho, maxiters=30)
     got = gpu.totalvariation2d(img, 0.5, dict(o))
@@ -123,6 +123,22 @@ def test_tv2d_any_height_through_the_chirp_transform(gpu, H, W, rho):
     rstop = S.totalvariation2d(img, 0.4, dict(objevals=1, rho=rho, stopcond="both", maxiters=80))
     assert stop["steps"] == rstop["steps"]
     _close("xopt", stop["xopt"], rstop["xopt"], 1e-9)
+
+
+@pytest.mark.parametrize("H,W,opts", [(256, 255, dict(objevals=1, maxiters=14, domaxiters=1)),           # glued kernel
+                                      (64, 513, dict(objevals=1, stopcond="both", maxiters=80)),
+                                      (100, 333, dict(objevals=1, maxiters=10, domaxiters=1)),            # chirp transform
+                                      (2048, 201, dict(maxiters=6, domaxiters=1, record_history=0))])
+def test_tv2d_odd_widths(gpu, H, W, opts):
+    """the column kernels transform two real columns as one complex sequence; an odd width's last column is both halves
+    of its pair (same values written twice) -- spectral x-update, against the oracle"""
+    img = _image(H + 11 * W, H, W)
+    got = gpu.totalvariation2d(img, 0.5, dict(opts))
+    ref = S.totalvariation2d(img, 0.5, {k: v for k, v in opts.items() if k != "record_history"})
+    assert got["steps"] == ref["steps"] and got["cg_iters_total"] == 0
+    keys = ("xopt", "zopt", "uopt", "pnorm", "dnorm", "perr", "derr") + (("objevals",) if opts.get("objevals") else ())
+    for k in keys + (("xvals", "zvals", "uvals") if opts.get("record_history", 1) else ()):
+        _close(k, got[k], ref[k], 1e-9)
 
 
 @pytest.mark.parametrize("H,W,iters", [(64, 64, 1), (64, 64, 2), (64, 64, 7), (40, 33, 2), (128, 96, 12)])
