@@ -214,7 +214,7 @@ __device__ __forceinline__ void dct_cols_forward_body(double* __restrict__ img, 
 // the FFT's LDS image at its Makhoul position, transforms, and stores the coefficients where the row stage expects
 // them.  Against the two kernels it replaces: one write and one read of the image less per iteration (11 N doubles
 // instead of 13 N), one launch less.
-template <bool VIN>
+template <bool VIN, bool ODDW>
 __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, double* __restrict__ bhat, DctTables t,
                                                                 const Ctrl* __restrict__ ctrl) {
   if (ctrl->stop) return;
@@ -226,7 +226,10 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
   double acc[S_COUNT];
 #pragma unroll
   for (int s = 0; s < S_COUNT; ++s) acc[s] = 0.0;
-  const int64_t npairs = (W + 1) >> 1;  // (an odd width: the last pair is its single column twice)
+  // ODDW (an odd width): the last pair is its single column twice.  A separate instantiation: the even-width body has
+  // no control flow between the loads of its two columns and their updates (with the uniform branch of the odd form in
+  // it the launch took 241 instead of 215 us at 4096^2)
+  const int64_t npairs = ODDW ? (W + 1) >> 1 : W >> 1;
   // Neighbouring pairs share two columns of x and one of v (the stencil's halo).  Workgroup b runs on XCD b mod 8
   // (round-robin placement; speed only): within every 64 consecutive pairs, XCD c takes the 8 adjacent pairs
   // [8c, 8c + 8), so that seven of eight halos are hits in its own L2 while all XCDs still work inside one 128-column
@@ -238,29 +241,41 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
     const int64_t b = w & 63;
     const int64_t pair = xcd_groups ? (w - b) + (b & 7) * 8 + (b >> 3) : w;
     const int64_t j0 = 2 * pair;
-    for (int64_t row0 = 0; row0 < H; row0 += kBlock) {
-      const int64_t i = row0 + tid;
-      if (i < H) {
-        const bool hasv = i < H - 1, up = i > 0;
-        const uint32_t o_up = up ? tid : tid + 1;  // relative to the element before the chunk: own row when there is none
-        const uint32_t o_dn = hasv ? tid + 1 : tid;
-        Tv2Px px[2];
-        int64_t base[2];
+    // NC row chunks of kBlock rows per round, the loads of all of them (2 columns x 10 values each) issued before any
+    // update: a column pair is a chain of H / (NC*kBlock) dependent round trips to memory, and two workgroups per CU
+    // (64 KB of LDS each at H = 4096) do not hide them
+    auto rows = [&](auto nc_tag, int64_t row0) {
+      constexpr int NC = decltype(nc_tag)::value;
+      Tv2Px px[NC][2];
+      int64_t base[NC][2];
+      uint32_t o_up[NC], o_dn[NC];
+      bool hasv[NC], up[NC];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {  // both columns' loads before either update
-          const int64_t j = (j0 + c < W) ? j0 + c : j0;
-          base[c] = j * H + row0;
-          const int64_t lbase = j > 0 ? base[c] - H : base[c], rbase = j < W - 1 ? base[c] + H : base[c];
-          tv2px_load<VIN>(a, N, base[c], lbase, rbase, tid, o_up, o_dn, px[c]);
+      for (int h = 0; h < NC; ++h) {
+        const int64_t r0 = row0 + h * kBlock, i = r0 + tid;
+        hasv[h] = i < H - 1;
+        up[h] = i > 0;
+        o_up[h] = up[h] ? tid : tid + 1;  // relative to the element before the chunk: own row when there is none
+        o_dn[h] = hasv[h] ? tid + 1 : tid;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int64_t j = (!ODDW || j0 + c < W) ? j0 + c : j0;
+          base[h][c] = j * H + r0;
+          const int64_t lbase = j > 0 ? base[h][c] - H : base[h][c], rbase = j < W - 1 ? base[h][c] + H : base[h][c];
+          tv2px_load<VIN>(a, N, base[h][c], lbase, rbase, tid, o_up[h], o_dn[h], px[h][c]);
         }
+      }
+#pragma unroll
+      for (int h = 0; h < NC; ++h) {
+        const int64_t i = row0 + h * kBlock + tid;
         const int k = static_cast<int>(i >> 1);
         const int pos = swz((i & 1) ? n - 1 - k : k);  // Makhoul order: x[2k] -> v[k], x[2k+1] -> v[n-1-k]
         double bv0 = 0.0;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int64_t j = j0 + c;
-          if (j < W) {  // (uniform)
-            const double bv = tv2px_apply<VIN>(a, N, it, base[c], tid, hasv, up, j < W - 1, j > 0, px[c], acc);
+          if (!ODDW || j < W) {  // (uniform)
+            const double bv = tv2px_apply<VIN>(a, N, it, base[h][c], tid, hasv[h], up[h], j < W - 1, j > 0, px[h][c], acc);
             if (c == 0) bv0 = bv;
             reinterpret_cast<double*>(&zs[pos])[c] = bv;
           } else {
@@ -268,10 +283,16 @@ __global__ __launch_bounds__(kBlock) void tv2d_fused_dct_kernel(Tv2Args a, doubl
           }
         }
       }
+    };
+    if (H >= 2 * kBlock) {  // (H is a power of two: whole double chunks)
+      for (int64_t row0 = 0; row0 < H; row0 += 2 * kBlock) rows(std::integral_constant<int, 2>{}, row0);
+    } else {
+      for (int64_t row0 = 0; row0 < H; row0 += kBlock)
+        if (row0 + tid < H) rows(std::integral_constant<int, 1>{}, row0);
     }
     __syncthreads();
     double* ca = bhat + j0 * H;
-    dct_forward_from_lds(zs, ca, (j0 + 1 < W) ? ca + H : ca, t);
+    dct_forward_from_lds(zs, ca, (!ODDW || j0 + 1 < W) ? ca + H : ca, t);
     __syncthreads();  // zs is the next pair's
   }
   tv2_block_partials_lds(acc, a.part);
@@ -697,13 +718,13 @@ void launch_tv2d_fused_dct(const Tv2Args& a, bool state_in, double* bhat, const 
   if (nb > kMaxPartBlocks) nb = kMaxPartBlocks;  // (a workgroup then walks several pairs: one set of partials each)
   *nblk_out = static_cast<int>(nb);
   const size_t lds = dct_lds_bytes(th.n);
-  if (state_in) {
-    dct_allow_lds(tv2d_fused_dct_kernel<true>, lds);
-    hipLaunchKernelGGL(tv2d_fused_dct_kernel<true>, dim3(static_cast<unsigned>(nb)), dim3(kBlock), lds, stream, a, bhat, th, ctrl);
-  } else {
-    dct_allow_lds(tv2d_fused_dct_kernel<false>, lds);
-    hipLaunchKernelGGL(tv2d_fused_dct_kernel<false>, dim3(static_cast<unsigned>(nb)), dim3(kBlock), lds, stream, a, bhat, th, ctrl);
-  }
+  auto go = [&](auto kernel) {
+    dct_allow_lds(kernel, lds);
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nb)), dim3(kBlock), lds, stream, a, bhat, th, ctrl);
+  };
+  const bool odd = (a.W & 1) != 0;
+  if (state_in) odd ? go(tv2d_fused_dct_kernel<true, true>) : go(tv2d_fused_dct_kernel<true, false>);
+  else odd ? go(tv2d_fused_dct_kernel<false, true>) : go(tv2d_fused_dct_kernel<false, false>);
 }
 
 void launch_dct_cols_forward_fin(double* img, int64_t H, int64_t W, const DctTables& th, const FinArgs& f,
