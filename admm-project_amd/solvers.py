@@ -116,6 +116,17 @@ def huberfit(D, s, options=None):
     return _lad_like("huberfit", D, s, options if options is not None else {})
 
 
+def _single_column_quirk(D):
+    """admm.m:151 takes nA from a matrix A only when it has more than one column, and unwrappedadmm.m:81-86 /
+    linearsvm.m:221-227 pass no options.nA: with a single-column D the check of admm.m:188-190 (rows of A' against
+    nA = 0) fails -- the reference cannot run these solvers on one feature, and neither does the mirror."""
+    if D.shape[1] == 1 and D.shape[0] != 1:
+        raise ValueError("Number of rows in At (A transpose) do not match number of columns in A, in constraint Ax + Bz = c")
+    if D.shape == (1, 1):
+        raise ValueError("Given scalar as matrix A with no number of columns nA specified in options struct; cannot infer nA "
+                         "- please specify nA in options!")
+
+
 def unwrappedadmm(zming, D, options=None):
     """results = unwrappedadmm(zming, D, options)   (solvers/unwrappedadmm.m:1-143)
 
@@ -127,6 +138,7 @@ def unwrappedadmm(zming, D, options=None):
     options = dict(options or {})
     D = _matrix(D, "D")
     m, n = D.shape
+    _single_column_quirk(D)
     if options.get("parallel", "none") in ("xminf", "zming", "both"):
         # unwrappedadmm.m:45-74: the x-update becomes the transpose reduction (W = sum D_i'D_i, d = sum D_i'(z_i-u_i),
         # x = W\d: the engine's cached factor of D'D does exactly that) and admm slices the z-prox ('zming').
@@ -168,6 +180,7 @@ def linearsvm(D, ell, C, options=None):
     D = _matrix(D, "D")
     if D.shape[0] != ell.size:
         raise ValueError("Product ell*D is not possible; sizes incompatible!")
+    _single_column_quirk(D)
     loss = options.get("lossfunction", "hinge")  # linearsvm.m:154-158
     args = _engine_args(options, dict(D=D, Dt=None, ell=ell, C=C, lossfunction=loss))
     if options.get("parallel", "none") in ("both", "zming", "xminf"):  # linearsvm.m:170-205
@@ -325,6 +338,9 @@ def totalvariation(s, lam, options=None):
     lam = float(np.real(lam))
     s = _colvec(s, "s")
     n = s.size
+    if n == 1:  # admm.m:145-148: totalvariation.m:151 hands admm a 1 x 1 matrix D and no options.nA
+        raise ValueError("Given scalar as matrix A with no number of columns nA specified in options struct; cannot infer nA "
+                         "- please specify nA in options!")
     args = _engine_args(options, dict(s=s))
     args["lambda"] = lam
     xmin, zmin, _ = getproxops("TotalVariation", args)

@@ -1,0 +1,352 @@
+"""Randomized parity sweep over EVERY solver of the plug-in surface: tiny, odd and ragged shapes (1 x 1 upwards), random
+rho / lambda and random option mixes (relaxation, fast ADMM, stop conditions, objective, histories on or off, x-solve
+form) against the oracle, history by history.  A checker (test infrastructure), not the product.
+    python tests/sweeps/fuzz_solvers.py [seed] [cases per solver]
+Prints one line per solver with the worst relative error and every failing case with its parameters; exit code 1 if
+any case failed."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import admm_project_amd as ap  # noqa: E402
+from oracle import solvers_ref as S  # noqa: E402  (this script is a checker)
+
+CASES = 12
+rng = np.random.default_rng(0)
+HIST = ("xvals", "zvals", "uvals", "pnorm", "dnorm", "perr", "derr", "objevals", "xopt", "zopt", "uopt")
+TOL = 1e-6
+worst, failures, knives = {}, [], []
+
+
+def rel(a, b, floor=0.0):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if a.shape != b.shape:
+        return float("inf")
+    if a.size == 0:
+        return 0.0
+    if not np.array_equal(np.isnan(a), np.isnan(b)):  # (nodualerror: dnorm / derr are NaN in both or in neither)
+        return float("inf")
+    keep = ~np.isnan(b)
+    if not keep.any():
+        return 0.0
+    a, b = a[keep], b[keep]
+    return float(np.max(np.abs(a - b)) / max(1e-300, floor, np.max(np.abs(b))))
+
+
+def compare(tag, got, ref, histories=True):
+    if "steps" not in ref:  # the reference's convergence test returned early (admm.m:692-701)
+        assert "steps" not in got and got.get("convtest_failed_at") == ref.get("convtest_failed_at"), "convtest abort differs"
+        return 0.0
+    assert got["steps"] == ref["steps"], ("steps", got["steps"], ref["steps"])
+    scale = max(float(np.max(np.abs(ref[k]))) if np.size(ref[k]) else 0.0 for k in ("xopt", "zopt", "uopt"))
+    e = 0.0
+    for k in HIST:
+        if k in ref:
+            if not histories and k in ("xvals", "zvals", "uvals"):
+                assert k not in got, f"record_history=0 but {k} present"
+                continue
+            assert k in got, f"field {k} missing"
+            # iterates that are rounding noise next to the others (u of an interpolating fit) are measured against the
+            # largest of x, z, u; norms and tolerances against themselves
+            floor = scale if k in ("xvals", "zvals", "uvals", "xopt", "zopt", "uopt") else 0.0
+            if k in ("pnorm", "dnorm"):  # a residual that is rounding noise of the iterates (forced iterations past convergence)
+                floor = 1e-8 * scale
+            ek = rel(got[k], ref[k], floor)
+            assert ek < TOL, (k, ek)
+            e = max(e, ek)
+    return e
+
+
+def loop_options(allow_fast=True, allow_relax=True):
+    o = dict(maxiters=int(rng.integers(1, 45)), rho=float(10 ** rng.uniform(-1, 1)))
+    if rng.random() < 0.6:
+        o["objevals"] = 1
+    if allow_relax and rng.random() < 0.3:
+        o["relax"] = float(rng.uniform(1.0, 1.8))
+    elif allow_fast and rng.random() < 0.3:
+        o["fast"] = 1
+        if rng.random() < 0.5:
+            o["fasttype"] = "strong" if rng.random() < 0.5 else "weak"
+    r = rng.random()
+    if r < 0.2:
+        o["stopcond"] = "hnorm"
+    elif r < 0.4:
+        o["stopcond"] = "both"
+    if rng.random() < 0.25:
+        o["domaxiters"] = 1
+    if rng.random() < 0.2:
+        o["nodualerror"] = 1
+    if rng.random() < 0.3:
+        o["abstol"], o["reltol"] = float(10 ** rng.uniform(-6, -2)), float(10 ** rng.uniform(-5, -1))
+    return o
+
+
+def engine_only(o):
+    e = {}
+    if rng.random() < 0.3:
+        e["record_history"] = 0
+    return e
+
+
+def diagnose(got, ref):
+    """first iteration at which each history leaves the oracle's (1e-8 of the history's largest entry)"""
+    out = []
+    for k in ("steps",) + HIST + ("restarted", "Hnormsq"):
+        if k not in ref or k not in got:
+            continue
+        a, b = np.asarray(got[k], float), np.asarray(ref[k], float)
+        if a.shape != b.shape:
+            out.append(f"{k}: shapes {a.shape} / {b.shape}")
+            continue
+        if a.ndim == 0:
+            if a != b:
+                out.append(f"{k}: {a} / {b}")
+            continue
+        d = np.abs(a - b)
+        d = d if d.ndim == 1 else d.max(axis=0)
+        sc = max(1e-300, float(np.nanmax(np.abs(b))))
+        bad = np.nonzero(~(d <= 1e-8 * sc))[0]
+        if bad.size:
+            i = int(bad[0])
+            va = a[i] if a.ndim == 1 else a[:3, i]
+            vb = b[i] if b.ndim == 1 else b[:3, i]
+            out.append(f"{k}: first at iteration {i + 1} of {d.size}: got {va} ref {vb} (scale {sc:.3g})")
+    if "restarted" in ref and "restarted" in got and "dvals" in ref and "dvals" in got:
+        a, b = np.asarray(got["restarted"], float), np.asarray(ref["restarted"], float)
+        k = min(a.size, b.size)
+        bad = np.nonzero(a[:k] != b[:k])[0]
+        if bad.size:
+            i = int(bad[0])
+            lo = max(0, i - 2)
+            out.append(f"dvals[{lo + 1}..{i + 1}] got {np.asarray(got['dvals'])[lo:i + 1]} ref {np.asarray(ref['dvals'])[lo:i + 1]}")
+    return "; ".join(out)
+
+
+def knife_edge(got, ref):
+    """Accelerated ADMM with restarts (admm.m:572-591, 706) decides by comparing d with 0.999*dprev.  Two situations make
+    that comparison a coin toss of the last bits in the REFERENCE itself (its outcome then depends on its BLAS):
+    an exact tie -- after a restart dprev is d_old/0.999, and on polyhedral problems (LP, basis pursuit, LAD) the plain
+    step that follows reproduces d_old exactly, so d is compared with 0.999*(d_old/0.999) --, and d that is rounding
+    noise of a converged iterate (1e-25 against iterates of size 1).  Returns a description, or None."""
+    if not all(k in got and k in ref for k in ("restarted", "dvals")):
+        return None
+    ra, rb = np.asarray(got["restarted"], float), np.asarray(ref["restarted"], float)
+    da, db = np.asarray(got["dvals"], float), np.asarray(ref["dvals"], float)
+    k = min(ra.size, rb.size)
+    bad = np.nonzero(ra[:k] != rb[:k])[0]
+    i = int(bad[0]) if bad.size else k - 1  # (same decisions as far as both ran: one of them stopped on |d - dprev|)
+    scale = max(float(np.max(np.abs(ref[f]))) for f in ("xopt", "zopt", "uopt")) if "xopt" in ref else 1.0
+    if max(da[min(i, da.size - 1)], db[min(i, db.size - 1)]) <= 1e-18 * max(1.0, scale * scale):
+        return f"d is rounding noise at iteration {i + 1}: {da[min(i, da.size - 1)]:.3g} / {db[min(i, db.size - 1)]:.3g}"
+    if bad.size and i >= 1:
+        free, prev = (da, da[i - 1]) if ra[i] == 0 else (db, db[i - 1])  # the side that did not restart holds the computed d
+        if abs(free[i] - 0.999 * prev) <= 1e-7 * free[i] and abs(da[i - 1] - db[i - 1]) <= 1e-7 * db[i - 1]:
+            return f"exact tie at iteration {i + 1}: d = {free[i]:.10g}, 0.999*dprev = {0.999 * prev:.10g}"
+    return None
+
+
+def run(tag, make):
+    for c in range(CASES):
+        desc = None
+        got = ref = None
+        try:
+            desc, got_f, ref_f = make(c)
+            histories = "'record_history': 0" not in desc
+            try:
+                got = got_f()
+            except Exception as exc:  # noqa: BLE001
+                try:
+                    ref_f()
+                except Exception:  # both refuse (argument errors of the reference reproduced, or outside both domains)
+                    continue
+                if isinstance(exc, (ap.AdmmError, NotImplementedError)):
+                    print(f"  {tag} refused ({str(exc)[:70]}): {desc}", flush=True)
+                    continue
+                raise
+            ref = ref_f()
+            e = compare(tag, got, ref, histories)
+            worst[tag] = max(worst.get(tag, 0.0), e)
+        except Exception as exc:  # noqa: BLE001
+            why = knife_edge(got, ref) if got is not None and ref is not None else None
+            if why:
+                knives.append((tag, desc, why))
+                print(f"  knife-edge {tag}: {desc}: {why}", flush=True)
+                continue
+            failures.append((tag, desc, repr(exc)[:300]))
+            print(f"  FAIL {tag}: {desc}: {repr(exc)[:300]}", flush=True)
+            if got is not None and ref is not None and "steps" in ref and "steps" in got:
+                print("       " + diagnose(got, ref), flush=True)
+            if os.environ.get("FUZZ_TRACE"):
+                traceback.print_exc()
+    print(f"{tag}: worst {worst.get(tag)}", flush=True)
+
+
+def dims(lo_m=1, hi_m=400, lo_n=1, hi_n=200, tall=True):
+    if rng.random() < 0.3:  # tiny
+        m, n = int(rng.integers(lo_m, 9)), int(rng.integers(lo_n, 9))
+    else:
+        m, n = int(rng.integers(lo_m, hi_m)), int(rng.integers(lo_n, hi_n))
+    if tall and m < n:
+        m, n = n, m
+    return max(m, lo_m), max(n, lo_n)
+
+
+def strip(o):
+    return {k: v for k, v in o.items() if k not in ("record_history", "xsolve")}
+
+
+def mk_lasso(c):
+    m, n = dims(tall=rng.random() < 0.7)
+    p = ap.synth.lasso_problem(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    if rng.random() < 0.7:
+        o["xsolve"] = ["trsv", "inverse", "cg"][int(rng.integers(0, 3))] if m >= n else ["trsv", "inverse"][int(rng.integers(0, 2))]
+    lam = float(p["lam"] * 10 ** rng.uniform(-1, 0.5))
+    return (f"lasso {m}x{n} {o}", lambda: ap.lasso(p["D"], p["s"], lam, dict(o)), lambda: S.lasso(p["D"], p["s"], lam, strip(o)))
+
+
+def mk_lad(c):
+    m, n = dims(lo_m=2, tall=True)
+    m = max(m, n + 1)
+    huber = rng.random() < 0.5
+    p = (ap.synth.huber_problem if huber else ap.synth.lad_problem)(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    f, g = (ap.huberfit, S.huberfit) if huber else (ap.lad, S.lad)
+    return (f"{'huber' if huber else 'lad'} {m}x{n} {o}", lambda: f(p["D"], p["s"], dict(o)), lambda: g(p["D"], p["s"], strip(o)))
+
+
+def mk_tv(c):
+    n = int(rng.integers(1, 12)) if rng.random() < 0.3 else int(rng.integers(2, 20000))
+    p = ap.synth.tv_problem(int(rng.integers(1 << 30)), n)
+    lam = float(10 ** rng.uniform(-1, 1))
+    o = loop_options(allow_relax=False)
+    o.update(engine_only(o))
+    return (f"tv {n} lam {lam:.3g} {o}", lambda: ap.totalvariation(p["s"], lam, dict(o)),
+            lambda: S.totalvariation(p["s"], lam, strip(o)))
+
+
+def mk_tv2d(c):
+    H, W = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+    if rng.random() < 0.4:
+        H = int(2 ** rng.integers(3, 8))
+    if rng.random() < 0.3:
+        W = int(2 ** rng.integers(3, 8))
+    img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
+    lam = float(10 ** rng.uniform(-1, 0.5))
+    o = loop_options(allow_fast=False, allow_relax=False)
+    o["maxiters"] = min(o["maxiters"], 20)
+    return (f"tv2d {H}x{W} lam {lam:.3g} {o}", lambda: ap.totalvariation2d(img, lam, dict(o)),
+            lambda: S.totalvariation2d(img, lam, strip(o)))
+
+
+def mk_svm(c):
+    m, n = int(rng.integers(3, 1500)), int(rng.integers(1, 120))
+    q = ap.synth.mnist_like_problem(seed=int(rng.integers(1 << 30)), m=m, n=n, digit=int(rng.integers(0, 10)))
+    o = dict(maxiters=int(rng.integers(1, 50)), x0=q["x0"], z0=q["z0"], u0=q["u0"])
+    if rng.random() < 0.6:
+        o["objevals"] = 1
+    if rng.random() < 0.3:
+        o["fast"] = 1
+    if rng.random() < 0.3:
+        o["stopcond"] = "both"
+    if rng.random() < 0.3:
+        o["lossfunction"] = "01"
+    o.update(engine_only(o))
+    return (f"svm {m}x{n} { {k: v for k, v in o.items() if k not in ('x0', 'z0', 'u0')} }",
+            lambda: ap.linearsvm(q["D"], q["ell"], q["C"], dict(o)), lambda: S.linearsvm(q["D"], q["ell"], q["C"], strip(o)))
+
+
+def mk_qp(c):
+    n = int(rng.integers(1, 9)) if rng.random() < 0.3 else int(rng.integers(1, 220))
+    p = ap.synth.qp_bounded_problem(int(rng.integers(1 << 30)), n)
+    o = loop_options()
+    o.update(engine_only(o))
+    return (f"qp-bounded {n} {o}", lambda: ap.quadraticprogram(p["P"], p["q"], p["r"], p["lb"], p["ub"], dict(o)),
+            lambda: S.quadraticprogram_bounded(p["P"], p["q"], p["r"], p["lb"], p["ub"], strip(o)))
+
+
+def mk_qpstd(c):
+    n = int(rng.integers(3, 120))
+    m = int(rng.integers(2, n))  # (a 1 x n constraint matrix is a vector to quadraticprogram.m's dispatch: bounds)
+    p = ap.synth.qp_standard_problem(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    return (f"qp-standard {m}x{n} {o}", lambda: ap.quadraticprogram(p["P"], p["q"], p["r"], p["D"], p["s"], dict(o)),
+            lambda: S.quadraticprogram_standard(p["P"], p["q"], p["r"], p["D"], p["s"], strip(o)))
+
+
+def mk_lp(c):
+    n = int(rng.integers(2, 120))
+    m = int(rng.integers(1, n))
+    p = ap.synth.lp_problem(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    return (f"lp {m}x{n} {o}", lambda: ap.linearprogram(p["b"], p["D"], p["s"], dict(o)),
+            lambda: S.linearprogram(p["b"], p["D"], p["s"], strip(o)))
+
+
+def mk_bp(c):
+    n = int(rng.integers(2, 150))
+    m = int(rng.integers(1, n))
+    p = ap.synth.basispursuit_problem(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    return (f"bp {m}x{n} {o}", lambda: ap.basispursuit(p["D"], p["s"], dict(o)), lambda: S.basispursuit(p["D"], p["s"], strip(o)))
+
+
+def mk_model(c):
+    m, n = dims(lo_m=1, hi_m=150, hi_n=150, tall=False)
+    p = ap.synth.model_problem(int(rng.integers(1 << 30)), m, n)
+    o = loop_options()
+    o.update(engine_only(o))
+    return (f"model {m}x{n} {o}", lambda: ap.model(p["P"], p["Q"], p["r"], p["s"], dict(o)),
+            lambda: S.model(p["P"], p["Q"], p["r"], p["s"], strip(o)))
+
+
+def mk_consensus(c):
+    n = int(rng.integers(1, 90))
+    k = int(rng.integers(2, 7))
+    m = int(rng.integers(k * max(n, 2), k * max(n, 2) + 400))
+    p = ap.synth.lasso_problem(int(rng.integers(1 << 30)), m, n)
+    o = dict(maxiters=int(rng.integers(1, 40)), rho=float(10 ** rng.uniform(-0.5, 0.8)), parallel="both")
+    if rng.random() < 0.5:
+        o["objevals"] = 1
+    if rng.random() < 0.3:
+        o["stopcond"] = "both"
+    return (f"consensus {m}x{n} workers {k} {o}", lambda: ap.lasso(p["D"], p["s"], p["lam"], dict(o, workers=k)),
+            lambda: S.lasso(p["D"], p["s"], p["lam"], dict(o), workers=k))
+
+
+ALL = dict(lasso=mk_lasso, lad=mk_lad, tv=mk_tv, tv2d=mk_tv2d, svm=mk_svm, qp=mk_qp, qpstd=mk_qpstd, lp=mk_lp, bp=mk_bp,
+           model=mk_model, consensus=mk_consensus)
+
+
+def main(seed=0, cases=12, only=None):
+    """Runs the sweep; returns (worst relative error per solver, failures, knife-edge cases)."""
+    global rng, CASES
+    rng = np.random.default_rng(seed)
+    CASES = cases
+    worst.clear()
+    del failures[:], knives[:]
+    for name, mk in ALL.items():
+        if only and name not in only:
+            continue
+        run(name, mk)
+    return dict(worst), list(failures), list(knives)
+
+
+if __name__ == "__main__":
+    only_env = os.environ.get("FUZZ_ONLY")
+    w, f, k = main(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 12,
+                   only_env.split(",") if only_env else None)
+    print("worst relative errors:", w, flush=True)
+    print("knife-edge restart decisions (indeterminate in the reference itself):", len(k), flush=True)
+    print("failures:", len(f), flush=True)
+    for x in f:
+        print("  ", x)
+    sys.exit(1 if f else 0)

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import admm_project_amd as ap  # noqa: E402
 from oracle import solvers_ref as S  # noqa: E402  (test infrastructure: this script is a checker, not the product)
 

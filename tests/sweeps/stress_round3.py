@@ -1,13 +1,13 @@
 """Randomized parity sweep of the paths added in round 3 against the oracle: the one-block triangular solves (lasso and
 bounded QP, every loop variant, early stops), the three-launch 2-D TV iteration (cooperative row stage, fused pass into
 the forward transform; heights 64..2048, any even width, rho on both sides of the cooperative kernel's truncation
-limit), the ABI's binding layer feeding the same engine.  `python profiles/stress_round3.py [seed]`"""
+limit), the ABI's binding layer feeding the same engine.  `python tests/sweeps/stress_round3.py [seed]`"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["ADMM_TRSV_FORM"] = "one"
 import admm_project_amd as ap  # noqa: E402
 from oracle import solvers_ref as S  # noqa: E402  (test infrastructure: this script is a checker, not the product)

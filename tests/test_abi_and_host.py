@@ -235,6 +235,26 @@ def test_solver_argument_errors_mirror_the_reference(ap):
         ap.linearprogram(z(3), z((2, 3)), z(2), "options")
 
 
+def test_single_feature_quirks_of_the_reference_are_reproduced(ap):
+    """admm.m:145-148, 151, 188-190: the solvers that hand admm a data matrix as A without options.nA
+    (totalvariation.m:151-157, unwrappedadmm.m:81-86, linearsvm.m:221-227) cannot run with a single column -- the
+    oracle restates those checks, the mirror raises the same errors (found by tests/sweeps/fuzz_solvers.py: the engine
+    itself solves these shapes)."""
+    from oracle import solvers_ref as S
+
+    one = np.array([0.7])
+    col = np.arange(1.0, 6.0).reshape(5, 1)
+    ell = np.array([1.0, -1.0, 1.0, -1.0, 1.0])
+    for f in (ap.totalvariation, S.totalvariation):
+        with pytest.raises(ValueError, match="(?i)scalar"):
+            f(one, 1.0, {})
+    for f in (ap.linearsvm, S.linearsvm):
+        with pytest.raises(ValueError, match="(?i)rows of At|rows in At"):
+            f(col, ell, 1.0, {})
+    with pytest.raises(ValueError, match="rows in At"):
+        ap.unwrappedadmm(lambda x, z, u, rho: x, col, {})
+
+
 def _gfx950_disassembly(tmp_path, symbol_part):
     """Disassembly (llvm-objdump) of the shipped library's gfx950 kernels whose mangled name contains `symbol_part`."""
     import shutil
