@@ -101,6 +101,7 @@ constexpr size_t kP2pCap = size_t{1} << 15;  // doubles per peer slot (256 KB); 
 constexpr int kP2pMaxRanks = 16;
 struct P2pExchange {  // one per rank, in the shm segment behind the all-reduce slots
   int64_t pid;
+  int64_t device;
   uint64_t raw_recv, raw_flags;  // device addresses (valid inside that process)
   hipIpcMemHandle_t h_recv, h_flags;
 };
@@ -142,6 +143,7 @@ struct admm_comm {
   ShmState shm;
   P2pState p2p;
   int rank = 0, nranks = 1, device = 0;
+  int queue_slot = 0, queue_sharers = 1;  // P2P, ranks that are threads of one process on ONE device (comm_stream_create)
 };
 
 namespace {
@@ -335,6 +337,7 @@ int p2p_attach(admm_comm* c) {
                                                    static_cast<size_t>(c->nranks) * kShmSlotElems * sizeof(double));
   P2pExchange mine{};
   mine.pid = static_cast<int64_t>(getpid());
+  mine.device = c->device;
   mine.raw_recv = reinterpret_cast<uint64_t>(s.recv);
   mine.raw_flags = reinterpret_cast<uint64_t>(s.flags);
   if (hipIpcGetMemHandle(&mine.h_recv, s.recv) != hipSuccess || hipIpcGetMemHandle(&mine.h_flags, s.flags) != hipSuccess) {
@@ -347,6 +350,13 @@ int p2p_attach(admm_comm* c) {
   std::vector<double*> pr(static_cast<size_t>(c->nranks));
   std::vector<unsigned long long*> pf(static_cast<size_t>(c->nranks));
   int rc = ADMM_OK;
+  c->queue_slot = 0;
+  c->queue_sharers = 0;
+  for (int p = 0; p < c->nranks; ++p)
+    if (ex[p].pid == mine.pid && ex[p].device == mine.device) {
+      c->queue_sharers += 1;
+      if (p < c->rank) c->queue_slot += 1;
+    }
   for (int p = 0; p < c->nranks && rc == ADMM_OK; ++p) {
     const P2pExchange& e = ex[p];
     if (e.pid == mine.pid) {  // a thread of this process: its addresses are ours
@@ -435,6 +445,25 @@ int comm_allreduce_device(admm_comm* c, double* buf, size_t count, hipStream_t s
   return ADMM_OK;
 }
 
+// A stream for work that contains this communicator's collectives.  The P2P kernel of a rank waits for the kernels of its
+// peers, so ranks that are threads of ONE process on ONE device (the one-GPU rehearsal of the MEX-gateway deployment)
+// need hardware queues of their own: the runtime deals a process's streams onto a small pool of queues PER PRIORITY
+// (which queue a new stream gets depends on every stream the process made before: two ranks that landed on one queue
+// trip the polling limit), so such ranks take different priorities -- a different pool each.  With more sharers than
+// priority levels (three here) the pools are shared again.  One rank per device: a plain stream.
+int comm_stream_create(const admm_comm* comm, hipStream_t* out) {
+  if (comm && comm->transport == ADMM_COMM_P2P && comm->queue_sharers > 1) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
+      const int levels = least - greatest + 1;
+      if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest + comm->queue_slot % levels) == hipSuccess)
+        return ADMM_OK;
+    }
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking) == hipSuccess ? ADMM_OK : fail(ADMM_E_DEVICE, "hipStreamCreate");
+}
+
 }  // namespace admm
 
 extern "C" {
@@ -521,9 +550,9 @@ int admm_comm_allreduce_sum(admm_comm* comm, double* host_buf, size_t count) {
   // a stream of its own: ranks that are threads of one process must not queue behind each other on the null stream
   // (the P2P kernel of one rank waits for the kernels of the others)
   hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+  if (comm_stream_create(comm, &st) != ADMM_OK) {
     (void)hipFree(d);
-    return fail(ADMM_E_DEVICE, "hipStreamCreate");
+    return ADMM_E_DEVICE;
   }
   if (hipMemcpy(d, host_buf, sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess)
     rc = fail(ADMM_E_DEVICE, "hipMemcpy H2D");
@@ -543,9 +572,9 @@ int admm_comm_measure_latency(admm_comm* comm, size_t count, int reps, double* m
   double* d = nullptr;
   ADMM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * count));
   hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+  if (comm_stream_create(comm, &st) != ADMM_OK) {
     (void)hipFree(d);
-    return fail(ADMM_E_DEVICE, "hipStreamCreate");
+    return ADMM_E_DEVICE;
   }
   int rc = ADMM_OK;
   if (hipMemsetAsync(d, 0, sizeof(double) * count, st) != hipSuccess) rc = fail(ADMM_E_DEVICE, "hipMemsetAsync");

@@ -772,7 +772,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
 
   e->device = desc->device;
   e->comm = desc->comm;
-  E_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  E_TRY(comm_stream_create(e->comm, &e->stream));
   e->problem = desc->problem;
   e->m = desc->m;
   e->n = desc->n;

@@ -52,6 +52,7 @@ struct admm_comm;  // comm.hip
 namespace admm {
 int comm_allreduce_device(admm_comm* comm, double* buf, size_t count, hipStream_t stream);
 int comm_nranks(admm_comm* comm);
+int comm_stream_create(const admm_comm* comm, hipStream_t* out);  // a stream whose hardware queue no same-device peer rank shares (comm.hip)
 int comm_check_error(admm_comm* comm, hipStream_t stream);  // P2P transport: a peer never arrived (synchronises)
 int comm_rank(admm_comm* comm);
 }  // namespace admm

@@ -161,9 +161,11 @@ def test_one_process_ranks_over_the_one_shot_p2p_all_reduce(gpu, nranks):
     """ADMM_COMM_P2P between ranks that are threads of ONE process (the MEX-gateway deployment): the peers' buffers are
     plain device pointers here, the kernels of the ranks run on their engines' streams at the same time, nothing
     synchronises with the host inside an iteration.  (On this box all ranks share device 0, and a rank's kernel waits
-    for the kernels of the others: each needs a hardware queue of its own.  The runtime multiplexes a process's streams
-    onto 4 queues: two ranks rehearse reliably, four already share queues -- measured: the polling limit trips and the
-    call returns ADMM_E_COMM, it does not hang.  One GPU per rank has no such limit.)"""
+    for the kernels of the others: each needs a hardware queue of its own.  The runtime deals a process's streams onto a
+    pool of queues per stream priority, depending on every stream made before -- two ranks on one queue trip the polling
+    limit (seen once the suite grew: ADMM_E_COMM, no hang) --, so same-device ranks of one process take different
+    priorities (comm.hip: comm_stream_create): up to three ranks are separated for certain.  One GPU per rank has no
+    such limit.)"""
     from admm_project_amd import parallel
     m, n = 1003, 40
     p = gpu.synth.lad_problem(0, m, n)
