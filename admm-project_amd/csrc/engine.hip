@@ -497,6 +497,12 @@ static int probe_affine_map(admm_engine* e, const double* D, int64_t m, int64_t 
   launch_sum_partials(partD, pd.nchunk, pd.ldy, m, r, nullptr, e->stream);
   ADMM_HIP_TRY(hipMemcpyAsync(rh.data(), r, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
   ADMM_HIP_TRY(hipMemcpyAsync(sh.data(), s_dev, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
+  // the size of D*(an unstructured vector): with s = 0 (or tiny) D*x and s are both rounding noise, and their own
+  // magnitudes would make a relative violation of order 1 out of nothing (found by the solver sweep: 1 x 2, s = 0)
+  std::vector<double> dyh(static_cast<size_t>(m));
+  launch_gemv_n(pd, D, y, partD, nullptr, e->stream);
+  launch_sum_partials(partD, pd.nchunk, pd.ldy, m, r, nullptr, e->stream);
+  ADMM_HIP_TRY(hipMemcpyAsync(dyh.data(), r, sizeof(double) * m, hipMemcpyDeviceToHost, e->stream));
   ADMM_HIP_TRY(hipStreamSynchronize(e->stream));
   for (double* p : {y, x, r, partK, partD}) mem_free_one(e->mem, p);
   double viol = 0.0, scale = 0.0;
@@ -504,7 +510,7 @@ static int probe_affine_map(admm_engine* e, const double* D, int64_t m, int64_t 
   for (int64_t i = 0; i < m; ++i) {
     finite = finite && std::isfinite(rh[i]);
     viol = std::max(viol, std::fabs(rh[i] - sh[i]));
-    scale = std::max(scale, std::max(std::fabs(rh[i]), std::fabs(sh[i])));
+    scale = std::max(scale, std::max(std::max(std::fabs(rh[i]), std::fabs(sh[i])), std::fabs(dyh[i])));
   }
   const double rel = viol / (scale > 0.0 ? scale : 1.0);
   if (!finite || !(rel <= 1e-9))

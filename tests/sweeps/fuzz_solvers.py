@@ -64,6 +64,9 @@ def compare(tag, got, ref, histories=True):
 
 def loop_options(allow_fast=True, allow_relax=True):
     o = dict(maxiters=int(rng.integers(1, 45)), rho=float(10 ** rng.uniform(-1, 1)))
+    if rng.random() < 0.04:  # admm.m:334-339: a fractional count is rounded up, zero or less means 1000
+        o["maxiters"] = [0, -3, 6.5][int(rng.integers(0, 3))]
+        allow_fast = allow_fast and o["maxiters"] > 0  # (1000 iterations of a momentum that does not settle amplify rounding)
     if rng.random() < 0.6:
         o["objevals"] = 1
     if allow_relax and rng.random() < 0.3:
@@ -264,10 +267,12 @@ def mk_tv2d(c):
         H = int(2 ** rng.integers(3, 8))
     if rng.random() < 0.3:
         W = int(2 ** rng.integers(3, 8))
+    if SC == 1 and rng.random() < 0.1:  # degenerate images: a single row, a single column, a single pixel
+        H, W = [(1, W), (H, 1), (1, 1)][int(rng.integers(0, 3))]
     img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
     lam = float(10 ** rng.uniform(-1, 0.5))
     o = loop_options(allow_fast=False, allow_relax=False)
-    o["maxiters"] = min(o["maxiters"], 20)
+    o["maxiters"] = min(o["maxiters"], 20) if o["maxiters"] > 0 else 12
     return (f"tv2d {H}x{W} lam {lam:.3g} {o}", lambda: ap.totalvariation2d(img, lam, dict(o)),
             lambda: S.totalvariation2d(img, lam, strip(o)))
 

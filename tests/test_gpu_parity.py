@@ -467,6 +467,28 @@ def test_basispursuit(gpu):
     _compare(gpu.basispursuit(p["D"], p["s"], o), S.basispursuit(p["D"], p["s"], o))
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 2), (2, 3), (7, 30)])
+def test_equality_constrained_solvers_with_a_zero_right_hand_side(gpu, rows, cols):
+    """s = 0: the create-time probe of the eliminated maps (engine.hip: probe_affine_map) measures D*x = s against the
+    size of D times an unstructured vector -- against |D*x| and |s| alone the violation of an exactly feasible x (noise
+    over noise) read as 1 and the problem was refused (found by tests/sweeps/fuzz_solvers.py at 1 x 2)."""
+    rng = np.random.default_rng(rows * 100 + cols)
+    D = np.asfortranarray(rng.standard_normal((rows, cols)))
+    s = np.zeros(rows)
+    # random starts: from zero every iterate of these problems IS zero
+    o = dict(objevals=1, maxiters=25, z0=rng.standard_normal(cols), u0=rng.standard_normal(cols))
+
+    def same(got, ref):  # the solution is x = 0: late iterates are rounding noise, measured against the starts' size
+        assert got["steps"] == ref["steps"]
+        for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "objevals"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-8, atol=1e-12, err_msg=k)
+
+    same(gpu.basispursuit(D, s, dict(o)), S.basispursuit(D, s, dict(o)))
+    if rows > 1:  # (a 1 x n constraint is a vector to linearprogram.m's argument checks)
+        b = rng.random(cols) + 0.5
+        same(gpu.linearprogram(b, D, s, dict(o)), S.linearprogram(b, D, s, dict(o)))
+
+
 @pytest.mark.parametrize("n,lam,rho,opts", [
     (128, 1.0, 1.0, dict(maxiters=10000)),          # totalvariationtest.m defaults
     (1000, 2.0, 1.0, dict()),
