@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _load():
-    spec = importlib.util.spec_from_file_location("fuzz_solvers", os.path.join(HERE, "sweeps", "fuzz_solvers.py"))
+def _load(name="fuzz_solvers"):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, "sweeps", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -27,3 +27,13 @@ def test_random_shapes_and_options_match_the_oracle(gpu, seed):
     # restart decisions of accelerated ADMM that are ties or rounding noise in the reference itself (fuzz_solvers.knife_edge):
     # rare, and never the majority of a seed's fast-ADMM cases
     assert len(knives) <= 6, knives
+
+
+def test_random_row_shards_match_the_unsharded_oracle(gpu):
+    """tests/sweeps/fuzz_sharded.py: 2-8 ranks (threads, device 0, host-staged transport) with the rows slicemaker gives
+    them -- ragged shards, shards with fewer rows than columns -- against the unsharded oracle (lasso, LAD, Huber, SVM)
+    and the N-slice oracle (consensus lasso)."""
+    fz = _load("fuzz_sharded")
+    worst, failures = fz.main(seed=3, cases=3)
+    assert not failures, failures
+    assert len(worst) == 5 and max(worst.values()) < 1e-6
