@@ -1233,6 +1233,13 @@ int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, i
   }
   if (H < 2) H = 2;
   if (H & 1) H += 1;  // even: the sweeps walk the processing range in aligned pairs
+  // a window never needs to be longer than the signal: clipped at both ends it starts and ends exactly (no incoming
+  // carry to damp).  Without this a short signal with a large rho (n = 3, rho = 430: 5900 positions to damp a carry by
+  // 1e-18) was refused below although one workgroup holds all of it.
+  {
+    const int64_t whole = (n + 1) & ~int64_t{1};
+    if (static_cast<int64_t>(H) > whole) H = static_cast<int>(whole < 2 ? 2 : whole);
+  }
   // workgroup capacity = 256*elems positions = owned tile + halo.  Small tiles keep the LDS
   // footprint low (17 KiB at elems = 8 -> 8 workgroups per CU), which is what hides the
   // load -> scan -> store phase structure of a workgroup behind its neighbours.

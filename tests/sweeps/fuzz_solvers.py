@@ -63,7 +63,8 @@ def compare(tag, got, ref, histories=True):
 
 
 def loop_options(allow_fast=True, allow_relax=True):
-    o = dict(maxiters=int(rng.integers(1, 45)), rho=float(10 ** rng.uniform(-1, 1)))
+    span = 4.0 if os.environ.get("FUZZ_RHO_WIDE") else 1.0  # (FUZZ_RHO_WIDE=1: rho from 1e-4 to 1e4)
+    o = dict(maxiters=int(rng.integers(1, 45)), rho=float(10 ** rng.uniform(-span, span)))
     if rng.random() < 0.04:  # admm.m:334-339: a fractional count is rounded up, zero or less means 1000
         o["maxiters"] = [0, -3, 6.5][int(rng.integers(0, 3))]
         allow_fast = allow_fast and o["maxiters"] > 0  # (1000 iterations of a momentum that does not settle amplify rounding)

@@ -497,6 +497,10 @@ def test_equality_constrained_solvers_with_a_zero_right_hand_side(gpu, rows, col
     (4096, 1.0, 40.0, dict(maxiters=300)),          # slower-decaying recurrence (halo ~ 270, 20-element tiles)
     (30011, 1.0, 800.0, dict(maxiters=6, domaxiters=1)),  # halo ~ 1200: 48-element tiles, odd n
     (2, 1.0, 1.0, dict(maxiters=5)), (257, 0.0, 1.0, dict(maxiters=20)),
+    # short signals with a large rho: the damping length of a carry (5900 positions at rho = 430) exceeds every window
+    # size, but a window is never longer than the signal (tv_plan; refused before the solver sweep found it)
+    (3, 0.21, 430.0, dict(maxiters=33, domaxiters=1)), (10, 6.0, 4800.0, dict(maxiters=23)),
+    (3000, 1.0, 6000.0, dict(maxiters=12, domaxiters=1)),
 ])
 def test_total_variation(gpu, n, lam, rho, opts):
     p = gpu.synth.tv_problem(n % 97, n)
