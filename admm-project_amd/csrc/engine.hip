@@ -1237,7 +1237,10 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
       e->prox = PROX_SOFT;
       e->rhs_kind = RHS_NONE;
       if (desc->cg_tol <= 0 || desc->cg_tol == 1e-12) e->cg_tol = 1e-11;
-      if (desc->cg_maxit <= 0 || desc->cg_maxit == 200) e->cg_maxit = 500;
+      if (desc->cg_maxit <= 0 || desc->cg_maxit == 200) {
+        e->cg_maxit = 500;
+        e->cg_maxit_auto = true;  // (raised per run to what rho needs: engine_run_tv.hip)
+      }
       E_TRY(upload(e->mem, &e->s, desc->s, N, mk, e->stream));
       E_TRY(e->mem.alloc(&e->tv_zB, round_up(2 * N, 2)));
       E_TRY(e->mem.alloc(&e->tv_uB, round_up(2 * N, 2)));

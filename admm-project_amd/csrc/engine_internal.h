@@ -138,6 +138,7 @@ struct admm_engine {
   // matrix-free x-update (xsolve = cg)
   double cg_tol = 1e-12;
   int32_t cg_maxit = 200;
+  bool cg_maxit_auto = false;  // 2-D TV with the default cap: the cap follows rho (cond(I + rho*D'D) < 1 + 8*rho)
   bool cg_shift_is_rho = false;
   double *cg_r = nullptr, *cg_p = nullptr, *cg_q = nullptr, *cg_tmp = nullptr, *cg_part = nullptr;
   CgState* cg_st = nullptr;

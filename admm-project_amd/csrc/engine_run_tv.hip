@@ -23,6 +23,15 @@ int cg_solve_tv2d(admm_engine* e, const double* y) {
   a.st = e->cg_st;
   a.ctrl = e->ctrl;
   const double rho = e->last_opts.rho;
+  // the default cap follows the conditioning: I + rho*D'D has its spectrum in [1, 1 + 8 rho), and CG reaches a relative
+  // residual tol within 1/2*sqrt(cond)*ln(2/tol) steps -- 500 steps stop short of 1e-11 from rho = 190 on, and the
+  // x-update silently lost digits there (2e-4 at rho = 5000; found by the solver sweep on images without a spectral path)
+  int32_t maxit = e->cg_maxit;
+  if (e->cg_maxit_auto) {
+    const double need = 0.5 * std::sqrt(1.0 + 8.0 * rho) * std::log(2.0 / e->cg_tol) + 20.0;
+    if (need > maxit) maxit = need < 2.0e5 ? static_cast<int32_t>(need) : 200000;
+  }
+  a.maxit = maxit;
   ADMM_HIP_TRY(hipMemsetAsync(&e->cg_st->iters, 0, 2 * sizeof(int32_t), e->stream));
   // r = y - (I + rho*D'D) x, p = r, rs, ||y||
   launch_tv2d_laplace(e->tv2_H, e->tv2_W, rho, e->x, e->cg_tmp, e->ctrl, e->stream);
@@ -35,8 +44,8 @@ int cg_solve_tv2d(admm_engine* e, const double* y) {
   launch_tv2d_cg_pq(e->tv2_H, e->tv2_W, rho, a, pbuf[1], true, e->stream);  // q = A p, p.q (beta = 0)
   cur = 1;
   const int chunk = e->cg_chunk;  // as long as the previous solve: launches after convergence are no-ops
-  for (int done_it = 0; done_it < e->cg_maxit;) {
-    const int k = (e->cg_maxit - done_it < chunk) ? e->cg_maxit - done_it : chunk;
+  for (int done_it = 0; done_it < maxit;) {
+    const int k = (maxit - done_it < chunk) ? maxit - done_it : chunk;
     for (int c = 0; c < k; ++c) {
       a.p = pbuf[cur];
       launch_cg_update(a, e->stream);   // alpha, x += alpha p, r -= alpha q, (r.r)_new partials

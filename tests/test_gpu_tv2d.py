@@ -36,6 +36,21 @@ def test_tv2d_matches_oracle(gpu, H, W, opts):
     assert (got["cg_iters_total"] == 0) if pow2 else (got["cg_iters_total"] >= got["steps"])  # spectral x-update
 
 
+@pytest.mark.parametrize("H,W,rho", [(170, 110, 2381.0), (61, 75, 4958.0)])
+def test_tv2d_matrix_free_x_update_with_a_large_rho(gpu, H, W, rho):
+    """No spectral path for these shapes and this rho (the Toeplitz row stage would need ~2000 taps, the width is not
+    a power of two): CG on I + rho*D'D, condition number up to 1 + 8 rho.  The DEFAULT iteration cap follows rho
+    (engine_run_tv.hip: cg_solve_tv2d); with the fixed 500 the x-update stopped short and the iterates were off by 2e-6
+    resp. 2e-4 from the first iteration on (found by tests/sweeps/fuzz_solvers.py with FUZZ_RHO_WIDE=1 FUZZ_SIZE=8)."""
+    rng = np.random.default_rng(H + W)
+    img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
+    o = dict(objevals=1, maxiters=6, domaxiters=1, rho=rho)
+    got, ref = gpu.totalvariation2d(img, 0.6, dict(o)), S.totalvariation2d(img, 0.6, dict(o))
+    assert got["steps"] == ref["steps"] and got["cg_iters_total"] > 500  # (past the fixed cap in the first x-update)
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "objevals", "xopt"):
+        _close(k, got[k], ref[k], 1e-7)
+
+
 @pytest.mark.parametrize("H,W,rho", [(8, 8, 1.0), (16, 64, 1.0), (64, 32, 2.5), (128, 256, 0.7), (32, 8, 1.0),
                                      (512, 8, 1.0), (8, 1024, 1.3), (2048, 16, 1.0), (16, 4096, 0.5),
                                      (8192, 8, 1.0), (8, 8192, 2.0)])  # every radix plan; 8192: 128 KB of LDS
