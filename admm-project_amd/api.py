@@ -680,7 +680,11 @@ def admm(xminf, zming, options):
     results["steps"] = steps
     results["engine_info"] = eng.info()  # engine extension: which x-solve form runs, probe errors, rank (not a reference field)
     try:  # matrix-free x-update: total inner CG iterations (engine extension, not a reference field)
-        results["cg_iters_total"] = int(eng.fetch(L.F_CG_ITERS, 1)[0])
+        cg = eng.fetch(L.F_CG_ITERS, 2)
+        results["cg_iters_total"] = int(cg[0])
+        results["cg_capped_updates"] = int(cg[1])  # x-updates that ended on cg_maxit above cg_tol (inexact iterates)
+        if cg[1] > 0 and not _setopt(options, "quiet", 0):
+            print(f"admm: {int(cg[1])} of {steps} x-updates ended on the CG iteration cap above cg_tol; raise cg_maxit")
     except L.AdmmError:
         pass
     if prob.kind == "lasso-consensus":

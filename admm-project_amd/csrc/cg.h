@@ -10,6 +10,7 @@ struct CgState {     // device scalars of one solve
   int32_t iters;     // inner iterations of the current solve
   int32_t done;      // converged (or hit maxit): the remaining launches of the chunk are no-ops
   int64_t total;     // inner iterations since the run started
+  int64_t capped;    // x-updates of this run that ended on the iteration cap with the residual still above tol
 };
 
 struct CgArgs {

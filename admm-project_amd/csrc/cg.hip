@@ -116,7 +116,9 @@ __global__ void cg_advance_kernel(CgArgs a, int nblk) {
     a.st->rs = rsn;
     a.st->iters += 1;
     a.st->total += 1;
-    if (sqrt(rsn) <= a.tol * a.st->ynorm || a.st->iters >= a.maxit) {
+    const bool converged = sqrt(rsn) <= a.tol * a.st->ynorm;
+    if (converged || a.st->iters >= a.maxit) {
+      if (!converged) a.st->capped += 1;
       a.st->done = 1;
       if (a.skip) *a.skip = 1;
     }

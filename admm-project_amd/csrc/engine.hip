@@ -1575,7 +1575,8 @@ int admm_engine_fetch(admm_engine* e, int field, double* dst, size_t cap, size_t
       if (e->xsolve != ADMM_XSOLVE_CG) return fail(ADMM_E_INVALID, "field exists only for xsolve = cg");
       if (cap < 1) return fail(ADMM_E_CAPACITY, "destination too small");
       dst[0] = static_cast<double>(e->cg_total_last);
-      if (written) *written = 1;
+      if (cap >= 2) dst[1] = static_cast<double>(e->cg_capped_last);  // x-updates that ended on cg_maxit above cg_tol
+      if (written) *written = cap >= 2 ? 2 : 1;
       return ADMM_OK;
     }
     case ADMM_F_ZCONSENSUS:

@@ -145,7 +145,7 @@ struct admm_engine {
   Ctrl* cg_skip = nullptr;  // Ctrl-shaped block whose .stop mirrors (CG converged || ctrl->stop): skips the operator kernels
   int cg_chunk = 8;         // inner iterations enqueued between polls: follows the last solve's count
   CgState* cg_st_host = nullptr;  // pinned
-  int64_t cg_total_last = 0;
+  int64_t cg_total_last = 0, cg_capped_last = 0;
   // consensus lasso (getProxOps.m:383-442, 1217-1343)
   std::vector<ConsSlice> cslices;
   int32_t cons_total = 0;  // slicenum over all ranks

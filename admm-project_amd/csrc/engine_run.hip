@@ -1164,6 +1164,7 @@ int admm_engine_run(admm_engine* e, const admm_options* opts, admm_run_summary* 
   if (e->cg_st) {
     ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
     e->cg_total_last = e->cg_st_host->total;
+    e->cg_capped_last = e->cg_st_host->capped;
   }
   e->last.stopped_early = (e->ctrl_host->steps < N) ? 1 : 0;
   e->last.convtest_failed_at = e->ctrl_host->convfail;

@@ -292,6 +292,7 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   e->u = e->tv_uA;
   ADMM_HIP_TRY(hipMemcpy(e->cg_st_host, e->cg_st, sizeof(CgState), hipMemcpyDeviceToHost));
   e->cg_total_last = e->cg_st_host->total;
+  e->cg_capped_last = e->cg_st_host->capped;
   e->last = admm_run_summary{};
   e->last.steps = steps;
   e->last.stopped_early = (steps < N) ? 1 : 0;

@@ -240,7 +240,8 @@ enum {
   ADMM_F_VVALS = 16, ADMM_F_UHATVALS = 17,
   ADMM_F_ZCONSENSUS = 18, /* consensus lasso: the true consensus z (the z handed to admm is 0, q9) */
   ADMM_F_FACTOR = 19,     /* n x n (or m x m, fat lasso) lower Cholesky factor */
-  ADMM_F_CG_ITERS = 20,   /* ADMM_XSOLVE_CG: inner iterations used per x-update */
+  ADMM_F_CG_ITERS = 20,   /* matrix-free x-update: [0] inner iterations of the last run in total, [1] (capacity >= 2) the number of
+                           * its x-updates that ended on cg_maxit with the residual still above cg_tol (an inexact iterate) */
   ADMM_F_CONS_X = 21,     /* consensus lasso: the local slices' x_k, n x K column-major (closure state xi{k}, getProxOps.m:1247) */
   ADMM_F_CONS_U = 22,     /* consensus lasso: the local slices' u_k (closure state ui{k}, getProxOps.m:1296) */
   ADMM_F_WVALS = 23       /* (nA + nB + nU) x steps: w = [x; z; rho*u] per iteration, results.wvals of the H-norm runs

@@ -554,6 +554,18 @@ def test_consensus_lasso(gpu, rows, cols, workers, opts, xsolve):
         assert obj(got["zconsensus"]) < obj(p["testx"])
 
 
+def test_matrix_free_x_update_reports_the_updates_that_ended_on_the_cap(gpu):
+    """cg_maxit too small for cg_tol: the iterates are inexact, and the run says so (results.cg_capped_updates, the
+    second entry of ADMM_F_CG_ITERS) instead of returning them as if nothing had happened; with the default cap no
+    update of this well-conditioned problem ends on it."""
+    p = gpu.synth.lasso_problem(4, 600, 120)
+    o = dict(maxiters=12, domaxiters=1, quiet=1)
+    res = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, xsolve="cg", cg_maxit=3))
+    assert res["cg_capped_updates"] == 12 and res["cg_iters_total"] == 36
+    res = gpu.lasso(p["D"], p["s"], p["lam"], dict(o, xsolve="cg"))
+    assert res["cg_capped_updates"] == 0 and res["cg_iters_total"] > 12
+
+
 @pytest.mark.parametrize("solver,opts", [
     ("lasso", dict()), ("lasso", dict(rho=3.0, relax=1.5)), ("lasso", dict(fast=1, fasttype="strong", maxiters=40)),
     ("lad", dict()), ("huberfit", dict(convtest=1)),
