@@ -62,6 +62,13 @@ int tv2d_rows_green_taps(double rho);
 // fin != nullptr: one extra workgroup runs the finalize logic `*fin` of the previous iteration (when fin_pending)
 void launch_tv2d_rows_green(const double* src, double* dst, int64_t H, int64_t W, double rho, const DctTables& th,
                             const Ctrl* ctrl, hipStream_t stream, const FinArgs* fin = nullptr, bool fin_pending = false);
+
+// the same row stage as an exact Thomas elimination along the rows (any width, any rho): setup once per run and rho
+// (cp, inv: H x W scratch images holding the elimination factors), then src -> dst per iteration (may alias)
+void launch_tv2d_rows_thomas_setup(int64_t H, int64_t W, double rho, const DctTables& th, double* cp, double* inv,
+                                   hipStream_t stream);
+void launch_tv2d_rows_thomas(const double* src, double* dst, int64_t H, int64_t W, double rho, const double* cp,
+                             const double* inv, const Ctrl* ctrl, hipStream_t stream);
 // dst (cols x rows, column-major) = src (rows x cols, column-major) transposed
 void launch_transpose(const double* src, double* dst, int64_t rows, int64_t cols, const Ctrl* ctrl,
                       hipStream_t stream);

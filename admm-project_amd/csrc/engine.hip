@@ -808,8 +808,7 @@ int admm_engine_create(const admm_problem_desc* desc, admm_engine** out) {
   // as long as the row kernel's truncation fits the width; run() falls back to CG for a rho where it does not)
   // (a height that is not a power of two takes the chirp form of the column transform, dct.hip: any height up to 4096)
   const bool tv2_want_dct = desc->problem == ADMM_PROB_TV2D && desc->xsolve != ADMM_XSOLVE_CG &&
-                            (dct_length_ok(desc->m) || dct_chirp_length_ok(desc->m)) &&
-                            (dct_length_ok(desc->n) || desc->n >= 64);  // (any width the row stage's truncation fits: run())
+                            (dct_length_ok(desc->m) || dct_chirp_length_ok(desc->m));  // (any width: run() picks the row stage)
   if (desc->problem == ADMM_PROB_TV2D) xs = ADMM_XSOLVE_CG;
   if (xs == ADMM_XSOLVE_CG && desc->problem != ADMM_PROB_TV2D && desc->problem != ADMM_PROB_LASSO && desc->problem != ADMM_PROB_LAD &&
       desc->problem != ADMM_PROB_HUBERFIT && desc->problem != ADMM_PROB_LINEARSVM)

@@ -80,6 +80,12 @@ static bool tv2d_rows_green_default(const admm_engine* e, double rho) {
                                                             std::getenv("ADMM_HIP_TV2D_TRANSPOSED") == nullptr));
 }
 
+// the exact tridiagonal row stage (dct.hip) is what is left when neither of the two applies
+static bool tv2d_rows_thomas_default(const admm_engine* e, double rho) {
+  return !tv2d_rows_green_default(e, rho) && !(e->tv2_rows_dct && e->tv2_H % 2 == 0) &&
+         std::getenv("ADMM_HIP_TV2D_NO_THOMAS") == nullptr;
+}
+
 // fin != nullptr: the forward transform's launch carries the finalize logic of the previous iteration (when pending)
 static int dct_solve_tv2d(admm_engine* e, double* y, const FinArgs* fin = nullptr, bool fin_pending = false) {
   TimerScope ts(e, ADMM_K_XSOLVE);
@@ -89,6 +95,14 @@ static int dct_solve_tv2d(admm_engine* e, double* y, const FinArgs* fin = nullpt
   if (tv2d_rows_green_default(e, e->last_opts.rho)) {
     // default: no row transform at all -- the exact Toeplitz kernel of the row operator on the mirrored row (dct.hip)
     launch_tv2d_rows_green(y, e->x, H, W, e->last_opts.rho, e->dctH, e->ctrl, e->stream);
+    launch_dct_cols_inverse(e->x, e->x, H, W, e->dctH, e->ctrl, e->stream);
+    return ADMM_OK;
+  }
+  if (tv2d_rows_thomas_default(e, e->last_opts.rho)) {
+    // neither the Toeplitz form (width / rho) nor a row transform (width not a power of two, or an odd height):
+    // the row systems solved as they stand (dct.hip: tv2d_rows_thomas_kernel; factors in e->cg_p / e->cg_q, set up by
+    // run_total_variation_2d)
+    launch_tv2d_rows_thomas(y, e->x, H, W, e->last_opts.rho, e->cg_p, e->cg_q, e->ctrl, e->stream);
     launch_dct_cols_inverse(e->x, e->x, H, W, e->dctH, e->ctrl, e->stream);
     return ADMM_OK;
   }
@@ -119,9 +133,12 @@ int run_total_variation_2d(admm_engine* e, RunState& rs, admm_run_summary* summa
   if (o.relax != 1.0)
     return fail(ADMM_E_INVALID, "relaxation with the 2-D total-variation prox is a dimension error (D is 2N x N)");
   const int64_t Npix = e->tv2_H * e->tv2_W;
-  // spectral x-update: needs the row DCT (width a power of two) or a rho the Toeplitz row stage covers; else CG
-  // (the row transform works on row PAIRS: an odd height needs the Toeplitz row stage)
-  const bool spectral = e->tv2_dct && ((e->tv2_rows_dct && e->tv2_H % 2 == 0) || tv2d_rows_green_ok(e, o.rho));
+  // spectral x-update: the column DCT, then along the rows the Toeplitz stage (small rho, wide image), the row DCT
+  // (width a power of two, even height: it works on row PAIRS) or the exact tridiagonal solve (anything else)
+  const bool spectral = e->tv2_dct && ((e->tv2_rows_dct && e->tv2_H % 2 == 0) || tv2d_rows_green_ok(e, o.rho) ||
+                                       tv2d_rows_thomas_default(e, o.rho));
+  if (spectral && tv2d_rows_thomas_default(e, o.rho))  // the elimination factors of this run's rho
+    launch_tv2d_rows_thomas_setup(e->tv2_H, e->tv2_W, o.rho, e->dctH, e->cg_p, e->cg_q, e->stream);
   if (e->z != e->tv_zA) {  // the initial iterates were written to e->z / e->u; make buffer A the current one
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_zA, e->z, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));
     ADMM_HIP_TRY(hipMemcpyAsync(e->tv_uA, e->u, sizeof(double) * len, hipMemcpyDeviceToDevice, e->stream));

@@ -72,7 +72,7 @@ for t in range(20):
         o["record_history"] = 0
     got = ap.totalvariation2d(img, 0.6, dict(o))
     ref = S.totalvariation2d(img, 0.6, {k: v for k, v in o.items() if k != "record_history"})
-    spectral = got["cg_iters_total"] == 0  # (CG where the row kernel's truncation does not fit the width: 4 x taps > W)
+    spectral = got["cg_iters_total"] == 0  # (CG where the height has no column transform)
     nspec += spectral
     check("tv2d" if spectral else "tv2d/cg", got, ref, ("xopt", "zopt", "uopt", "pnorm", "dnorm", "objevals"),
           tol=1e-8 if spectral else 1e-6)

@@ -32,16 +32,35 @@ def test_tv2d_matches_oracle(gpu, H, W, opts):
         if k in ref:
             _close(k, got[k], ref[k], 1e-7)
     assert got["xopt"].shape == (H, W)
-    pow2 = all(v >= 8 and v & (v - 1) == 0 for v in (H, W))
-    assert (got["cg_iters_total"] == 0) if pow2 else (got["cg_iters_total"] >= got["steps"])  # spectral x-update
+    spectral = 8 <= H <= 4096  # (the column transform exists; the row stage takes any width)
+    assert (got["cg_iters_total"] == 0) if spectral else (got["cg_iters_total"] >= got["steps"])
 
 
-@pytest.mark.parametrize("H,W,rho", [(170, 110, 2381.0), (61, 75, 4958.0)])
+@pytest.mark.parametrize("H,W,rho", [(170, 110, 2381.0), (61, 75, 4958.0), (24, 17, 1.0), (33, 40, 300.0), (4095, 7, 50.0),
+                                     (64, 1, 3.0), (256, 255, 900.0), (1000, 100, 1.0)])
+def test_tv2d_exact_row_stage_for_any_width_and_rho(gpu, H, W, rho):
+    """Widths below four times the Toeplitz stage's tap count, or a rho whose kernel decays over thousands of columns,
+    on widths that are no power of two: the row systems are solved as they stand (dct.hip: tv2d_rows_thomas_kernel),
+    no CG -- against the oracle's sparse-direct solve at the spectral path's tolerance."""
+    rng = np.random.default_rng(H + W)
+    img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
+    o = dict(objevals=1, maxiters=8, domaxiters=1, rho=rho)
+    got, ref = gpu.totalvariation2d(img, 0.6, dict(o)), S.totalvariation2d(img, 0.6, dict(o))
+    assert got["steps"] == ref["steps"] and got["cg_iters_total"] == 0
+    for k in ("xvals", "zvals", "uvals", "pnorm", "dnorm", "objevals", "xopt"):
+        _close(k, got[k], ref[k], 1e-8)
+    cg = gpu.totalvariation2d(img, 0.6, dict(o, maxiters=2, xsolve="cg"))  # (and the matrix-free path on the same input)
+    assert cg["cg_iters_total"] > 0 and cg["cg_capped_updates"] == 0
+    _close("xvals", cg["xvals"], ref["xvals"][:, :2], 1e-7)
+
+
+@pytest.mark.parametrize("H,W,rho", [(6, 400, 2381.0), (7, 333, 4958.0)])
 def test_tv2d_matrix_free_x_update_with_a_large_rho(gpu, H, W, rho):
-    """No spectral path for these shapes and this rho (the Toeplitz row stage would need ~2000 taps, the width is not
-    a power of two): CG on I + rho*D'D, condition number up to 1 + 8 rho.  The DEFAULT iteration cap follows rho
-    (engine_run_tv.hip: cg_solve_tv2d); with the fixed 500 the x-update stopped short and the iterates were off by 2e-6
-    resp. 2e-4 from the first iteration on (found by tests/sweeps/fuzz_solvers.py with FUZZ_RHO_WIDE=1 FUZZ_SIZE=8)."""
+    """No column transform for fewer than 8 rows: CG on I + rho*D'D, condition number up to 1 + 8 rho.  The DEFAULT
+    iteration cap follows rho
+    (engine_run_tv.hip: cg_solve_tv2d); with the fixed 500 the x-update stopped short and the iterates of 170 x 110 and
+    258 x 265 images -- matrix-free then -- were off by 2e-6 resp. 2e-4 from the first iteration on (found by
+    tests/sweeps/fuzz_solvers.py with FUZZ_RHO_WIDE=1 FUZZ_SIZE=8)."""
     rng = np.random.default_rng(H + W)
     img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
     o = dict(objevals=1, maxiters=6, domaxiters=1, rho=rho)
@@ -84,7 +103,7 @@ def test_tv2d_denoises(gpu):
     assert r["objopt"] == pytest.approx(obj(r["xopt"]), rel=1e-9)
 
 
-@pytest.mark.parametrize("H,W", [(24, 17), (32, 64)])  # CG x-update / spectral x-update
+@pytest.mark.parametrize("H,W", [(5, 17), (24, 17), (32, 64)])  # CG x-update / exact row stage / Toeplitz row stage
 @pytest.mark.parametrize("opts", [dict(fast=1, fasttype="strong", objevals=1, maxiters=60),
                                   dict(fast=1, fasttype="weak", objevals=1, maxiters=25),
                                   dict(fast=1, fasttype="strong", stopcond="both", rho=2.0, maxiters=40)])
@@ -105,11 +124,11 @@ def test_tv2d_fast_admm(gpu, H, W, opts):
 
 
 @pytest.mark.parametrize("H,W,rho,spectral", [(32, 200, 1.0, True), (64, 334, 0.5, True), (16, 1000, 2.0, True),
-                                              (32, 100, 1.0, False), (32, 300, 10.0, False), (64, 333, 0.5, True)])
+                                              (32, 100, 1.0, True), (32, 300, 10.0, True), (64, 333, 0.5, True)])
 def test_tv2d_any_width_when_the_height_is_a_power_of_two(gpu, H, W, rho, spectral):
     """the row stage of the spectral solve is the Toeplitz kernel of the row operator (no row transform), so only the
     height has to be a power of two -- while the kernel's truncation (42 terms per side at rho = 1) is well inside the
-    width (an odd width's last column is both halves of its column pair); otherwise the solve falls back to CG"""
+    width (an odd width's last column is both halves of its column pair); otherwise the exact tridiagonal row stage runs"""
     img = _image(H + W, H, W)
     o = dict(objevals=1, rho=rho, maxiters=30)
     got = gpu.totalvariation2d(img, 0.5, dict(o))
