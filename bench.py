@@ -614,7 +614,7 @@ def main():
     # profiles/collect.sh + summarize.py; bench.py cannot run rocprofv3 on itself): valid for the default size
     traffic = None
     tj = {}
-    for name in ("r3e_traffic.json", "r3d_traffic.json", "r3c_traffic.json", "r3b_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r3f_traffic.json", "r3e_traffic.json", "r3d_traffic.json", "r3c_traffic.json", "r3b_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         tfile = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tfile):
             with open(tfile) as fh:
