@@ -387,3 +387,72 @@ def test_mex_adaptive_rho_stepped_through_create_run_destroy(gpu, mex):
     assert mex.call("livecount") == 0
     assert len(xs) == N and rho != 1.0
     assert _rel(np.stack(xs, axis=1), np.asarray(ref["xvals"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_mex_random_shapes_and_options(gpu, mex, seed):
+    """The gateway under the options the reference's admm takes, at random: shapes down to 2 x 1, rho, relaxation, the
+    accelerated variants, stop conditions, tolerances, forced iteration counts -- lasso.m / lad.m / totalvariation.m
+    argument structs through mexFunction against the oracle (the solver sweep of tests/sweeps does the same through the
+    Python mirror; this one crosses the MEX boundary: struct flattening, option parsing, result packing)."""
+    rng = np.random.default_rng(1000 + seed)
+
+    def loop_options():
+        o = dict(maxiters=int(rng.integers(1, 40)), rho=float(10 ** rng.uniform(-1, 1)), objevals=1)
+        r = rng.random()
+        if r < 0.25:
+            o["relax"] = float(rng.uniform(1.0, 1.8))
+        elif r < 0.45:
+            o.update(fast=1, fasttype="strong")  # (no restarts: none of the reference's knife-edge decisions)
+        r = rng.random()
+        if r < 0.2:
+            o["stopcond"] = "hnorm"
+        elif r < 0.4:
+            o["stopcond"] = "both"
+        if rng.random() < 0.25:
+            o["domaxiters"] = 1
+        if rng.random() < 0.3:
+            o["abstol"], o["reltol"] = float(10 ** rng.uniform(-6, -2)), float(10 ** rng.uniform(-5, -1))
+        return o
+
+    for case in range(8):
+        kind = ("lasso", "lad", "totalvariation")[case % 3]
+        o = loop_options()
+        keys = HIST + ("objevals",)
+        if kind == "lasso":
+            n = int(rng.integers(1, 90))
+            m = int(rng.integers(n + 1, n + 300))
+            p = gpu.synth.lasso_problem(int(rng.integers(1 << 30)), m, n)
+            args = dict(D=p["D"], Dts=p["D"].T @ p["s"], m=m, n=n, parallel=0, rho=o["rho"])
+            args["lambda"] = p["lam"]
+            options = dict(o, A=1, At=1, m=n, nA=n, nB=n, B=-1, c=0, parallel="none")
+            got = mex.call("solve", "lasso", args, options, dict(objnative=1, s=p["s"]))
+            ref = S.lasso(p["D"], p["s"], p["lam"], dict(o))
+        elif kind == "lad":
+            n = int(rng.integers(1, 60))
+            m = int(rng.integers(2 * n + 2, 2 * n + 400))
+            p = gpu.synth.lad_problem(int(rng.integers(1 << 30)), m, n)
+            R = np.linalg.cholesky(p["D"].T @ p["D"])
+            options = dict(o, A=p["D"], At=p["D"].T, B=-1, c=p["s"], m=m, nA=n, nB=m)
+            got = mex.call("solve", "lad", dict(R=R, D=p["D"], s=p["s"]), options, dict(objnative=1))
+            ref = S.lad(p["D"], p["s"], dict(o))
+        else:
+            n = int(rng.integers(2, 3000))
+            p = gpu.synth.tv_problem(int(rng.integers(1 << 30)), n)
+            o.pop("relax", None)  # (the reference's relaxed TV iteration diverges: its own test covers that form)
+            got = mex.call("solve", "totalvariation", {"s": p["s"], "lambda": p["lam"]}, dict(o), dict(objnative=1))
+            ref = S.totalvariation(p["s"], p["lam"], dict(o))
+        assert int(got["steps"]) == ref["steps"], (kind, o)
+        scale = max(float(np.max(np.abs(ref[k]))) for k in ("xopt", "zopt", "uopt"))
+        for k in keys:
+            if k not in ref:
+                continue
+            assert k in got, (kind, k)
+            a, b = np.asarray(got[k], float), np.asarray(ref[k], float)
+            if a.size == b.size and a.shape != b.shape:  # (one iteration: an n x 1 history is a column vector and a 1 x 1
+                a = a.reshape(b.shape)                   #  history a scalar to the harness, as they are to MATLAB)
+            assert a.shape == b.shape, (kind, k, a.shape, b.shape)
+            floor = scale if k in ("xvals", "zvals", "uvals", "xopt", "zopt", "uopt") else (1e-5 * scale if k in ("pnorm", "dnorm") else 0.0)
+            err = float(np.nanmax(np.abs(a - b)) / max(1e-300, floor, np.nanmax(np.abs(b))))
+            assert err < 1e-7, (kind, k, err, o)
