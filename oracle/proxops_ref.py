@@ -87,7 +87,8 @@ def getproxops(problem, args):
             v = ll * Dxplusu
             if loss != "01":  # 1094: anything that is not '01' runs the hinge prox (quirk q18)
                 return Dxplusu + ll * np.maximum(np.minimum(1 - v, C / rho), 0.0)
-            return ll * minz01(v, rho / C)
+            with np.errstate(divide="ignore"):  # MATLAB arithmetic: rho/0 is Inf (C = 0: the threshold 1 - sqrt(2/t) is 1)
+                return ll * minz01(v, np.float64(rho) / np.float64(C))
 
         if "slices" in args:  # 284-303, 1120-1143
             slices = [int(k) for k in args["slices"]]
