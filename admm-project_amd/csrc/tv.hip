@@ -1249,7 +1249,7 @@ int tv_plan(double rho, int64_t n, std::vector<double>* prefix, double* bstar, i
   } else if (H <= 1024) {
     *elems = 20;
     *tile = 256 * 20 - H;
-  } else if (H <= 4096) {
+  } else if (H <= 8192) {  // (beyond 4096 the owned part of a workgroup's 12288 positions shrinks to a third: slow, not wrong)
     *elems = 48;
     *tile = 256 * 48 - H;
   } else {

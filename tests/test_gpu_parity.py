@@ -501,6 +501,7 @@ def test_equality_constrained_solvers_with_a_zero_right_hand_side(gpu, rows, col
     # size, but a window is never longer than the signal (tv_plan; refused before the solver sweep found it)
     (3, 0.21, 430.0, dict(maxiters=33, domaxiters=1)), (10, 6.0, 4800.0, dict(maxiters=23)),
     (3000, 1.0, 6000.0, dict(maxiters=12, domaxiters=1)),
+    (30000, 1.0, 30000.0, dict(maxiters=6, domaxiters=1)),  # halo ~ 7200 of a workgroup's 12288 positions
 ])
 def test_total_variation(gpu, n, lam, rho, opts):
     p = gpu.synth.tv_problem(n % 97, n)
