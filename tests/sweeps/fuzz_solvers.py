@@ -54,6 +54,8 @@ def compare(tag, got, ref, histories=True, iterative=False):
             # iterates that are rounding noise next to the others (u of an interpolating fit) are measured against the
             # largest of x, z, u; norms and tolerances against themselves
             floor = scale if k in ("xvals", "zvals", "uvals", "xopt", "zopt", "uopt") else 0.0
+            if k == "objevals":  # (an exact fit: the objective itself is rounding noise, 1e-30)
+                floor = 1e-12 * max(1.0, scale * scale)
             if k in ("pnorm", "dnorm"):  # a residual that is rounding noise of the iterates (forced iterations past convergence;
                 floor = 1e-5 * scale     # noise = eps * cond * |iterates|, nearly square random matrices reach cond = 1e6)
                 if iterative:            # (xsolve = cg: x carries the 1e-12 relative residual of its solve, times cond)
