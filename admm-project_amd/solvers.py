@@ -360,8 +360,11 @@ def totalvariation2d(S, lam, options=None):
         minimise 1/2*||X - S||_F^2 + lambda*(sum|X[i+1,j] - X[i,j]| + sum|X[i,j+1] - X[i,j]|),
 
     as ADMM on D*x - z = 0 with D = [Dv; Dh] (2N x N forward differences, x = X(:) column-major).  The
-    x-update (I + rho*D'D) x = s + rho*D'(z - u) is solved matrix-free by warm-started CG on the device
-    (``options['cg_tol']``, default 1e-11 relative); nothing is factored.  ``xopt`` is returned as an image.
+    x-update (I + rho*D'D) x = s + rho*D'(z - u) is solved spectrally where the height has a column transform (8 to
+    4096 rows, or a power of two up to 8192): column DCT, a row stage (Toeplitz kernel, row DCT or exact tridiagonal
+    solve, whichever applies to this width and rho), inverse column DCT -- and matrix-free by warm-started CG otherwise
+    or with ``options['xsolve'] = 'cg'`` (``options['cg_tol']``, default 1e-11 relative; ``results['cg_capped_updates']``
+    counts x-updates that ended on the step cap); nothing is factored.  ``xopt`` is returned as an image.
     """
     if options is None:
         options = {}

@@ -48,8 +48,9 @@ enum {
   ADMM_PROB_LINEARPROGRAM = 10,   /* getProxOps.m:459-542, x: 1357-1366 (KKT solve), z: 1378-1382 */
   ADMM_PROB_QP_STANDARD = 11,     /* getProxOps.m:624-630, x: 1397-1412 (KKT solve), z: 1422-1426 */
   ADMM_PROB_TV2D = 12,            /* engine-side extension: 2-D anisotropic TV of an m x n image (D = [Dv; Dh] forward
-                                     differences), x-update by matrix-free CG on I + rho*D'D; no reference counterpart
-                                     (totalvariation.m is 1-D) -- BASELINE config 5 as literally written */
+                                     differences); x-update of I + rho*D'D spectral (column DCT + row stage) where the
+                                     height has a column transform, matrix-free CG otherwise or with ADMM_XSOLVE_CG; no
+                                     reference counterpart (totalvariation.m is 1-D) -- BASELINE config 5 as literally written */
   ADMM_PROB_MODEL = 9             /* getProxOps.m:60-95, x: 952-979, z: 990-1013 (model.m); with both prox
                                      callbacks set and no data it is the generic admm(xminf, zming, options)
                                      of admm.m:24 for A = 1, B = -1 */
