@@ -198,6 +198,11 @@ def run(tag, make):
                     print(f"  {tag} refused ({str(exc)[:70]}): {desc}", flush=True)
                     continue
                 raise
+            if "steps" in got and rng.random() < 0.25:  # run-to-run determinism: fixed-order sums, no float atomics -- a
+                again = got_f()                          # missing barrier or a racing store would show up here
+                for k in ("steps", "xopt", "zopt", "uopt", "pnorm", "dnorm", "objevals"):
+                    if k in got:
+                        assert np.array_equal(np.asarray(got[k]), np.asarray(again[k]), equal_nan=True), ("not reproducible", k)
             if got.get("cg_capped_updates", 0) > 0:  # xsolve='cg' asked for on an ill-conditioned matrix: the run itself
                 capped.append((tag, desc))           # reports x-updates that ended on the iteration cap (inexact by request)
                 continue
