@@ -325,7 +325,7 @@ def mk_tv2d(c):
         H, W = [(1, W), (H, 1), (1, 1)][int(rng.integers(0, 3))]
     img = rng.standard_normal((H, W)) + 2.0 * (rng.random((H, W)) > 0.7)
     lam = float(10 ** rng.uniform(-1, 0.5))
-    o = loop_options(allow_fast=False, allow_relax=False)
+    o = loop_options(allow_fast=True, allow_relax=False)
     o["maxiters"] = min(o["maxiters"], 20) if o["maxiters"] > 0 else 12
     return (f"tv2d {H}x{W} lam {lam:.3g} {o}", lambda: ap.totalvariation2d(img, lam, dict(o)),
             lambda: S.totalvariation2d(img, lam, strip(o)))
