@@ -265,7 +265,7 @@ static int choose_trsv_form(admm_engine* e, SliceFactor& f) {
 
 // W (n x n, ld) holds an SPD matrix in its lower triangle (or receives the caller's factor Lgiven) -> f: the
 // Cholesky factor in place, its inverted 64 x 64 diagonal blocks, and ONE way of applying inv(L L'):
-// want = TRSV: blocked triangular solves; INVERSE / AUTO (n > 256): the explicit inverse if the probe allows it.
+// want = TRSV: blocked triangular solves; INVERSE / AUTO: the explicit inverse if the probe allows it.
 int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int64_t ld, int want, const double* Lgiven,
                        int memkind) {
   f.F = W;
@@ -307,7 +307,10 @@ int build_slice_factor(admm_engine* e, SliceFactor& f, double* W, int64_t n, int
     f.diag_max = hi;
     f.cond_diag = (lo > 0.0) ? (hi / lo) * (hi / lo) : INFINITY;
   }
-  if (want == ADMM_XSOLVE_AUTO) want = (n > 256) ? ADMM_XSOLVE_INVERSE : ADMM_XSOLVE_TRSV;
+  // AUTO: the explicit inverse at every size while the probe below allows it -- one launch per x-update where the
+  // triangular solves take three or more, which is all a small problem pays for (256 x 64, the testers' default:
+  // 20 -> 13 us per iteration)
+  if (want == ADMM_XSOLVE_AUTO) want = ADMM_XSOLVE_INVERSE;
   // the blocked triangular solves are built in every case: they are the fallback and the probe's yardstick
   ADMM_TRY(e->mem.alloc(&f.work, trsv_plan_elems(n)));
   ADMM_TRY(trsv_build(W, n, ld, f.dinv, f.work, &f.trsv, e->stream));

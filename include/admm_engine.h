@@ -63,7 +63,7 @@ enum { ADMM_LOSS_HINGE = 0, ADMM_LOSS_01 = 1,
 
 /* how the cached-factor x-update is applied every iteration */
 enum {
-  ADMM_XSOLVE_AUTO = 0,    /* TRSV up to n = 256; beyond, INVERSE if it passes the accuracy probe below, else TRSV */
+  ADMM_XSOLVE_AUTO = 0,    /* INVERSE if it passes the accuracy probe below, else TRSV */
   ADMM_XSOLVE_TRSV = 1,    /* two triangular solves with the Cholesky factor (reference form: getProxOps.m:1200, 1514),
                               as blocked substitution: 2K + 1 bandwidth-bound launches, K = ceil(n / 2048) */
   ADMM_XSOLVE_INVERSE = 2, /* one symmetric n x n GEMV with the explicit inverse, built once.  Its forward error grows
