@@ -53,7 +53,8 @@ def compare(tag, got, ref, histories=True, iterative=False):
             assert k in got, f"field {k} missing"
             # iterates that are rounding noise next to the others (u of an interpolating fit) are measured against the
             # largest of x, z, u; norms and tolerances against themselves
-            floor = scale if k in ("xvals", "zvals", "uvals", "xopt", "zopt", "uopt") else 0.0
+            # (inputs are O(1): a solution that is exactly zero is compared at 1e-13 absolute)
+            floor = max(scale, 1e-7) if k in ("xvals", "zvals", "uvals", "xopt", "zopt", "uopt") else 0.0
             if k == "objevals":  # (an exact fit: the objective itself is rounding noise, 1e-30)
                 floor = 1e-12 * max(1.0, scale * scale)
             if k in ("pnorm", "dnorm"):  # a residual that is rounding noise of the iterates (forced iterations past convergence;
@@ -61,7 +62,10 @@ def compare(tag, got, ref, histories=True, iterative=False):
                 if iterative:            # (xsolve = cg: x carries the 1e-12 relative residual of its solve, times cond)
                     floor = 1e-3 * scale
             ek = rel(got[k], ref[k], floor)
-            assert ek < TOL, (k, ek)
+            # (rho from 1e-4 to 1e4: factors with condition numbers of 1e6 and an objective whose terms cancel to a small
+            # misfit -- iterates that agree to 1e-9 give objectives that agree to 1e-5)
+            tol = 1e-4 if k == "objevals" and os.environ.get("FUZZ_RHO_WIDE") else TOL
+            assert ek < tol, (k, ek)
             e = max(e, ek)
     return e
 
